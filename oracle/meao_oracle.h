@@ -1,0 +1,111 @@
+/*
+ * meao_oracle.h -- CPU oracle for the multi-scale SSAO hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported baseline.  The
+ * product path (libmeao_hip.so) never links, loads or calls it.
+ *
+ * PARITY PIN: the reference (keijiro/MiniEngineAO) ships no golden vectors,
+ * no tests and cannot be executed here (Unity + HLSL + C#, none available),
+ * so parity against reference *outputs* is unpinned.  The pin used instead
+ *  is: two independently structured restatements of the
+ * same source -- this file's per-pixel gather form and meao_hlsl_emul.c's
+ * literal thread-group/LDS emulation -- must agree bit-for-bit on all 17
+ * intermediates, plus the analytical known-answer tests derived from the
+ * reference source (tests/test_oracle_kat.py).
+ *
+ * Canonical numerics (DESIGN.md "Numerics contract"): IEEE-754 binary32,
+ * round-to-nearest-even, correctly rounded '/' and sqrt; an HLSL expression
+ * of the shape a*b+c / a*b-c / c-a*b is a single `mad` and is evaluated
+ * fused (fmaf); everything else is separately rounded (-ffp-contract=off).
+ */
+#ifndef MEAO_ORACLE_H
+#define MEAO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MEAO_ORACLE_AO_R8 = 0, MEAO_ORACLE_AO_F16 = 1 };
+enum { MEAO_ORACLE_F16_RTZ = 0, MEAO_ORACLE_F16_RTNE = 1 };
+
+/* Everything the reference component + camera feed into the path
+ * (AmbientOcclusion.cs:20-68 properties; :561-573 camera terms). */
+typedef struct meao_oracle_desc {
+    int32_t width, height;        /* camera.pixelWidth/Height  (AO.cs:339-340) */
+    int32_t num_levels;           /* 1..4; the reference always runs 4        */
+    int32_t ao_format;            /* R8 = reference (AO.cs:466-475) or F16    */
+    int32_t f16_rounding;         /* store conversion f32->f16                */
+    int32_t reversed_z;           /* SystemInfo.usesReversedZBuffer           */
+    float noise_filter_tolerance; /* AO.cs:20  default  0    */
+    float blur_tolerance;         /* AO.cs:28  default -4.6  */
+    float upsample_tolerance;     /* AO.cs:36  default -12   */
+    float thickness_modifier;     /* AO.cs:44  default  1    */
+    float intensity;              /* AO.cs:52  default  1    */
+    float near_clip, far_clip;    /* AO.cs:563 */
+    float proj00;                 /* camera.projectionMatrix[0,0] (AO.cs:572) */
+} meao_oracle_desc;
+
+/* The 17 debug-visible buffers (AO.cs:789-808) + nothing else.  Any pointer
+ * may be NULL: the oracle then uses a private scratch buffer for it.
+ * AO buffers are uint8 (R8) or uint16 f16 bit patterns (F16). */
+typedef struct meao_oracle_buffers {
+    uint16_t *linear_depth;    /* id 1      f16 bits, L0                 */
+    float    *low_depth[4];    /* id 2..5   f32, L1..L4                  */
+    uint16_t *tiled_depth[4];  /* id 6..9   f16 bits, [16][h][w] L3..L6  */
+    void     *occlusion[4];    /* id 10..13 AO, L1..L4                   */
+    void     *combined[3];     /* id 14..16 AO, L1..L3                   */
+    void     *result;          /* id 17     AO, L0                       */
+} meao_oracle_buffers;
+
+/* Constant blocks, exactly what AO.cs uploads per dispatch. */
+typedef struct meao_oracle_render_consts {
+    float inv_thickness[12];   /* gInvThicknessTable  AO.cs:687-688 */
+    float sample_weight[12];   /* gSampleWeightTable  AO.cs:696-724 */
+    float inv_slice_dim[2];    /* gInvSliceDimension  AO.cs:732     */
+    float reject_fadeoff;      /* AO.cs:733 */
+    float intensity;           /* AO.cs:734 */
+} meao_oracle_render_consts;
+
+typedef struct meao_oracle_upsample_consts {
+    float inv_low_res[2], inv_high_res[2];   /* AO.cs:766-767 */
+    float noise_filter_strength;             /* AO.cs:764,768 */
+    float step_size;                         /* AO.cs:760,769 */
+    float blur_tolerance;                    /* AO.cs:761-762,770 */
+    float upsample_tolerance;                /* AO.cs:763,771 */
+} meao_oracle_upsample_consts;
+
+/* level k dims = ceil(W / 2^k)  (AO.cs:276-281) */
+void meao_oracle_level_dims(int32_t width, int32_t height, int32_t level,
+                            int32_t *w, int32_t *h);
+void meao_oracle_zbuffer_params(const meao_oracle_desc *d, float zp[4]);
+void meao_oracle_sample_thickness(float out[12]);
+/* level = 1..4: source atlas is TiledDepth<level> (dims of mip level+2). */
+void meao_oracle_render_constants(const meao_oracle_desc *d, int32_t level,
+                                  meao_oracle_render_consts *out);
+/* low_level = mip level of the low-res input (1..4), high = low_level-1. */
+void meao_oracle_upsample_constants(const meao_oracle_desc *d, int32_t low_level,
+                                    meao_oracle_upsample_consts *out);
+
+/* Storage conversions (exposed so tests can pin them). */
+uint16_t meao_oracle_f32_to_f16(float x, int32_t rounding);
+float    meao_oracle_f16_to_f32(uint16_t h);
+uint8_t  meao_oracle_f32_to_unorm8(float x);
+float    meao_oracle_unorm8_to_f32(uint8_t v);
+
+/* Full pipeline, gather form.  nthreads <= 1 -> scalar single core.
+ * Returns 0 on success, negative on bad arguments / allocation failure. */
+int32_t meao_oracle_run(const meao_oracle_desc *d, const float *depth,
+                        meao_oracle_buffers *out, int32_t nthreads);
+
+/* Same contract, literal HLSL thread-group emulation (meao_hlsl_emul.c). */
+int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const float *depth,
+                           meao_oracle_buffers *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
