@@ -1,0 +1,204 @@
+/*
+ * meao.h -- C ABI of libmeao_hip.so: the MI355X-native (gfx950 / CDNA4) multi-scale
+ * SSAO hot path of keijiro/MiniEngineAO.   depth in  ->  ambient-occlusion texture out.
+ *
+ * What this boundary replaces.  The reference has no FFI: the path sits behind the Unity
+ * component MiniEngineAO.AmbientOcclusion (Assets/MiniEngineAO/AmbientOcclusion.cs, "AO.cs"
+ * below), which records ten compute dispatches into a CommandBuffer
+ * (AO.cs:496-531 RebuildCommandBuffers).  Every entry point below names the reference
+ * lines it stands in for; INTEGRATION.md shows the C# [DllImport] stub and the
+ * AmbientOcclusion wrapper a maintainer would add on the reference side.
+ *
+ * Conventions: plain C, no C++ or torch types; every function returns a meao_status
+ * (0 = ok, negative = error) unless stated; no exception crosses the boundary; a context
+ * is not thread-safe, distinct contexts are independent (no global state -- the reference's
+ * shared statics AO.cs:136-137,592-593 are per-context here); one context per device.
+ * The caller owns the input depth and output AO memory; the context owns every
+ * intermediate and never allocates inside meao_execute*.
+ */
+#ifndef MEAO_H
+#define MEAO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MEAO_API __attribute__((visibility("default")))
+#else
+#define MEAO_API
+#endif
+
+#define MEAO_ABI_VERSION 1
+#define MEAO_MAX_BATCH 16      /* frames per batched launch */
+#define MEAO_NUM_PASSES 6      /* downsample, render, upsample x4 (see meao_pass) */
+
+typedef struct meao_ctx meao_ctx;
+typedef void *meao_stream;     /* hipStream_t; NULL = the context's own stream */
+
+typedef enum meao_status {
+    MEAO_OK = 0,
+    MEAO_ERR_INVALID_ARGUMENT = -1,
+    MEAO_ERR_HIP = -2,            /* HIP runtime error; text via meao_last_error */
+    MEAO_ERR_OUT_OF_MEMORY = -3,
+    MEAO_ERR_UNSUPPORTED = -4,
+    MEAO_ERR_NO_DEVICE = -5,      /* no gfx950 device visible: there is no CPU fallback */
+    MEAO_ERR_BUFFER_TOO_SMALL = -6
+} meao_status;
+
+/* Storage of the AO targets.  R8 = the reference's FixedUAV / RenderTextureFormat.R8
+ * (AO.cs:262-273,466-475): AO is quantised to 8 bits between every pass.  F16 = fp16 AO
+ * storage (BASELINE config 5). */
+typedef enum meao_ao_format { MEAO_AO_R8 = 0, MEAO_AO_F16 = 1 } meao_ao_format;
+
+/* f32 -> f16 store conversion of the HalfUAV targets (AO.cs:454).  RTZ_CLAMP (round toward
+ * zero, finite overflow -> 65504) is canonical; RTNE (overflow -> inf) is the other common
+ * hardware behaviour.  Only matters for sky texels (1e5) and the last mantissa bit. */
+typedef enum meao_f16_rounding { MEAO_F16_RTZ_CLAMP = 0, MEAO_F16_RTNE = 1 } meao_f16_rounding;
+
+/* STRICT: bit-exact against the CPU oracle (IEEE '/', explicit mad fusion only). */
+typedef enum meao_numerics { MEAO_NUMERICS_STRICT = 0 } meao_numerics;
+
+typedef enum meao_mem { MEAO_MEM_HOST = 0, MEAO_MEM_DEVICE = 1 } meao_mem;
+
+typedef enum meao_format { MEAO_FMT_F32 = 0, MEAO_FMT_F16 = 1, MEAO_FMT_UNORM8 = 2 } meao_format;
+
+/* Kernel launches of one frame/batch, in stream order. */
+typedef enum meao_pass {
+    MEAO_PASS_DOWNSAMPLE = 0,  /* Downsample1.main + Downsample2.main fused  (AO.cs:627-657) */
+    MEAO_PASS_RENDER = 1,      /* Render.main_interleaved, all levels, one grid (AO.cs:519-522) */
+    MEAO_PASS_UPSAMPLE_3 = 2,  /* Upsample.main_blendout L4 -> L3             (AO.cs:528) */
+    MEAO_PASS_UPSAMPLE_2 = 3,  /* Upsample.main_blendout L3 -> L2             (AO.cs:529) */
+    MEAO_PASS_UPSAMPLE_1 = 4,  /* Upsample.main_blendout L2 -> L1             (AO.cs:530) */
+    MEAO_PASS_UPSAMPLE_0 = 5   /* Upsample.main          L1 -> L0 result      (AO.cs:531) */
+} meao_pass;
+
+/* What DoLazyInitialization + RTHandle sizing fix per instance (AO.cs:440-476,276-281). */
+typedef struct meao_config {
+    uint32_t struct_size;   /* sizeof(meao_config), for ABI evolution */
+    int32_t device;         /* HIP device ordinal */
+    int32_t width, height;  /* camera.pixelWidth / pixelHeight (AO.cs:339-340) */
+    int32_t num_levels;     /* 1..4; the reference always runs 4 (AO.cs:519-531) */
+    int32_t ao_format;      /* meao_ao_format */
+    int32_t f16_rounding;   /* meao_f16_rounding */
+    int32_t numerics;       /* meao_numerics */
+    int32_t max_batch;      /* 1..MEAO_MAX_BATCH frames resident per launch */
+} meao_config;
+
+/* The component's serialized properties (AO.cs:20-68; defaults there) and the camera terms
+ * the path reads (AO.cs:561-573). */
+typedef struct meao_params {
+    uint32_t struct_size;
+    float noise_filter_tolerance;   /* [-8, 0]   default  0     AO.cs:20 */
+    float blur_tolerance;           /* [-8,-1]   default -4.6   AO.cs:28 */
+    float upsample_tolerance;       /* [-12,-1]  default -12    AO.cs:36 */
+    float thickness_modifier;       /* [1, 10]   default  1     AO.cs:44 */
+    float intensity;                /* [0, 2]    default  1     AO.cs:52 */
+    float near_clip, far_clip;      /* camera.nearClipPlane / farClipPlane  AO.cs:563 */
+    float proj00;                   /* camera.projectionMatrix[0,0]         AO.cs:572 */
+    int32_t reversed_z;             /* SystemInfo.usesReversedZBuffer       AO.cs:564 */
+} meao_params;
+
+/* Description of one of the 17 debug-visible buffers (AO.cs:789-808). */
+typedef struct meao_desc {
+    int32_t debug_id;       /* 1..17 */
+    int32_t width, height;
+    int32_t slices;         /* 16 for TiledDepth1..4 (AO.cs:154), else 1 */
+    int32_t format;         /* meao_format */
+    uint64_t bytes;         /* width*height*slices*element size */
+} meao_desc;
+
+/* Constant buffers exactly as the reference uploads them. */
+typedef struct meao_render_constants {   /* CB1 of Render.compute:38-44, AO.cs:687-734 */
+    float inv_thickness_table[12];
+    float sample_weight_table[12];
+    float inv_slice_dimension[2];
+    float reject_fadeoff;
+    float intensity;
+} meao_render_constants;
+
+typedef struct meao_upsample_constants { /* CB1 of Upsample.compute:41-48, AO.cs:760-771 */
+    float inv_low_resolution[2];
+    float inv_high_resolution[2];
+    float noise_filter_strength;
+    float step_size;
+    float blur_tolerance;
+    float upsample_tolerance;
+} meao_upsample_constants;
+
+/* ---- library ------------------------------------------------------------------------ */
+MEAO_API int32_t meao_abi_version(void);
+MEAO_API const char *meao_status_string(int32_t status);
+/* Fills the reference defaults (4 levels, R8, RTZ, strict, batch 1; AO.cs:20-68). */
+MEAO_API void meao_default_config(meao_config *cfg);
+MEAO_API void meao_default_params(meao_params *p);
+
+/* ---- host-side plan: pure CPU, usable without a GPU ------------------------------------ */
+/* RTHandle.CalculateDimensions (AO.cs:276-281): ceil(W / 2^level), level 0..6. */
+MEAO_API int32_t meao_level_dims(int32_t width, int32_t height, int32_t level,
+                                 int32_t *out_w, int32_t *out_h);
+/* CalculateZBufferParams (AO.cs:561-568). */
+MEAO_API int32_t meao_zbuffer_params(const meao_params *p, float out[4]);
+/* PushRenderCommands constant math (AO.cs:660-734) for level 1..4. */
+MEAO_API int32_t meao_render_constants_for(int32_t width, int32_t height, const meao_params *p,
+                                           int32_t level, meao_render_constants *out);
+/* PushUpsampleCommands constant math (AO.cs:750-771); low_level 1..4 is the mip of LoResDB. */
+MEAO_API int32_t meao_upsample_constants_for(int32_t width, int32_t height, const meao_params *p,
+                                             int32_t low_level, meao_upsample_constants *out);
+/* Buffer table (AO.cs:453-475): dims/format/bytes of debug buffer 1..17. */
+MEAO_API int32_t meao_describe_buffer(const meao_config *cfg, int32_t debug_id, meao_desc *out);
+/* Compulsory traffic of each pass in the reference's storage formats (SURVEY.md 8d,
+ * BASELINE.md 3): the numerator of the roofline fraction.  bytes[MEAO_NUM_PASSES]. */
+MEAO_API int32_t meao_algorithmic_bytes(const meao_config *cfg, uint64_t bytes[MEAO_NUM_PASSES]);
+
+/* ---- context (replaces DoLazyInitialization / OnDestroy, AO.cs:440-494,357-381) --------- */
+MEAO_API int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx);
+MEAO_API int32_t meao_destroy(meao_ctx *ctx);
+/* Screen-size change (AO.cs:338-341,501): re-plans and re-allocates the intermediates. */
+MEAO_API int32_t meao_resize(meao_ctx *ctx, int32_t width, int32_t height);
+/* Property change (AO.cs:104-113): recomputes the per-level constant blocks. */
+MEAO_API int32_t meao_set_params(meao_ctx *ctx, const meao_params *p);
+MEAO_API int32_t meao_get_params(const meao_ctx *ctx, meao_params *out);
+MEAO_API int32_t meao_get_config(const meao_ctx *ctx, meao_config *out);
+/* Last error text of this context ("" if none).  Never NULL; ctx may be NULL. */
+MEAO_API const char *meao_last_error(const meao_ctx *ctx);
+
+/* ---- the hot path (replaces the recorded "SSAO" CommandBuffer, AO.cs:496-531) ----------- */
+/* depth: width*height float32 raw device depth, row-major, tightly packed
+ *        (_CameraDepthTexture / ResolvedDepth, AO.cs:608-641).
+ * ao_out: width*height AO texels in cfg.ao_format (the "AmbientOcclusion" RT, AO.cs:475).
+ * *_loc: meao_mem; HOST pointers are staged through context-owned device buffers.
+ * Asynchronous on `stream` for DEVICE/DEVICE; returns after completion if either is HOST. */
+MEAO_API int32_t meao_execute(meao_ctx *ctx, const void *depth, int32_t depth_loc,
+                              void *ao_out, int32_t out_loc, meao_stream stream);
+/* n independent frames (n <= cfg.max_batch) through one launch per pass. */
+MEAO_API int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth,
+                                    int32_t depth_loc, void *const *ao_out, int32_t out_loc,
+                                    meao_stream stream);
+MEAO_API int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream);
+
+/* ---- observability (replaces the _debug 1..17 views, AO.cs:787-820) --------------------- */
+/* Copies debug buffer `debug_id` of batch slot `frame` (as left by the last execute) to dst
+ * in the reference's layout (TiledDepth: [16][h][w]).  dst may be NULL to query desc only. */
+MEAO_API int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id,
+                                       void *dst, uint64_t dst_capacity, int32_t dst_loc,
+                                       meao_desc *out_desc);
+
+/* Per-pass device timing: when enabled, meao_execute* brackets every pass with HIP events on
+ * the launch stream; meao_get_pass_times averages them over the executes since the last reset
+ * (synchronises the stream).  ms[MEAO_NUM_PASSES]; passes not run report 0. */
+MEAO_API int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable);
+MEAO_API int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *out_samples);
+
+/* Exhaustive device self-tests of the storage conversions and exact-division sequences the
+ * kernels rely on; returns the number of mismatching inputs in *out_mismatches.
+ * which: 0 = f32->f16 RTZ_CLAMP, 1 = f32->f16 RTNE, 2 = f32->unorm8, 3 = unorm8->f32. */
+MEAO_API int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEAO_H */

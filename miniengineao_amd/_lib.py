@@ -1,0 +1,128 @@
+"""ctypes binding of libmeao_hip.so -- the C ABI declared in include/meao.h.
+
+The library is the product; this module only declares its signatures.  There is no CPU
+fallback: if the shared object is missing the import of the hot path fails loudly, and on a
+machine without a gfx950 device ``meao_create`` returns MEAO_ERR_NO_DEVICE.
+
+HIP runtime note: if ``torch`` is going to be used in the same process, import it *before*
+this module loads the library, so both share torch's bundled ``libamdhip64.so.7`` (same
+SONAME as /opt/rocm's; the dynamic loader then resolves ours to the already-loaded copy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmeao_hip.so")
+
+ABI_VERSION = 1
+MAX_BATCH = 16
+NUM_PASSES = 6
+PASS_NAMES = ("downsample", "render", "upsample_L4_to_L3", "upsample_L3_to_L2",
+              "upsample_L2_to_L1", "upsample_L1_to_L0")
+
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_OUT_OF_MEMORY = -1, -2, -3
+ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL = -4, -5, -6
+AO_R8, AO_F16 = 0, 1
+F16_RTZ_CLAMP, F16_RTNE = 0, 1
+NUMERICS_STRICT = 0
+MEM_HOST, MEM_DEVICE = 0, 1
+FMT_F32, FMT_F16, FMT_UNORM8 = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("num_levels", C.c_int32), ("ao_format", C.c_int32),
+                ("f16_rounding", C.c_int32), ("numerics", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("noise_filter_tolerance", C.c_float),
+                ("blur_tolerance", C.c_float), ("upsample_tolerance", C.c_float),
+                ("thickness_modifier", C.c_float), ("intensity", C.c_float),
+                ("near_clip", C.c_float), ("far_clip", C.c_float), ("proj00", C.c_float),
+                ("reversed_z", C.c_int32)]
+
+
+class Desc(C.Structure):
+    _fields_ = [("debug_id", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("slices", C.c_int32), ("format", C.c_int32), ("bytes", C.c_uint64)]
+
+
+class RenderConstants(C.Structure):
+    _fields_ = [("inv_thickness_table", C.c_float * 12), ("sample_weight_table", C.c_float * 12),
+                ("inv_slice_dimension", C.c_float * 2), ("reject_fadeoff", C.c_float),
+                ("intensity", C.c_float)]
+
+
+class UpsampleConstants(C.Structure):
+    _fields_ = [("inv_low_resolution", C.c_float * 2), ("inv_high_resolution", C.c_float * 2),
+                ("noise_filter_strength", C.c_float), ("step_size", C.c_float),
+                ("blur_tolerance", C.c_float), ("upsample_tolerance", C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/meao.h declares
+SIGNATURES = {
+    "meao_abi_version": (C.c_int32, []),
+    "meao_status_string": (C.c_char_p, [C.c_int32]),
+    "meao_default_config": (None, [C.POINTER(Config)]),
+    "meao_default_params": (None, [C.POINTER(Params)]),
+    "meao_level_dims": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "meao_zbuffer_params": (C.c_int32, [C.POINTER(Params), C.POINTER(C.c_float * 4)]),
+    "meao_render_constants_for": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(Params), C.c_int32, C.POINTER(RenderConstants)]),
+    "meao_upsample_constants_for": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(Params), C.c_int32, C.POINTER(UpsampleConstants)]),
+    "meao_describe_buffer": (C.c_int32, [C.POINTER(Config), C.c_int32, C.POINTER(Desc)]),
+    "meao_algorithmic_bytes": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_uint64 * NUM_PASSES)]),
+    "meao_create": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "meao_destroy": (C.c_int32, [C.c_void_p]),
+    "meao_resize": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "meao_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
+    "meao_get_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
+    "meao_get_config": (C.c_int32, [C.c_void_p, C.POINTER(Config)]),
+    "meao_last_error": (C.c_char_p, [C.c_void_p]),
+    "meao_execute": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "meao_execute_batch": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                       C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "meao_synchronize": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "meao_get_intermediate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64,
+                                          C.c_int32, C.POINTER(Desc)]),
+    "meao_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "meao_get_pass_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float * NUM_PASSES), C.POINTER(C.c_int32)]),
+    "meao_selftest": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+class MeaoError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"meao status {status}: {message}")
+        self.status = status
+
+
+def load() -> C.CDLL:
+    """Load libmeao_hip.so (built by ``python -m miniengineao_amd.build``).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m miniengineao_amd.build` "
+                "(hipcc, gfx950).  There is no CPU fallback for the SSAO hot path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if the ABI lost a symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.meao_abi_version() != ABI_VERSION:
+            raise ImportError(f"libmeao_hip.so ABI {lib.meao_abi_version()} != binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(status: int, ctx=None) -> None:
+    if status != OK:
+        lib = load()
+        detail = lib.meao_last_error(ctx).decode() or lib.meao_status_string(status).decode()
+        raise MeaoError(status, detail)

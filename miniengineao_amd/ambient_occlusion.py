@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference component ``MiniEngineAO.AmbientOcclusion``
+(Assets/MiniEngineAO/AmbientOcclusion.cs, "AO.cs") over the C ABI of libmeao_hip.so.
+
+The reference is a Unity MonoBehaviour: six public properties (AO.cs:22-66), implicit camera
+inputs (AO.cs:339-340,563-573), depth texture in, "AmbientOcclusion" R8 texture out
+(AO.cs:475,824).  This class keeps the property names and meaning; what Unity did implicitly
+(camera, depth texture, render-texture output) is explicit here.  Property changes are picked
+up lazily before the next frame, like CheckPropertiesChanged (AO.cs:104-113).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+_NP_OF_FMT = {L.FMT_F32: np.float32, L.FMT_F16: np.uint16, L.FMT_UNORM8: np.uint8}
+
+# _debug values (AO.cs:789-808)
+DEBUG_BUFFER_NAMES = {
+    1: "LinearDepth", 2: "LowDepth1", 3: "LowDepth2", 4: "LowDepth3", 5: "LowDepth4",
+    6: "TiledDepth1", 7: "TiledDepth2", 8: "TiledDepth3", 9: "TiledDepth4",
+    10: "Occlusion1", 11: "Occlusion2", 12: "Occlusion3", 13: "Occlusion4",
+    14: "Combined1", 15: "Combined2", 16: "Combined3", 17: "AmbientOcclusion",
+}
+
+
+class AmbientOcclusion:
+    """depth in -> AO texture out, on one MI355X.  One instance per device."""
+
+    def __init__(self, width: int, height: int, *, device: int = 0, num_levels: int = 4,
+                 ao_format: int = L.AO_R8, f16_rounding: int = L.F16_RTZ_CLAMP,
+                 max_batch: int = 1, near_clip: float = 0.3, far_clip: float = 1000.0,
+                 projection00: Optional[float] = None, reversed_z: bool = True):
+        self._lib = L.load()
+        cfg = L.Config()
+        self._lib.meao_default_config(C.byref(cfg))
+        cfg.device, cfg.width, cfg.height = device, width, height
+        cfg.num_levels, cfg.ao_format, cfg.f16_rounding = num_levels, ao_format, f16_rounding
+        cfg.max_batch = max_batch
+        self._cfg = cfg
+        prm = L.Params()
+        self._lib.meao_default_params(C.byref(prm))
+        prm.near_clip, prm.far_clip = near_clip, far_clip
+        if projection00 is not None:
+            prm.proj00 = projection00
+        prm.reversed_z = 1 if reversed_z else 0
+        self._prm = prm
+        self._ambient_only = True          # AO.cs:68; composite-only flag, kept for surface parity
+        self._debug = 0                    # AO.cs:60
+        self._dirty = True
+        self._ctx = C.c_void_p()
+        L.check(self._lib.meao_create(C.byref(cfg), C.byref(self._ctx)))
+
+    # ---- the six public properties of the reference (AO.cs:22-66) ----------------------
+    def _get(self, name):
+        return getattr(self._prm, name)
+
+    def _set(self, name, value):
+        if getattr(self._prm, name) != value:   # CheckUpdate (AO.cs:91-102)
+            setattr(self._prm, name, value)
+            self._dirty = True
+
+    noiseFilterTolerance = property(lambda s: s._get("noise_filter_tolerance"),
+                                    lambda s, v: s._set("noise_filter_tolerance", float(v)))
+    blurTolerance = property(lambda s: s._get("blur_tolerance"),
+                             lambda s, v: s._set("blur_tolerance", float(v)))
+    upsampleTolerance = property(lambda s: s._get("upsample_tolerance"),
+                                 lambda s, v: s._set("upsample_tolerance", float(v)))
+    thicknessModifier = property(lambda s: s._get("thickness_modifier"),
+                                 lambda s, v: s._set("thickness_modifier", float(v)))
+    intensity = property(lambda s: s._get("intensity"), lambda s, v: s._set("intensity", float(v)))
+
+    @property
+    def ambientOnly(self) -> bool:
+        return self._ambient_only
+
+    @ambientOnly.setter
+    def ambientOnly(self, value: bool) -> None:
+        self._ambient_only = bool(value)
+
+    # ---- camera terms Unity supplied implicitly (AO.cs:563-573) ------------------------
+    nearClipPlane = property(lambda s: s._get("near_clip"), lambda s, v: s._set("near_clip", float(v)))
+    farClipPlane = property(lambda s: s._get("far_clip"), lambda s, v: s._set("far_clip", float(v)))
+    projection00 = property(lambda s: s._get("proj00"), lambda s, v: s._set("proj00", float(v)))
+    usesReversedZBuffer = property(lambda s: bool(s._get("reversed_z")),
+                                   lambda s, v: s._set("reversed_z", 1 if v else 0))
+
+    # ---- geometry ----------------------------------------------------------------------
+    width = property(lambda s: s._cfg.width)
+    height = property(lambda s: s._cfg.height)
+    ao_format = property(lambda s: s._cfg.ao_format)
+    max_batch = property(lambda s: s._cfg.max_batch)
+    ao_dtype = property(lambda s: np.uint8 if s._cfg.ao_format == L.AO_R8 else np.uint16)
+
+    def resize(self, width: int, height: int) -> None:
+        """Screen-size change (AO.cs:338-341)."""
+        L.check(self._lib.meao_resize(self._ctx, width, height), self._ctx)
+        self._cfg.width, self._cfg.height = width, height
+
+    def _sync_params(self) -> None:
+        if self._dirty:
+            L.check(self._lib.meao_set_params(self._ctx, C.byref(self._prm)), self._ctx)
+            self._dirty = False
+
+    # ---- the hot path ------------------------------------------------------------------
+    def render(self, depth: np.ndarray) -> np.ndarray:
+        """One frame, host arrays: float32 (H, W) raw depth -> AO (H, W) uint8 / f16 bits."""
+        return self.render_batch([depth])[0]
+
+    def render_batch(self, depths: Sequence[np.ndarray]) -> list:
+        n = len(depths)
+        self._sync_params()
+        ins = [np.ascontiguousarray(d, dtype=np.float32) for d in depths]
+        for d in ins:
+            if d.shape != (self.height, self.width):
+                raise ValueError(f"depth shape {d.shape} != ({self.height}, {self.width})")
+        outs = [np.empty((self.height, self.width), self.ao_dtype) for _ in range(n)]
+        pin = (C.c_void_p * n)(*[d.ctypes.data for d in ins])
+        pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        L.check(self._lib.meao_execute_batch(self._ctx, n, pin, L.MEM_HOST, pout, L.MEM_HOST, None), self._ctx)
+        return outs
+
+    def execute_device(self, depth_ptrs: Sequence[int], out_ptrs: Sequence[int], stream: int = 0) -> None:
+        """Device-resident frames (raw device addresses, e.g. torch ``data_ptr()``); asynchronous."""
+        n = len(depth_ptrs)
+        self._sync_params()
+        pin = (C.c_void_p * n)(*depth_ptrs)
+        pout = (C.c_void_p * n)(*out_ptrs)
+        L.check(self._lib.meao_execute_batch(self._ctx, n, pin, L.MEM_DEVICE, pout, L.MEM_DEVICE,
+                                             C.c_void_p(stream) if stream else None), self._ctx)
+
+    def synchronize(self, stream: int = 0) -> None:
+        L.check(self._lib.meao_synchronize(self._ctx, C.c_void_p(stream) if stream else None), self._ctx)
+
+    # ---- observability (the _debug views, AO.cs:787-820) -------------------------------
+    def debug_buffer(self, debug_id: int, frame: int = 0) -> np.ndarray:
+        d = L.Desc()
+        L.check(self._lib.meao_get_intermediate(self._ctx, frame, debug_id, None, 0, L.MEM_HOST, C.byref(d)), self._ctx)
+        shape = (d.slices, d.height, d.width) if d.slices > 1 else (d.height, d.width)
+        out = np.empty(shape, _NP_OF_FMT[d.format])
+        L.check(self._lib.meao_get_intermediate(self._ctx, frame, debug_id, out.ctypes.data, out.nbytes,
+                                                L.MEM_HOST, C.byref(d)), self._ctx)
+        return out
+
+    def set_profiling(self, enable: bool) -> None:
+        L.check(self._lib.meao_set_profiling(self._ctx, 1 if enable else 0), self._ctx)
+
+    def pass_times_ms(self):
+        ms = (C.c_float * L.NUM_PASSES)()
+        n = C.c_int32()
+        L.check(self._lib.meao_get_pass_times(self._ctx, C.byref(ms), C.byref(n)), self._ctx)
+        return list(ms), n.value
+
+    def algorithmic_bytes(self):
+        b = (C.c_uint64 * L.NUM_PASSES)()
+        L.check(self._lib.meao_algorithmic_bytes(C.byref(self._cfg), C.byref(b)))
+        return list(b)
+
+    def selftest(self, which: int) -> int:
+        n = C.c_uint64()
+        L.check(self._lib.meao_selftest(self._ctx, which, C.byref(n)), self._ctx)
+        return n.value
+
+    def close(self) -> None:
+        if self._ctx:
+            self._lib.meao_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

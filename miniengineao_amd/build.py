@@ -1,0 +1,71 @@
+"""Builds libmeao_hip.so (the C-ABI product library) in-tree with hipcc for gfx950.
+
+    python -m miniengineao_amd.build [--force] [--verbose]
+
+The library links only against the HIP runtime; there is no torch dependency and no CPU
+fallback.  hipcc cross-compiles without a GPU, so this runs in the build container.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+_INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmeao_hip.so")
+
+SOURCES = ["meao_plan.cpp", "meao_api.cpp", "meao_kernels.hip"]
+HEADERS = ["meao_plan.hpp", "meao_kernels.hpp"]
+
+# -ffp-contract=off: the only fused multiply-adds are the explicit mad()/fma2() calls, which
+# is what makes the kernels bit-exact against the oracle.  Correctly rounded '/' and sqrt are
+# hipcc's default; the flag is spelled out because parity depends on it.
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fvisibility=hidden", "-Wall", "-Wextra", "-Wno-unused-parameter",
+]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(_CSRC, f) for f in SOURCES + HEADERS]
+    deps += [os.path.join(_INCLUDE, "meao.h"), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc(), *FLAGS, *extra_flags, f"-I{_INCLUDE}"]
+    cmd += [os.path.join(_CSRC, s) for s in SOURCES]
+    tmp = LIB_PATH + ".tmp"
+    cmd += ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    if verbose and proc.stderr.strip():
+        print(proc.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    path = build_lib(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    print(path)

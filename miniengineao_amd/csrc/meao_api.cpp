@@ -1,0 +1,633 @@
+// meao_api.cpp -- the C ABI of libmeao_hip.so (include/meao.h): context management, the
+// per-frame launch sequence, intermediates, profiling.  No CPU fallback exists anywhere in
+// this library: without a gfx950 device meao_create fails with MEAO_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "meao_kernels.hpp"
+#include "meao_plan.hpp"
+
+using namespace meao;
+
+namespace {
+
+thread_local std::string g_last_error;   // for failures that have no context (meao_create)
+
+constexpr uint64_t kAlign = 256;
+constexpr int kProfileRing = 64;          // executes buffered before timings are folded
+inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+}  // namespace
+
+struct meao_ctx {
+    meao_config cfg{};
+    meao_params prm{};
+    Plan plan{};
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+
+    // context-owned intermediates: max_batch identical slots inside one arena
+    char *arena = nullptr;
+    uint64_t slot_bytes = 0;
+    uint64_t off_linear = 0, off_low[4] = {}, off_occ[4] = {}, off_comb[3] = {};
+
+    // lazily allocated: staging for HOST in/out, atlas scratch, selftest counter
+    char *stage_depth = nullptr, *stage_out = nullptr, *atlas_scratch = nullptr;
+    uint64_t stage_depth_frame = 0, stage_out_frame = 0, atlas_scratch_bytes = 0;
+    unsigned long long *counter = nullptr;
+
+    const void *last_out[MEAO_MAX_BATCH] = {};   // device address of the last results (debug id 17)
+    int last_frames = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events;              // kProfileRing * (MEAO_NUM_PASSES + 1)
+    int ring_fill = 0;
+    bool ran[MEAO_NUM_PASSES] = {};
+    double pass_ms_sum[MEAO_NUM_PASSES] = {};
+    int pass_samples = 0;
+
+    std::string err;
+};
+
+namespace {
+
+int fail(meao_ctx *ctx, int status, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    g_last_error = msg;
+    return status;
+}
+
+int fail_hip(meao_ctx *ctx, hipError_t e, const char *what)
+{
+    (void)hipGetLastError();
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), static_cast<int>(e));
+    return fail(ctx, e == hipErrorOutOfMemory ? MEAO_ERR_OUT_OF_MEMORY : MEAO_ERR_HIP, buf);
+}
+
+#define MEAO_HIP(ctx, expr)                                      \
+    do {                                                         \
+        hipError_t e_ = (expr);                                  \
+        if (e_ != hipSuccess) return fail_hip((ctx), e_, #expr); \
+    } while (0)
+
+bool config_valid(const meao_config &c, std::string *why)
+{
+    if (c.width < 1 || c.height < 1 || c.width > 32768 || c.height > 32768) { *why = "width/height out of range [1, 32768]"; return false; }
+    if (c.num_levels < 1 || c.num_levels > 4) { *why = "num_levels must be 1..4"; return false; }
+    if (c.ao_format != MEAO_AO_R8 && c.ao_format != MEAO_AO_F16) { *why = "unknown ao_format"; return false; }
+    if (c.f16_rounding != MEAO_F16_RTZ_CLAMP && c.f16_rounding != MEAO_F16_RTNE) { *why = "unknown f16_rounding"; return false; }
+    if (c.max_batch < 1 || c.max_batch > MEAO_MAX_BATCH) { *why = "max_batch must be 1..MEAO_MAX_BATCH"; return false; }
+    return true;
+}
+
+uint64_t ao_elem(const meao_config &c) { return c.ao_format == MEAO_AO_R8 ? 1 : 2; }
+
+void layout_slot(meao_ctx *ctx)
+{
+    const Plan &p = ctx->plan;
+    uint64_t off = 0;
+    auto take = [&](uint64_t bytes) { const uint64_t o = off; off = align_up(off + bytes); return o; };
+    auto px = [&](int k) { return static_cast<uint64_t>(p.mip[k].w) * p.mip[k].h; };
+    ctx->off_linear = take(px(0) * 2);
+    for (int k = 1; k <= 4; ++k) ctx->off_low[k - 1] = take(px(k) * 4);
+    for (int k = 1; k <= 4; ++k) ctx->off_occ[k - 1] = take(px(k) * ao_elem(ctx->cfg));
+    for (int k = 1; k <= 3; ++k) ctx->off_comb[k - 1] = take(px(k) * ao_elem(ctx->cfg));
+    ctx->slot_bytes = off;
+}
+
+void release_buffers(meao_ctx *ctx)
+{
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->stage_depth) (void)hipFree(ctx->stage_depth);
+    if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+    if (ctx->atlas_scratch) (void)hipFree(ctx->atlas_scratch);
+    ctx->arena = ctx->stage_depth = ctx->stage_out = ctx->atlas_scratch = nullptr;
+    ctx->atlas_scratch_bytes = 0;
+    ctx->last_frames = 0;
+}
+
+int allocate_buffers(meao_ctx *ctx)
+{
+    build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->prm, &ctx->plan);
+    layout_slot(ctx);
+    MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->arena), ctx->slot_bytes * ctx->cfg.max_batch));
+    return MEAO_OK;
+}
+
+int use_device(meao_ctx *ctx)
+{
+    MEAO_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    return MEAO_OK;
+}
+
+template <typename T>
+T *slot_ptr(meao_ctx *ctx, uint64_t off) { return reinterpret_cast<T *>(ctx->arena + off); }
+
+void fold_profile(meao_ctx *ctx)
+{
+    // events of the buffered executes are complete once the last one is
+    const int per = MEAO_NUM_PASSES + 1;
+    if (ctx->ring_fill == 0) return;
+    (void)hipEventSynchronize(ctx->events[(ctx->ring_fill - 1) * per + MEAO_NUM_PASSES]);
+    for (int r = 0; r < ctx->ring_fill; ++r) {
+        for (int k = 0; k < MEAO_NUM_PASSES; ++k) {
+            if (!ctx->ran[k]) continue;
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ctx->events[r * per + k], ctx->events[r * per + k + 1]) == hipSuccess)
+                ctx->pass_ms_sum[k] += ms;
+        }
+        ++ctx->pass_samples;
+    }
+    ctx->ring_fill = 0;
+}
+
+// The launch sequence of one batch: what RebuildCommandBuffers records (AO.cs:511-531).
+int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream)
+{
+    const Plan &p = ctx->plan;
+    const meao_config &c = ctx->cfg;
+    const int rtne = c.f16_rounding == MEAO_F16_RTNE;
+    const int per = MEAO_NUM_PASSES + 1;
+    hipEvent_t *ev = nullptr;
+    if (ctx->profiling) {
+        if (ctx->ring_fill == kProfileRing) fold_profile(ctx);
+        ev = &ctx->events[ctx->ring_fill * per];
+        std::memset(ctx->ran, 0, sizeof ctx->ran);
+    }
+    auto mark = [&](int k) -> hipError_t { return ev ? hipEventRecord(ev[k], stream) : hipSuccess; };
+
+    // ---- PushDownsampleCommands (AO.cs:604-658)
+    DownsampleArgs ds{};
+    for (int f = 0; f < n; ++f) ds.depth[f] = static_cast<const float *>(depth_dev[f]);
+    ds.linear = slot_ptr<uint16_t>(ctx, ctx->off_linear);
+    for (int k = 0; k < 4; ++k) ds.low[k] = slot_ptr<float>(ctx, ctx->off_low[k]);
+    ds.frame_stride = ctx->slot_bytes;
+    for (int k = 0; k < 5; ++k) { ds.w[k] = p.mip[k].w; ds.h[k] = p.mip[k].h; }
+    ds.zp0 = p.zbuffer_params[0];
+    ds.zp1 = p.zbuffer_params[1];
+    ds.reversed_z = ctx->prm.reversed_z != 0;
+    ds.f16_rtne = rtne;
+    ds.tiles_x = (p.mip[0].w + 127) / 128;
+    ds.tiles_y = (p.mip[0].h + 31) / 32;
+    MEAO_HIP(ctx, mark(0));
+    MEAO_HIP(ctx, launch_downsample(ds, n, stream));
+    if (ev) ctx->ran[MEAO_PASS_DOWNSAMPLE] = true;
+    MEAO_HIP(ctx, mark(1));
+
+    // ---- PushRenderCommands x num_levels (AO.cs:519-522) as one grid
+    RenderArgs rn{};
+    int blocks = 0;
+    for (int l = 1; l <= c.num_levels; ++l) {
+        RenderLevelArgs &L = rn.level[l - 1];
+        const RenderLevelPlan &rp = p.render[l - 1];
+        L.src = slot_ptr<float>(ctx, ctx->off_low[l - 1]);
+        L.dst = slot_ptr<void>(ctx, ctx->off_occ[l - 1]);
+        L.lw = p.mip[l].w; L.lh = p.mip[l].h;
+        L.sw = p.mip[l + 2].w; L.sh = p.mip[l + 2].h;
+        L.tiles_x = (L.lw + kRenTileW - 1) / kRenTileW;
+        L.tiles_y = (L.lh + kRenTileH - 1) / kRenTileH;
+        L.block_begin = blocks;
+        blocks += L.tiles_x * L.tiles_y;
+        L.pad_value = rp.pad_value;
+        for (int t = 0; t < kNumRenderTerms; ++t) {
+            L.inv_thickness[t] = rp.inv_thickness[t];
+            L.front_depth[t] = rp.front_depth[t];
+            L.weight[t] = rp.weight[t];
+        }
+        L.reject_fadeoff = rp.cb.reject_fadeoff;
+        L.intensity = rp.cb.intensity;
+    }
+    rn.frame_stride = ctx->slot_bytes;
+    rn.num_levels = c.num_levels;
+    rn.blocks_per_frame = blocks;
+    rn.f16_rtne = rtne;
+    MEAO_HIP(ctx, launch_render(rn, c.ao_format, n, stream));
+    if (ev) ctx->ran[MEAO_PASS_RENDER] = true;
+    MEAO_HIP(ctx, mark(2));
+
+    // ---- PushUpsampleCommands chain (AO.cs:528-531), generalised to num_levels
+    const void *lo_ao = slot_ptr<void>(ctx, ctx->off_occ[c.num_levels - 1]);
+    for (int hi = 3; hi >= 0; --hi) {
+        const int pass = MEAO_PASS_UPSAMPLE_0 - hi;
+        if (hi <= c.num_levels - 1) {
+            UpsampleArgs up{};
+            const meao_upsample_constants &k = p.upsample[hi];   // low level = hi + 1
+            up.lo_depth = slot_ptr<float>(ctx, ctx->off_low[hi]);
+            up.lo_ao = lo_ao;
+            up.frame_stride = ctx->slot_bytes;
+            up.lw = p.mip[hi + 1].w; up.lh = p.mip[hi + 1].h;
+            up.hw = p.mip[hi].w; up.hh = p.mip[hi].h;
+            up.tiles_x = (up.hw + kUpsTileW - 1) / kUpsTileW;
+            up.tiles_y = (up.hh + kUpsTileH - 1) / kUpsTileH;
+            up.noise_filter_strength = k.noise_filter_strength;
+            up.step_size = k.step_size;
+            up.blur_tolerance = k.blur_tolerance;
+            up.upsample_tolerance = k.upsample_tolerance;
+            up.f16_rtne = rtne;
+            if (hi > 0) {   // main_blendout: blend with Occlusion<hi>, write Combined<hi>
+                up.hi_depth = slot_ptr<float>(ctx, ctx->off_low[hi - 1]);
+                up.hi_ao = slot_ptr<void>(ctx, ctx->off_occ[hi - 1]);
+                up.dst[0] = slot_ptr<void>(ctx, ctx->off_comb[hi - 1]);
+                lo_ao = up.dst[0];
+            } else {        // main: LinearDepth f16 as HiResDB, no HiResAO, write the result
+                up.hi_depth = slot_ptr<uint16_t>(ctx, ctx->off_linear);
+                up.hi_ao = nullptr;
+                for (int f = 0; f < n; ++f) up.dst[f] = out_dev[f];
+            }
+            MEAO_HIP(ctx, launch_upsample(up, c.ao_format, hi == 0, n, stream));
+            if (ev) ctx->ran[pass] = true;
+        }
+        MEAO_HIP(ctx, mark(pass + 1));
+    }
+    if (ev) ++ctx->ring_fill;
+    for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
+    ctx->last_frames = n;
+    ctx->last_stream = stream;
+    return MEAO_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t meao_abi_version(void) { return MEAO_ABI_VERSION; }
+
+const char *meao_status_string(int32_t status)
+{
+    switch (status) {
+    case MEAO_OK: return "ok";
+    case MEAO_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case MEAO_ERR_HIP: return "HIP runtime error";
+    case MEAO_ERR_OUT_OF_MEMORY: return "out of memory";
+    case MEAO_ERR_UNSUPPORTED: return "unsupported";
+    case MEAO_ERR_NO_DEVICE: return "no gfx950 device (there is no CPU fallback)";
+    case MEAO_ERR_BUFFER_TOO_SMALL: return "destination buffer too small";
+    default: return "unknown status";
+    }
+}
+
+void meao_default_config(meao_config *cfg)
+{
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->device = 0;
+    cfg->width = 1920;
+    cfg->height = 1080;
+    cfg->num_levels = 4;
+    cfg->ao_format = MEAO_AO_R8;
+    cfg->f16_rounding = MEAO_F16_RTZ_CLAMP;
+    cfg->numerics = MEAO_NUMERICS_STRICT;
+    cfg->max_batch = 1;
+}
+
+void meao_default_params(meao_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->struct_size = sizeof *p;
+    p->noise_filter_tolerance = 0.0f;   // AO.cs:20
+    p->blur_tolerance = -4.6f;          // AO.cs:28
+    p->upsample_tolerance = -12.0f;     // AO.cs:36
+    p->thickness_modifier = 1.0f;       // AO.cs:44
+    p->intensity = 1.0f;                // AO.cs:52
+    p->near_clip = 0.3f;                // Unity camera defaults
+    p->far_clip = 1000.0f;
+    p->proj00 = 0.9742786f;             // fovY 60 deg at 16:9
+    p->reversed_z = 1;
+}
+
+int32_t meao_level_dims(int32_t width, int32_t height, int32_t level, int32_t *out_w, int32_t *out_h)
+{
+    if (width < 1 || height < 1 || level < 0 || level >= kNumMips || !out_w || !out_h)
+        return MEAO_ERR_INVALID_ARGUMENT;
+    const Dims d = level_dims(width, height, level);
+    *out_w = d.w;
+    *out_h = d.h;
+    return MEAO_OK;
+}
+
+int32_t meao_zbuffer_params(const meao_params *p, float out[4])
+{
+    if (!p || !out || !params_valid(*p)) return MEAO_ERR_INVALID_ARGUMENT;
+    zbuffer_params(*p, out);
+    return MEAO_OK;
+}
+
+int32_t meao_render_constants_for(int32_t width, int32_t height, const meao_params *p, int32_t level,
+                                  meao_render_constants *out)
+{
+    if (width < 1 || height < 1 || !p || !out || level < 1 || level > 4 || !params_valid(*p))
+        return MEAO_ERR_INVALID_ARGUMENT;
+    render_constants(width, height, *p, level, out);
+    return MEAO_OK;
+}
+
+int32_t meao_upsample_constants_for(int32_t width, int32_t height, const meao_params *p, int32_t low_level,
+                                    meao_upsample_constants *out)
+{
+    if (width < 1 || height < 1 || !p || !out || low_level < 1 || low_level > 4 || !params_valid(*p))
+        return MEAO_ERR_INVALID_ARGUMENT;
+    upsample_constants(width, height, *p, low_level, out);
+    return MEAO_OK;
+}
+
+int32_t meao_describe_buffer(const meao_config *cfg, int32_t debug_id, meao_desc *out)
+{
+    std::string why;
+    if (!cfg || !out || !config_valid(*cfg, &why)) return MEAO_ERR_INVALID_ARGUMENT;
+    return describe_buffer(cfg->width, cfg->height, cfg->ao_format, debug_id, out) ? MEAO_OK
+                                                                                   : MEAO_ERR_INVALID_ARGUMENT;
+}
+
+int32_t meao_algorithmic_bytes(const meao_config *cfg, uint64_t bytes[MEAO_NUM_PASSES])
+{
+    std::string why;
+    if (!cfg || !bytes || !config_valid(*cfg, &why)) return MEAO_ERR_INVALID_ARGUMENT;
+    algorithmic_bytes(cfg->width, cfg->height, cfg->num_levels, cfg->ao_format, bytes);
+    return MEAO_OK;
+}
+
+int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
+{
+    if (out_ctx) *out_ctx = nullptr;
+    if (!cfg || !out_ctx) return fail(nullptr, MEAO_ERR_INVALID_ARGUMENT, "meao_create: null argument");
+    if (cfg->struct_size != sizeof(meao_config))
+        return fail(nullptr, MEAO_ERR_INVALID_ARGUMENT, "meao_create: struct_size mismatch (ABI)");
+    std::string why;
+    if (!config_valid(*cfg, &why)) return fail(nullptr, MEAO_ERR_INVALID_ARGUMENT, "meao_create: " + why);
+    if (cfg->numerics != MEAO_NUMERICS_STRICT)
+        return fail(nullptr, MEAO_ERR_UNSUPPORTED, "meao_create: only MEAO_NUMERICS_STRICT is implemented");
+
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, MEAO_ERR_NO_DEVICE, "meao_create: no HIP device visible (no CPU fallback exists)");
+    }
+    if (cfg->device < 0 || cfg->device >= count)
+        return fail(nullptr, MEAO_ERR_INVALID_ARGUMENT, "meao_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return fail_hip(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MEAO_ERR_NO_DEVICE,
+                    std::string("meao_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+
+    meao_ctx *ctx = new (std::nothrow) meao_ctx();
+    if (!ctx) return fail(nullptr, MEAO_ERR_OUT_OF_MEMORY, "meao_create: host allocation failed");
+    ctx->cfg = *cfg;
+    meao_default_params(&ctx->prm);
+    int rc = use_device(ctx);
+    if (rc == MEAO_OK) {
+        e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) rc = fail_hip(ctx, e, "hipStreamCreateWithFlags");
+    }
+    if (rc == MEAO_OK) rc = allocate_buffers(ctx);
+    if (rc != MEAO_OK) {
+        g_last_error = ctx->err;
+        meao_destroy(ctx);
+        return rc;
+    }
+    ctx->last_stream = ctx->own_stream;
+    *out_ctx = ctx;
+    return MEAO_OK;
+}
+
+int32_t meao_destroy(meao_ctx *ctx)
+{
+    if (!ctx) return MEAO_OK;
+    (void)hipSetDevice(ctx->cfg.device);
+    (void)hipDeviceSynchronize();
+    release_buffers(ctx);
+    if (ctx->counter) (void)hipFree(ctx->counter);
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MEAO_OK;
+}
+
+int32_t meao_resize(meao_ctx *ctx, int32_t width, int32_t height)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    meao_config c = ctx->cfg;
+    c.width = width;
+    c.height = height;
+    std::string why;
+    if (!config_valid(c, &why)) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_resize: " + why);
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    MEAO_HIP(ctx, hipDeviceSynchronize());
+    release_buffers(ctx);
+    ctx->cfg = c;
+    return allocate_buffers(ctx);
+}
+
+int32_t meao_set_params(meao_ctx *ctx, const meao_params *p)
+{
+    if (!ctx || !p) return MEAO_ERR_INVALID_ARGUMENT;
+    if (p->struct_size != sizeof(meao_params)) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_set_params: struct_size mismatch (ABI)");
+    if (!params_valid(*p)) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_set_params: non-finite or degenerate parameter");
+    ctx->prm = *p;
+    build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->prm, &ctx->plan);
+    return MEAO_OK;
+}
+
+int32_t meao_get_params(const meao_ctx *ctx, meao_params *out)
+{
+    if (!ctx || !out) return MEAO_ERR_INVALID_ARGUMENT;
+    *out = ctx->prm;
+    return MEAO_OK;
+}
+
+int32_t meao_get_config(const meao_ctx *ctx, meao_config *out)
+{
+    if (!ctx || !out) return MEAO_ERR_INVALID_ARGUMENT;
+    *out = ctx->cfg;
+    return MEAO_OK;
+}
+
+const char *meao_last_error(const meao_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth, int32_t depth_loc,
+                           void *const *ao_out, int32_t out_loc, meao_stream stream_)
+{
+    if (!ctx || !depth || !ao_out) return MEAO_ERR_INVALID_ARGUMENT;
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_execute_batch: n must be 1..max_batch");
+    if ((depth_loc != MEAO_MEM_HOST && depth_loc != MEAO_MEM_DEVICE) || (out_loc != MEAO_MEM_HOST && out_loc != MEAO_MEM_DEVICE))
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_execute_batch: bad memory location");
+    for (int f = 0; f < n; ++f)
+        if (!depth[f] || !ao_out[f]) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_execute_batch: null frame pointer");
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->own_stream;
+
+    const uint64_t px = static_cast<uint64_t>(ctx->cfg.width) * ctx->cfg.height;
+    const uint64_t depth_bytes = px * 4, out_bytes = px * ao_elem(ctx->cfg);
+    const void *depth_dev[MEAO_MAX_BATCH];
+    void *out_dev[MEAO_MAX_BATCH];
+    if (depth_loc == MEAO_MEM_HOST) {
+        if (!ctx->stage_depth) {
+            ctx->stage_depth_frame = align_up(depth_bytes);
+            MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->stage_depth), ctx->stage_depth_frame * ctx->cfg.max_batch));
+        }
+        for (int f = 0; f < n; ++f) {
+            char *d = ctx->stage_depth + ctx->stage_depth_frame * f;
+            MEAO_HIP(ctx, hipMemcpyAsync(d, depth[f], depth_bytes, hipMemcpyHostToDevice, stream));
+            depth_dev[f] = d;
+        }
+    } else {
+        for (int f = 0; f < n; ++f) depth_dev[f] = depth[f];
+    }
+    if (out_loc == MEAO_MEM_HOST) {
+        if (!ctx->stage_out) {
+            ctx->stage_out_frame = align_up(out_bytes);
+            MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->stage_out), ctx->stage_out_frame * ctx->cfg.max_batch));
+        }
+        for (int f = 0; f < n; ++f) out_dev[f] = ctx->stage_out + ctx->stage_out_frame * f;
+    } else {
+        for (int f = 0; f < n; ++f) out_dev[f] = ao_out[f];
+    }
+
+    rc = run_batch(ctx, n, depth_dev, out_dev, stream);
+    if (rc != MEAO_OK) return rc;
+
+    if (out_loc == MEAO_MEM_HOST)
+        for (int f = 0; f < n; ++f)
+            MEAO_HIP(ctx, hipMemcpyAsync(ao_out[f], out_dev[f], out_bytes, hipMemcpyDeviceToHost, stream));
+    if (out_loc == MEAO_MEM_HOST || depth_loc == MEAO_MEM_HOST) MEAO_HIP(ctx, hipStreamSynchronize(stream));
+    return MEAO_OK;
+}
+
+int32_t meao_execute(meao_ctx *ctx, const void *depth, int32_t depth_loc, void *ao_out, int32_t out_loc,
+                     meao_stream stream)
+{
+    const void *d[1] = {depth};
+    void *o[1] = {ao_out};
+    return meao_execute_batch(ctx, 1, d, depth_loc, o, out_loc, stream);
+}
+
+int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    MEAO_HIP(ctx, hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : ctx->last_stream));
+    return MEAO_OK;
+}
+
+int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id, void *dst, uint64_t dst_capacity,
+                              int32_t dst_loc, meao_desc *out_desc)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    meao_desc d{};
+    if (!describe_buffer(ctx->cfg.width, ctx->cfg.height, ctx->cfg.ao_format, debug_id, &d))
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: debug_id must be 1..17");
+    if (out_desc) *out_desc = d;
+    if (!dst) return MEAO_OK;
+    if (frame < 0 || frame >= ctx->last_frames)
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: frame not produced by the last execute");
+    if (dst_capacity < d.bytes) return fail(ctx, MEAO_ERR_BUFFER_TOO_SMALL, "meao_get_intermediate: dst_capacity < desc.bytes");
+    if (dst_loc != MEAO_MEM_HOST && dst_loc != MEAO_MEM_DEVICE) return MEAO_ERR_INVALID_ARGUMENT;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    hipStream_t s = ctx->last_stream;
+    const char *slot = ctx->arena + ctx->slot_bytes * frame;
+    const void *src = nullptr;
+    const int nl = ctx->cfg.num_levels;
+    if (debug_id == 1) src = slot + ctx->off_linear;
+    else if (debug_id <= 5) src = slot + ctx->off_low[debug_id - 2];
+    else if (debug_id <= 9) {
+        // TiledDepth<level>: materialised on demand from LowDepth<level> (the hot path samples
+        // LowDepth directly and never builds the de-interleaved arrays).
+        const int level = debug_id - 5;
+        if (ctx->atlas_scratch_bytes < d.bytes) {
+            if (ctx->atlas_scratch) (void)hipFree(ctx->atlas_scratch);
+            ctx->atlas_scratch = nullptr;
+            ctx->atlas_scratch_bytes = 0;
+            MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->atlas_scratch), d.bytes));
+            ctx->atlas_scratch_bytes = d.bytes;
+        }
+        TileAtlasArgs ta{};
+        ta.src = reinterpret_cast<const float *>(slot + ctx->off_low[level - 1]);
+        ta.dst = reinterpret_cast<uint16_t *>(ctx->atlas_scratch);
+        ta.lw = ctx->plan.mip[level].w; ta.lh = ctx->plan.mip[level].h;
+        ta.sw = d.width; ta.sh = d.height;
+        ta.pad_value = ctx->plan.render[level - 1].pad_value;
+        ta.f16_rtne = ctx->cfg.f16_rounding == MEAO_F16_RTNE;
+        MEAO_HIP(ctx, launch_tile_atlas(ta, s));
+        src = ctx->atlas_scratch;
+    } else if (debug_id <= 13) {
+        if (debug_id - 9 > nl) return fail(ctx, MEAO_ERR_UNSUPPORTED, "meao_get_intermediate: level not rendered (num_levels)");
+        src = slot + ctx->off_occ[debug_id - 10];
+    } else if (debug_id <= 16) {
+        if (debug_id - 13 > nl - 1) return fail(ctx, MEAO_ERR_UNSUPPORTED, "meao_get_intermediate: level not combined (num_levels)");
+        src = slot + ctx->off_comb[debug_id - 14];
+    } else {
+        src = ctx->last_out[frame];
+    }
+    MEAO_HIP(ctx, hipMemcpyAsync(dst, src, d.bytes,
+                                 dst_loc == MEAO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    MEAO_HIP(ctx, hipStreamSynchronize(s));
+    return MEAO_OK;
+}
+
+int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    if (enable && ctx->events.empty()) {
+        const int count = kProfileRing * (MEAO_NUM_PASSES + 1);
+        ctx->events.reserve(count);
+        for (int i = 0; i < count; ++i) {
+            hipEvent_t ev;
+            MEAO_HIP(ctx, hipEventCreate(&ev));
+            ctx->events.push_back(ev);
+        }
+    }
+    if (enable) {   // (re)start a measurement window
+        if (ctx->ring_fill) fold_profile(ctx);
+        std::memset(ctx->pass_ms_sum, 0, sizeof ctx->pass_ms_sum);
+        ctx->pass_samples = 0;
+    }
+    ctx->profiling = enable != 0;
+    return MEAO_OK;
+}
+
+int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *out_samples)
+{
+    if (!ctx || !ms) return MEAO_ERR_INVALID_ARGUMENT;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    fold_profile(ctx);
+    for (int k = 0; k < MEAO_NUM_PASSES; ++k)
+        ms[k] = ctx->pass_samples ? static_cast<float>(ctx->pass_ms_sum[k] / ctx->pass_samples) : 0.0f;
+    if (out_samples) *out_samples = ctx->pass_samples;
+    return MEAO_OK;
+}
+
+int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches)
+{
+    if (!ctx || !out_mismatches || which < 0 || which > 3) return MEAO_ERR_INVALID_ARGUMENT;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    if (!ctx->counter) MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counter), sizeof(unsigned long long)));
+    MEAO_HIP(ctx, hipMemsetAsync(ctx->counter, 0, sizeof(unsigned long long), ctx->own_stream));
+    MEAO_HIP(ctx, launch_selftest(which, ctx->counter, ctx->own_stream));
+    unsigned long long host = 0;
+    MEAO_HIP(ctx, hipMemcpyAsync(&host, ctx->counter, sizeof host, hipMemcpyDeviceToHost, ctx->own_stream));
+    MEAO_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
+    *out_mismatches = host;
+    return MEAO_OK;
+}
+
+}  // extern "C"

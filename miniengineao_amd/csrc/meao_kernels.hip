@@ -1,0 +1,681 @@
+// meao_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the multi-scale SSAO hot path.
+//
+// One workgroup = 256 threads = 4 wave64.  Kernels (stream order, one launch each per batch):
+//   downsample_kernel  Downsample1.main + Downsample2.main   (DS1:52-81, DS2:32-51)
+//   render_kernel      Render.main_interleaved, all levels   (REN:112-177)
+//   upsample_kernel    Upsample.main / main_blendout         (UPS:185-233)
+// (DS1/DS2/REN/UPS = Assets/MiniEngineAO/Shaders/{Downsample1,Downsample2,Render,Upsample}.compute)
+//
+// Numerics contract: binary32, RNE, IEEE '/' (hipcc's correctly rounded divide),
+// compiled with -ffp-contract=off; the only fused operations are the explicit mad()/fma2()
+// calls, placed where the HLSL source has a*b+c in one expression.  Bit-exact against
+// oracle/meao_oracle.c.
+//
+// MI355X design notes:
+//  * The 4x4 de-interleaved TiledDepth arrays are never materialised on the hot path: a
+//    workgroup that renders ALL 16 slices of a 64x32 output tile needs exactly one contiguous
+//    (64+32)x(32+32) window of LowDepth<level>, so the kernel stages that window in LDS
+//    (applying the per-slice clamp addressing and the atlas padding rule while filling) and
+//    samples it with a stride of 4.  Output rows are then contiguous instead of a 4-byte
+//    strided scatter of single R8 texels.
+//  * Each lane renders horizontally adjacent texel pairs so every LDS sample is one
+//    conflict-free ds_read_b64 and the arithmetic is available to the packed-f32 VALU.
+//  * Upsample uses 64x32 hi-res tiles (32x16 low-res + aprons): 1.5x apron amplification
+//    instead of the reference's 2.6x, all 256 lanes busy in both blur phases, 16-byte loads
+//    of the hi-res depth and 4-byte stores of four AO texels.
+#include "meao_kernels.hpp"
+
+namespace meao {
+namespace {
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef uint16_t ushort4v __attribute__((ext_vector_type(4)));
+typedef uint16_t ushort2v __attribute__((ext_vector_type(2)));
+typedef uint8_t uchar4v __attribute__((ext_vector_type(4)));
+typedef uint8_t uchar2v __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------
+// scalar / packed helpers
+
+__device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+__device__ __forceinline__ float2v splat(float x) { return float2v{x, x}; }
+__device__ __forceinline__ float2v fma2(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float2v min2(float2v a, float2v b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ float2v max2(float2v a, float2v b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ float2v sat2(float2v x) { return min2(max2(x, splat(0.0f)), splat(1.0f)); }
+
+// f32 -> f16 store conversion (HalfUAV targets).  RTZ: v_cvt_pkrtz_f16_f32 rounds toward zero,
+// so finite overflow lands on 65504; RTNE: v_cvt_f16_f32 in the default rounding mode.
+template <bool RTNE>
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float x)
+{
+    if constexpr (RTNE) {
+        const _Float16 h = static_cast<_Float16>(x);
+        return __builtin_bit_cast(uint16_t, h);
+    } else {
+        const auto p = __builtin_amdgcn_cvt_pkrtz(x, 0.0f);
+        return static_cast<uint16_t>(__builtin_bit_cast(uint32_t, p) & 0xffffu);
+    }
+}
+
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b)
+{
+    return static_cast<float>(__builtin_bit_cast(_Float16, b));
+}
+
+// value an f16 render target returns after storing x
+template <bool RTNE>
+__device__ __forceinline__ float through_f16(float x) { return f16_bits_to_f32(f32_to_f16_bits<RTNE>(x)); }
+
+// f32 -> UNORM8 (FixedUAV targets): NaN -> 0, clamp, *255, +0.5, truncate
+__device__ __forceinline__ uint32_t f32_to_unorm8(float x)
+{
+    float s = sat(x) * 255.0f;
+    s = s + 0.5f;
+    return static_cast<uint32_t>(s);
+}
+
+// UNORM8 -> f32 == (float)n / 255.0f exactly: quotient estimate + one fused remainder step
+// (verified against IEEE division for all 256 inputs by tests and meao_selftest(2)).
+__device__ __forceinline__ float unorm8_to_f32(uint32_t n)
+{
+    const float fn = static_cast<float>(n);
+    const float r = 1.0f / 255.0f;       // folded at compile time
+    const float q = fn * r;
+    const float e = mad(-255.0f, q, fn);
+    return mad(e, r, q);
+}
+
+template <int AOFMT>
+struct AoTexel;
+template <>
+struct AoTexel<MEAO_AO_R8> {
+    typedef uint8_t type;
+    typedef uchar2v type2;
+    typedef uchar4v type4;
+    template <bool RTNE>
+    static __device__ __forceinline__ type encode(float v) { return static_cast<uint8_t>(f32_to_unorm8(v)); }
+    static __device__ __forceinline__ float decode(type t) { return unorm8_to_f32(t); }
+};
+template <>
+struct AoTexel<MEAO_AO_F16> {
+    typedef uint16_t type;
+    typedef ushort2v type2;
+    typedef ushort4v type4;
+    template <bool RTNE>
+    static __device__ __forceinline__ type encode(float v) { return f32_to_f16_bits<RTNE>(v); }
+    static __device__ __forceinline__ float decode(type t) { return f16_bits_to_f32(t); }
+};
+
+template <typename T>
+__device__ __forceinline__ T *frame_ptr(T *base, uint64_t stride_bytes, int frame)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(base) + stride_bytes * static_cast<uint64_t>(frame));
+}
+
+// ------------------------------------------------------------------------------------------
+// Downsample: linearize + point-downsample to L1..L4.   Tile 128 x 32 full-res texels.
+//
+// Closed form of DS1+DS2: LinearZ = lin(x,y); DS2x[i,j] = lin(2i,2j);
+// DS4x = lin(4i,4j); DS8x = lin(8i,8j); DS16x = lin(16i,16j) -- every level keeps the
+// top-left texel of its block, so a lane decides what to store from its own coordinates and
+// no LDS exchange is needed.
+
+constexpr int kDsTileW = 128, kDsTileH = 32, kDsRowsPerPass = 8;
+
+__device__ __forceinline__ float linearize(float depth, float zp0, float zp1, bool reversed)
+{
+    float dist = 1.0f / mad(zp0, depth, zp1);                       // DS1:40
+    if (reversed ? (depth == 0.0f) : (depth == 1.0f)) dist = 1e5f;  // DS1:41-45
+    return dist;
+}
+
+template <bool RTNE, bool VEC>
+__global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleArgs a)
+{
+    const int frame = blockIdx.z;
+    const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+    const float *__restrict__ depth = a.depth[frame];
+    uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
+    float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
+    float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
+    float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
+    float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
+    const int W = a.w[0], H = a.h[0];
+    const bool reversed = a.reversed_z != 0;
+
+    const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
+    const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
+    if (x0 >= W) return;
+
+    float v[kDsTileH / kDsRowsPerPass][4];
+#pragma unroll
+    for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
+        const int y = yb + k * kDsRowsPerPass;
+        v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.5f;
+        if (y < H) {
+            const float *row = depth + static_cast<size_t>(y) * W + x0;
+            if constexpr (VEC) {
+                const float4v q = *reinterpret_cast<const float4v *>(row);
+                v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (x0 + e < W) v[k][e] = row[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
+        const int y = yb + k * kDsRowsPerPass;
+        if (y >= H) continue;
+        float lin[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lin[e] = linearize(v[k][e], a.zp0, a.zp1, reversed);
+
+        uint16_t *lrow = linear + static_cast<size_t>(y) * W + x0;    // LinearZ[st] = dist (DS1:46)
+        if constexpr (VEC) {
+            ushort4v h;
+            h.x = f32_to_f16_bits<RTNE>(lin[0]); h.y = f32_to_f16_bits<RTNE>(lin[1]);
+            h.z = f32_to_f16_bits<RTNE>(lin[2]); h.w = f32_to_f16_bits<RTNE>(lin[3]);
+            *reinterpret_cast<ushort4v *>(lrow) = h;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x0 + e < W) lrow[e] = f32_to_f16_bits<RTNE>(lin[e]);
+        }
+        if ((y & 1) == 0) {                                           // DS2x (DS1:64-70)
+            float *p = low1 + static_cast<size_t>(y >> 1) * a.w[1] + (x0 >> 1);
+            if constexpr (VEC) {
+                *reinterpret_cast<float2v *>(p) = float2v{lin[0], lin[2]};
+            } else {
+                p[0] = lin[0];
+                if (x0 + 2 < W) p[1] = lin[2];
+            }
+            if ((y & 3) == 0) {                                       // DS4x (DS1:73-77)
+                low2[static_cast<size_t>(y >> 2) * a.w[2] + (x0 >> 2)] = lin[0];
+                if ((y & 7) == 0 && (x0 & 7) == 0) {                  // DS8x (DS2:35-40)
+                    low3[static_cast<size_t>(y >> 3) * a.w[3] + (x0 >> 3)] = lin[0];
+                    if ((y & 15) == 0 && (x0 & 15) == 0)              // DS16x (DS2:43-49)
+                        low4[static_cast<size_t>(y >> 4) * a.w[4] + (x0 >> 4)] = lin[0];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Render: volumetric-obscurance AO, 36-sample checker set.
+
+// TestSamplePair (REN:60-75) for two horizontally adjacent output texels.
+__device__ __forceinline__ float2v test_sample_pair(const float *centre, int offset, float2v inv_range,
+                                                    float2v neg_front, float2v reject)
+{
+    const float2v s1 = *reinterpret_cast<const float2v *>(centre + offset);
+    const float2v s2 = *reinterpret_cast<const float2v *>(centre - offset);
+    const float2v d1 = fma2(s1, inv_range, neg_front);
+    const float2v d2 = fma2(s2, inv_range, neg_front);
+    const float2v p1 = sat2(reject * d1);
+    const float2v p2 = sat2(reject * d2);
+    const float2v one = splat(1.0f);
+    const float2v acc = min2(max2(d1, p2), one) + min2(max2(d2, p1), one);
+    return sat2(fma2(-p1, p2, acc));
+}
+
+// TestSamples (REN:77-110).  (X, Y) are slice-texel offsets; one slice texel is 4 level
+// texels (4x4 interleave), so the LDS offset of (dx, dy) is 4*dy*pitch + 4*dx.
+template <int X, int Y>
+__device__ __forceinline__ float2v test_samples(const float *centre, float2v inv_depth, float inv_thickness,
+                                                float front_depth, float2v reject)
+{
+    constexpr int P = 4 * kRenLdsW, Q = 4;
+    const float2v inv_range = splat(inv_thickness) * inv_depth;
+    const float2v neg_front = splat(-front_depth);
+    if constexpr (Y == 0) {
+        return splat(0.5f) * (test_sample_pair(centre, X * Q, inv_range, neg_front, reject) +
+                              test_sample_pair(centre, X * P, inv_range, neg_front, reject));
+    } else if constexpr (X == Y) {
+        return splat(0.5f) * (test_sample_pair(centre, X * P - X * Q, inv_range, neg_front, reject) +
+                              test_sample_pair(centre, X * P + X * Q, inv_range, neg_front, reject));
+    } else {
+        return splat(0.25f) * (((test_sample_pair(centre, Y * P + X * Q, inv_range, neg_front, reject) +
+                                 test_sample_pair(centre, Y * P - X * Q, inv_range, neg_front, reject)) +
+                                test_sample_pair(centre, X * P + Y * Q, inv_range, neg_front, reject)) +
+                               test_sample_pair(centre, X * P - Y * Q, inv_range, neg_front, reject));
+    }
+}
+
+template <int AOFMT, bool RTNE>
+__global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * kRenLdsW];
+    typedef AoTexel<AOFMT> AO;
+
+    const int frame = blockIdx.y;
+    int b = blockIdx.x, lv = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < a.num_levels && b >= a.level[k].block_begin) lv = k;
+    const RenderLevelArgs &L = a.level[lv];
+    b -= L.block_begin;
+    const int X0 = (b % L.tiles_x) * kRenTileW, Y0 = (b / L.tiles_x) * kRenTileH;
+    const int lw = L.lw, lh = L.lh;
+    const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, frame);
+
+    // ---- stage the (64+32) x (32+32) window.  Window texel (vx,vy) (level coordinates, may
+    // be outside the level) belongs to slice (vx&3, vy&3), slice texel (vx>>2, vy>>2); the
+    // reference clamps the slice texel per slice (REN:118 Gather + clamp sampler) and finds
+    // Linearize(out-of-range) / 0 in atlas texels beyond the level (DS1:39-46, DS2:35).
+    {
+        const float pad = through_f16<RTNE>(L.pad_value);
+        const bool vec_ok = (lw & 3) == 0;
+        constexpr int kQuadsX = kRenLdsW / 4;
+        for (int q = threadIdx.x; q < kQuadsX * kRenLdsH; q += kThreads) {
+            const int qx = q % kQuadsX, qy = q / kQuadsX;
+            const int px0 = clampi((X0 >> 2) - (kRenApron >> 2) + qx, 0, L.sw - 1) * 4;
+            const int vy = Y0 - kRenApron + qy;
+            const int py = clampi(vy >> 2, 0, L.sh - 1) * 4 + (vy & 3);
+            float4v t = {pad, pad, pad, pad};
+            if (py < lh) {
+                const float *row = src + static_cast<size_t>(py) * lw + px0;
+                if (vec_ok && px0 + 3 < lw) {
+                    const float4v r = *reinterpret_cast<const float4v *>(row);
+                    t.x = through_f16<RTNE>(r.x); t.y = through_f16<RTNE>(r.y);
+                    t.z = through_f16<RTNE>(r.z); t.w = through_f16<RTNE>(r.w);
+                } else {
+                    if (px0 + 0 < lw) t.x = through_f16<RTNE>(row[0]);
+                    if (px0 + 1 < lw) t.y = through_f16<RTNE>(row[1]);
+                    if (px0 + 2 < lw) t.z = through_f16<RTNE>(row[2]);
+                    if (px0 + 3 < lw) t.w = through_f16<RTNE>(row[3]);
+                }
+            }
+            *reinterpret_cast<float4v *>(&tile[qy * kRenLdsW + qx * 4]) = t;
+        }
+    }
+    __syncthreads();
+
+    // ---- each lane: texel pairs (X, X+1) on rows ty, ty+8, ty+16, ty+24 of the tile
+    const int txl = threadIdx.x & 31, tyl = threadIdx.x >> 5;
+    const int X = X0 + 2 * txl;
+    if (X >= lw) return;
+    typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
+    const float2v reject = splat(L.reject_fadeoff);
+    const bool pair_store = ((lw & 1) == 0);
+
+#pragma unroll 1
+    for (int k = 0; k < kRenTileH / 8; ++k) {
+        const int ly = tyl + 8 * k, Y = Y0 + ly;
+        if (Y >= lh) break;
+        const float *centre = &tile[(ly + kRenApron) * kRenLdsW + 2 * txl + kRenApron];
+        const float2v c = *reinterpret_cast<const float2v *>(centre);
+        const float2v inv_depth = float2v{1.0f / c.x, 1.0f / c.y};   // REN:140
+        // REN:162-168, accumulation order and table slots 1,3,4,8,11,6,10
+        float2v ao = splat(0.0f);
+        ao = fma2(splat(L.weight[0]), test_samples<2, 0>(centre, inv_depth, L.inv_thickness[0], L.front_depth[0], reject), ao);
+        ao = fma2(splat(L.weight[1]), test_samples<4, 0>(centre, inv_depth, L.inv_thickness[1], L.front_depth[1], reject), ao);
+        ao = fma2(splat(L.weight[2]), test_samples<1, 1>(centre, inv_depth, L.inv_thickness[2], L.front_depth[2], reject), ao);
+        ao = fma2(splat(L.weight[3]), test_samples<2, 2>(centre, inv_depth, L.inv_thickness[3], L.front_depth[3], reject), ao);
+        ao = fma2(splat(L.weight[4]), test_samples<3, 3>(centre, inv_depth, L.inv_thickness[4], L.front_depth[4], reject), ao);
+        ao = fma2(splat(L.weight[5]), test_samples<1, 3>(centre, inv_depth, L.inv_thickness[5], L.front_depth[5], reject), ao);
+        ao = fma2(splat(L.weight[6]), test_samples<2, 4>(centre, inv_depth, L.inv_thickness[6], L.front_depth[6], reject), ao);
+        const float2v out = fma2(splat(L.intensity), ao - splat(1.0f), splat(1.0f));   // lerp(1, ao, gIntensity) REN:176
+
+        typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
+        const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
+        if (pair_store) {
+            typename AO::type2 pr; pr.x = e0; pr.y = e1;
+            *reinterpret_cast<typename AO::type2 *>(p) = pr;
+        } else {
+            p[0] = e0;
+            if (X + 1 < lw) p[1] = e1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Upsample: depth-aware 5-tap separable blur of the low-res AO + bilateral 2x upsample.
+
+constexpr int kUpsLowW = kUpsTileW / 2, kUpsLowH = kUpsTileH / 2;   // 32 x 16
+constexpr int kUpsRawW = kUpsLowW + 6, kUpsRawH = kUpsLowH + 6;     // 38 x 22 raw taps
+constexpr int kUpsRawPitch = 40;
+constexpr int kUpsBlurW = kUpsLowW + 2, kUpsBlurH = kUpsLowH + 2;   // 34 x 18 blurred texels
+constexpr int kUpsBlurPitch = 36;
+
+struct BlurConsts { float step_size, blur_tolerance; };
+
+// CompareDeltas (UPS:83-87)
+__device__ __forceinline__ bool compare_deltas(const BlurConsts &k, float d1, float d2, float l1, float l2)
+{
+    const float t = mad(d1, d2, k.step_size);
+    return t * t > (l1 * l2) * k.blur_tolerance;
+}
+
+// One output of BlurHorizontally / BlurVertically (UPS:89-170): 5 AO taps a[], 5 inverse
+// depths z[], centred on tap 2; SmartBlur is UPS:74-81.
+__device__ __forceinline__ float smart_blur5(const BlurConsts &k, const float a[5], const float z[5])
+{
+    const float d01 = z[1] - z[0], d12 = z[2] - z[1], d23 = z[3] - z[2], d34 = z[4] - z[3];
+    const float l01 = mad(d01, d01, k.step_size), l12 = mad(d12, d12, k.step_size);
+    const float l23 = mad(d23, d23, k.step_size), l34 = mad(d34, d34, k.step_size);
+    const bool left = compare_deltas(k, d01, d12, l01, l12);
+    const bool middle = compare_deltas(k, d12, d23, l12, l23);
+    const bool right = compare_deltas(k, d23, d34, l23, l34);
+    const float pc = a[2];
+    const float pb = (left | middle) ? a[1] : pc;
+    const float pa = left ? a[0] : pb;
+    const float pd = (right | middle) ? a[3] : pc;
+    const float pe = right ? a[4] : pd;
+    return ((((pa + pe) * 0.5f + pb) + pc) + pd) * 0.25f;
+}
+
+// BilateralUpsample (UPS:177-183); taps already in weight order 9,3,1,3.
+__device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao, float d0, float d1, float d2,
+                                                    float d3, float a0, float a1, float a2, float a3,
+                                                    float tolerance, float noise)
+{
+    const float w0 = 9.0f / (__builtin_fabsf(hi_depth - d0) + tolerance);
+    const float w1 = 3.0f / (__builtin_fabsf(hi_depth - d1) + tolerance);
+    const float w2 = 1.0f / (__builtin_fabsf(hi_depth - d2) + tolerance);
+    const float w3 = 3.0f / (__builtin_fabsf(hi_depth - d3) + tolerance);
+    float total = ((w0 + w1) + w2) + w3;
+    total = total + noise;
+    float sum = a0 * w0;
+    sum = mad(a1, w1, sum);
+    sum = mad(a2, w2, sum);
+    sum = mad(a3, w3, sum);
+    sum = sum + noise;
+    return (hi_ao * sum) / total;
+}
+
+template <int AOFMT, bool RTNE, bool FINAL>
+__global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a)
+{
+    typedef AoTexel<AOFMT> AO;
+    typedef typename AO::type ao_t;
+    __shared__ float s_ao[kUpsRawH * kUpsRawPitch];     // LoResAO1 taps        (AOCache1 before blur)
+    __shared__ float s_inv[kUpsRawH * kUpsRawPitch];    // 1 / LoResDB          (DepthCache)
+    __shared__ float s_dep[kUpsRawH * kUpsRawPitch];    // LoResDB              (LoDepths gather)
+    __shared__ float s_hb[kUpsRawH * kUpsBlurPitch];    // after BlurHorizontally (AOCache2)
+    __shared__ float s_vb[kUpsBlurH * kUpsBlurPitch];   // after BlurVertically   (AOCache1)
+
+    const int frame = blockIdx.z;
+    const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+    const int HX0 = tile_x * kUpsTileW, HY0 = tile_y * kUpsTileH;
+    const int LX0 = HX0 >> 1, LY0 = HY0 >> 1;
+    const int lw = a.lw, lh = a.lh, hw = a.hw, hh = a.hh;
+    const float *__restrict__ lo_depth = frame_ptr(a.lo_depth, a.frame_stride, frame);
+    const ao_t *__restrict__ lo_ao = frame_ptr(static_cast<const ao_t *>(a.lo_ao), a.frame_stride, frame);
+    const BlurConsts bk = {a.step_size, a.blur_tolerance};
+
+    // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
+    // [LX0-3, LX0+34] x [LY0-3, LY0+18], clamp addressing per texel.
+    for (int i = threadIdx.x; i < kUpsRawW * kUpsRawH; i += kThreads) {
+        const int r = i / kUpsRawW, c = i % kUpsRawW;
+        const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
+        const size_t idx = static_cast<size_t>(cy) * lw + cx;
+        const float d = lo_depth[idx];
+        s_dep[r * kUpsRawPitch + c] = d;
+        s_inv[r * kUpsRawPitch + c] = 1.0f / d;                       // UPS:67
+        s_ao[r * kUpsRawPitch + c] = AO::decode(lo_ao[idx]);
+    }
+    __syncthreads();
+
+    // ---- BlurHorizontally: output (r, c) is centred on raw column c+2
+    for (int i = threadIdx.x; i < kUpsBlurW * kUpsRawH; i += kThreads) {
+        const int r = i / kUpsBlurW, c = i % kUpsBlurW;
+        float av[5], zv[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            av[t] = s_ao[r * kUpsRawPitch + c + t];
+            zv[t] = s_inv[r * kUpsRawPitch + c + t];
+        }
+        s_hb[r * kUpsBlurPitch + c] = smart_blur5(bk, av, zv);
+    }
+    __syncthreads();
+
+    // ---- BlurVertically: output (r, c) is centred on H-blurred row r+2; depths come from
+    // the same virtual column (DepthCache[... + 2], UPS:141-146)
+    for (int i = threadIdx.x; i < kUpsBlurW * kUpsBlurH; i += kThreads) {
+        const int r = i / kUpsBlurW, c = i % kUpsBlurW;
+        float av[5], zv[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            av[t] = s_hb[(r + t) * kUpsBlurPitch + c];
+            zv[t] = s_inv[(r + t) * kUpsRawPitch + c + 2];
+        }
+        s_vb[r * kUpsBlurPitch + c] = smart_blur5(bk, av, zv);
+    }
+    __syncthreads();
+
+    // ---- bilateral upsample: lane = 4 x 2 hi-res texels
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int hx0 = HX0 + 4 * tx, hy0 = HY0 + 2 * ty;
+    if (hx0 >= hw || hy0 >= hh) return;
+
+    float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            vb[rr][cc] = s_vb[(ty + rr) * kUpsBlurPitch + 2 * tx + cc];
+            dl[rr][cc] = s_dep[(ty + rr + 2) * kUpsRawPitch + 2 * tx + cc + 2];
+        }
+
+    ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
+                                   : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
+    const bool vec_ok = (hw & 3) == 0;
+    // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
+    constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
+
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int hy = hy0 + f;
+        if (hy >= hh) break;
+        const size_t hrow = static_cast<size_t>(hy) * hw + hx0;
+        float hd[4], ha[4] = {1.0f, 1.0f, 1.0f, 1.0f};                  // HiSSAOs = 1 in "main" (UPS:222)
+        if constexpr (FINAL) {
+            const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
+            if (vec_ok) {
+                const ushort4v q = *reinterpret_cast<const ushort4v *>(p);
+                hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
+                hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hd[e] = (hx0 + e < hw) ? f16_bits_to_f32(p[e]) : 1.0f;
+            }
+        } else {
+            const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
+            const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
+            if (vec_ok) {
+                const float4v d4 = *reinterpret_cast<const float4v *>(p);
+                hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
+                const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(q);
+                ha[0] = AO::decode(a4.x); ha[1] = AO::decode(a4.y);
+                ha[2] = AO::decode(a4.z); ha[3] = AO::decode(a4.w);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hd[e] = (hx0 + e < hw) ? p[e] : 1.0f;
+                    ha[e] = (hx0 + e < hw) ? AO::decode(q[e]) : 1.0f;
+                }
+            }
+        }
+        ao_t res[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // hi texel (4tx+e, 2ty+f) is written by dispatch thread D = ((hx+1)>>1, (hy+1)>>1)
+            // through Gather component comp (UPS:229-232); its taps are rotated by comp.
+            const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // D in vb/dl coordinates
+            const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+            const int g0 = comp & 3, g1 = (comp + 1) & 3, g2 = (comp + 2) & 3, g3 = (comp + 3) & 3;
+            const float v = bilateral_upsample(
+                hd[e], ha[e],
+                dl[rr + gy[g0]][cc + gx[g0]], dl[rr + gy[g1]][cc + gx[g1]],
+                dl[rr + gy[g2]][cc + gx[g2]], dl[rr + gy[g3]][cc + gx[g3]],
+                vb[rr + gy[g0]][cc + gx[g0]], vb[rr + gy[g1]][cc + gx[g1]],
+                vb[rr + gy[g2]][cc + gx[g2]], vb[rr + gy[g3]][cc + gx[g3]],
+                a.upsample_tolerance, a.noise_filter_strength);
+            res[e] = AO::template encode<RTNE>(v);
+        }
+        ao_t *o = dst + hrow;
+        if (vec_ok) {
+            typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
+            *reinterpret_cast<typename AO::type4 *>(o) = r4;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (hx0 + e < hw) o[e] = res[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TiledDepth<level> for the debug views: atlas texel (tx,ty) of slice s is level texel
+// (4tx + (s&3), 4ty + (s>>2)) (DS1:69-71,76-78; DS2:38-40,46-48), padded beyond the level.
+
+template <bool RTNE>
+__global__ __launch_bounds__(kThreads) void tile_atlas_kernel(const TileAtlasArgs a)
+{
+    const int n = 16 * a.sw * a.sh;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const int s = i / (a.sw * a.sh), rem = i % (a.sw * a.sh);
+        const int ty = rem / a.sw, tx = rem % a.sw;
+        const int x = 4 * tx + (s & 3), y = 4 * ty + (s >> 2);
+        const float v = (x < a.lw && y < a.lh) ? a.src[static_cast<size_t>(y) * a.lw + x] : a.pad_value;
+        a.dst[i] = f32_to_f16_bits<RTNE>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Self-tests: hardware conversions vs a bit-level software model (all inputs).
+
+__device__ uint16_t soft_f32_to_f16(float x, bool rtne)
+{
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const uint32_t sign = (u >> 16) & 0x8000u, absu = u & 0x7fffffffu;
+    if (absu >= 0x7f800000u) return static_cast<uint16_t>(sign | (absu == 0x7f800000u ? 0x7c00u : 0x7e00u));
+    const int e = static_cast<int>(absu >> 23) - 127;
+    const uint32_t m = absu & 0x7fffffu;
+    if (e > 15) return static_cast<uint16_t>(sign | (rtne ? 0x7c00u : 0x7bffu));
+    uint32_t h, rest, half;
+    if (e >= -14) { h = (static_cast<uint32_t>(e + 15) << 10) | (m >> 13); rest = m & 0x1fffu; half = 0x1000u; }
+    else if (e >= -25) { const uint32_t full = m | 0x800000u; const int sh = -e - 1; h = full >> sh; rest = full & ((1u << sh) - 1u); half = 1u << (sh - 1); }
+    else { h = 0; rest = absu ? 1u : 0u; half = 2u; }
+    if (rtne) { if (rest > half || (rest == half && (h & 1u))) h += 1u; if (h >= 0x7c00u) h = 0x7c00u; }
+    return static_cast<uint16_t>(sign | h);
+}
+
+template <bool RTNE>
+__global__ __launch_bounds__(kThreads) void selftest_f16_kernel(unsigned long long *count)
+{
+    unsigned long long bad = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kThreads;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __builtin_bit_cast(float, static_cast<uint32_t>(i));
+        const uint16_t hw = f32_to_f16_bits<RTNE>(x), sw = soft_f32_to_f16(x, RTNE);
+        const bool both_nan = (hw & 0x7fffu) > 0x7c00u && (sw & 0x7fffu) > 0x7c00u;
+        if (hw != sw && !both_nan) ++bad;
+    }
+    if (bad) atomicAdd(count, bad);
+}
+
+__global__ void selftest_unorm8_decode_kernel(unsigned long long *count)
+{
+    const uint32_t n = threadIdx.x;   // 256 threads
+    const float ref = static_cast<float>(n) / 255.0f;
+    if (unorm8_to_f32(n) != ref) atomicAdd(count, 1ull);
+}
+
+__global__ __launch_bounds__(kThreads) void selftest_f16_decode_kernel(unsigned long long *count)
+{
+    const uint32_t b = blockIdx.x * kThreads + threadIdx.x;   // 65536 inputs
+    const uint32_t sign = (b & 0x8000u) << 16, e = (b >> 10) & 0x1fu, m = b & 0x3ffu;
+    uint32_t ref;
+    if (e == 31) ref = sign | 0x7f800000u | (m << 13);
+    else if (e == 0) ref = sign | __builtin_bit_cast(uint32_t, static_cast<float>(m) * 5.9604644775390625e-8f);
+    else ref = sign | ((e + 112u) << 23) | (m << 13);
+    const uint32_t got = __builtin_bit_cast(uint32_t, f16_bits_to_f32(static_cast<uint16_t>(b)));
+    const bool both_nan = (got & 0x7fffffffu) > 0x7f800000u && (ref & 0x7fffffffu) > 0x7f800000u;
+    if (got != ref && !both_nan) atomicAdd(count, 1ull);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+
+hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
+{
+    const dim3 grid(a.tiles_x * a.tiles_y, 1, frames), block(kThreads);
+    const bool vec = (a.w[0] & 3) == 0;
+    if (a.f16_rtne) {
+        if (vec) downsample_kernel<true, true><<<grid, block, 0, s>>>(a);
+        else downsample_kernel<true, false><<<grid, block, 0, s>>>(a);
+    } else {
+        if (vec) downsample_kernel<false, true><<<grid, block, 0, s>>>(a);
+        else downsample_kernel<false, false><<<grid, block, 0, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s)
+{
+    const dim3 grid(a.blocks_per_frame, frames, 1), block(kThreads);
+    if (ao_format == MEAO_AO_R8) {
+        if (a.f16_rtne) render_kernel<MEAO_AO_R8, true><<<grid, block, 0, s>>>(a);
+        else render_kernel<MEAO_AO_R8, false><<<grid, block, 0, s>>>(a);
+    } else {
+        if (a.f16_rtne) render_kernel<MEAO_AO_F16, true><<<grid, block, 0, s>>>(a);
+        else render_kernel<MEAO_AO_F16, false><<<grid, block, 0, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+template <int AOFMT, bool RTNE>
+static void launch_upsample_t(const UpsampleArgs &a, bool final_pass, dim3 grid, hipStream_t s)
+{
+    if (final_pass) upsample_kernel<AOFMT, RTNE, true><<<grid, dim3(kThreads), 0, s>>>(a);
+    else upsample_kernel<AOFMT, RTNE, false><<<grid, dim3(kThreads), 0, s>>>(a);
+}
+
+hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames, hipStream_t s)
+{
+    const dim3 grid(a.tiles_x * a.tiles_y, 1, frames);
+    if (ao_format == MEAO_AO_R8) {
+        if (a.f16_rtne) launch_upsample_t<MEAO_AO_R8, true>(a, hi_depth_f16, grid, s);
+        else launch_upsample_t<MEAO_AO_R8, false>(a, hi_depth_f16, grid, s);
+    } else {
+        if (a.f16_rtne) launch_upsample_t<MEAO_AO_F16, true>(a, hi_depth_f16, grid, s);
+        else launch_upsample_t<MEAO_AO_F16, false>(a, hi_depth_f16, grid, s);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s)
+{
+    const int n = 16 * a.sw * a.sh;
+    const int blocks = (n + kThreads - 1) / kThreads;
+    if (a.f16_rtne) tile_atlas_kernel<true><<<dim3(blocks < 4096 ? blocks : 4096), dim3(kThreads), 0, s>>>(a);
+    else tile_atlas_kernel<false><<<dim3(blocks < 4096 ? blocks : 4096), dim3(kThreads), 0, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest(int which, unsigned long long *count, hipStream_t s)
+{
+    switch (which) {
+    case 0: selftest_f16_kernel<false><<<dim3(4096), dim3(kThreads), 0, s>>>(count); break;
+    case 1: selftest_f16_kernel<true><<<dim3(4096), dim3(kThreads), 0, s>>>(count); break;
+    case 2: selftest_unorm8_decode_kernel<<<dim3(1), dim3(256), 0, s>>>(count); break;
+    case 3: selftest_f16_decode_kernel<<<dim3(65536 / kThreads), dim3(kThreads), 0, s>>>(count); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace meao

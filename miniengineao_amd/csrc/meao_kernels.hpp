@@ -1,0 +1,86 @@
+// meao_kernels.hpp -- launch interface between the C ABI layer and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/meao.h"
+
+namespace meao {
+
+// ---------------------------------------------------------------------------------------
+// Downsample (Downsample1.main + Downsample2.main fused; no LDS, pure streaming)
+struct DownsampleArgs {
+    const float *depth[MEAO_MAX_BATCH];  // caller-owned raw depth, one pointer per frame
+    uint16_t *linear;                    // LinearDepth f16 L0, frame 0
+    float *low[4];                       // LowDepth1..4 f32, frame 0
+    uint64_t frame_stride;               // bytes between consecutive frames' intermediates
+    int32_t w[5], h[5];                  // mip 0..4 dims
+    float zp0, zp1;                      // ZBufferParams.xy
+    int32_t reversed_z;
+    int32_t f16_rtne;
+    int32_t tiles_x, tiles_y;
+};
+
+// ---------------------------------------------------------------------------------------
+// Render (Render.main_interleaved for all levels in one grid)
+constexpr int kRenTileW = 64, kRenTileH = 32;   // output texels per workgroup
+constexpr int kRenApron = 16;                   // 4 slice texels * interleave 4
+constexpr int kRenLdsW = kRenTileW + 2 * kRenApron, kRenLdsH = kRenTileH + 2 * kRenApron;
+
+struct RenderLevelArgs {
+    const float *src;      // LowDepth<level> f32, frame 0
+    void *dst;             // Occlusion<level>, frame 0
+    int32_t lw, lh;        // level dims (= output dims)
+    int32_t sw, sh;        // slice dims of TiledDepth<level> (mip level+2)
+    int32_t tiles_x, tiles_y;
+    int32_t block_begin;   // first linear workgroup id of this level
+    float pad_value;       // value of atlas texels beyond the level
+    float inv_thickness[7], front_depth[7], weight[7];
+    float reject_fadeoff, intensity;
+};
+
+struct RenderArgs {
+    RenderLevelArgs level[4];
+    uint64_t frame_stride;
+    int32_t num_levels;
+    int32_t blocks_per_frame;
+    int32_t f16_rtne;
+};
+
+// ---------------------------------------------------------------------------------------
+// Upsample (Upsample.main / main_blendout)
+constexpr int kUpsTileW = 64, kUpsTileH = 32;   // hi-res texels per workgroup
+
+struct UpsampleArgs {
+    const float *lo_depth;     // LoResDB  f32
+    const void *lo_ao;         // LoResAO1
+    const void *hi_depth;      // HiResDB  f32, or f16 in the final pass
+    const void *hi_ao;         // HiResAO, nullptr in the final pass
+    void *dst[MEAO_MAX_BATCH]; // per-frame destination (caller-owned in the final pass)
+    uint64_t frame_stride;     // applies to lo_*, hi_* (context-owned intermediates)
+    int32_t lw, lh, hw, hh;
+    int32_t tiles_x, tiles_y;
+    float noise_filter_strength, step_size, blur_tolerance, upsample_tolerance;
+    int32_t f16_rtne;
+};
+
+// ---------------------------------------------------------------------------------------
+// TiledDepth<level> materialisation for the debug views (Downsample1/2 atlas stores)
+struct TileAtlasArgs {
+    const float *src;     // LowDepth<level> of the requested frame
+    uint16_t *dst;        // [16][sh][sw] f16
+    int32_t lw, lh, sw, sh;
+    float pad_value;
+    int32_t f16_rtne;
+};
+
+hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s);
+hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
+hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
+                           hipStream_t s);
+hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s);
+// Exhaustive conversion self-tests; *count (device) receives the number of mismatches.
+hipError_t launch_selftest(int which, unsigned long long *count, hipStream_t s);
+
+}  // namespace meao
