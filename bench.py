@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the multi-scale SSAO hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|8k] [--batch B]
+
+A step = one pass of the full pipeline (downsample -> render x4 levels -> upsample x4) over
+one batch of B independent synthetic frames, depth already resident in HBM.  Prints ONE JSON
+line: Mpixels/s (whole job, all ranks), the roofline of the dominant kernel measured live
+with HIP events on the launch stream, and the CPU oracle timed on the host cores (rank 0,
+N=1 only) as a reported baseline.
+
+N>1: launched by torch.distributed.run, one rank per GPU; frames are sharded across ranks
+(weak scaling: B frames per rank), there is no data-path collective -- RCCL is used only for
+the barrier and the max-over-ranks of the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch  # before libmeao_hip.so: both then share torch's libamdhip64 (see _lib.py)
+import torch.distributed as dist
+
+from miniengineao_amd import AmbientOcclusion, _lib, synth
+from miniengineao_amd.sharding import frame_seed
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+HBM_COPY_CEILING_GBPS = 6290.0
+
+WORKLOADS = {
+    # name: (W, H, generator, camera, intensity, ao_format, description)
+    "4k": (3840, 2160, "S2", synth.DEFAULT_CAMERA, 1.0, _lib.AO_R8,
+           "4K (3840x2160) S2 synthetic depth, full 4-level pipeline, R8 AO"),
+    "1080p": (1920, 1080, "S3", synth.SPONZA_CAMERA, 1.1, _lib.AO_R8,
+              "1080p S3 Sponza-like atrium (substitute for captured Sponza depth), full 4-level pipeline, R8 AO"),
+    "8k": (7680, 4320, "S2", synth.DEFAULT_CAMERA, 1.0, _lib.AO_F16,
+           "8K (7680x4320) S2 synthetic depth, full 4-level pipeline, fp16 AO storage"),
+}
+
+
+def make_frame(kind: str, w: int, h: int, seed: int) -> np.ndarray:
+    if kind == "S3":
+        return synth.atrium(w, h)
+    return synth.make(kind, w, h, seed=seed)
+
+
+def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
+    """The oracle (a port of the reference passes), row-parallel on all host cores, timed on a
+    bounded sample of the same workload: whole frames of this workload, median of <=3 after
+    one warm-up, stopping early once ~budget_s of CPU time is spent."""
+    from oracle import oracle as O   # test infrastructure: used here only as the reported baseline
+    cores = os.cpu_count() or 1
+    s = O.Settings(w, h, proj00=cam.proj00(w, h), near_clip=cam.near, far_clip=cam.far,
+                   reversed_z=cam.reversed_z, intensity=intensity, ao_format=ao_format)
+    times = []
+    t_begin = time.perf_counter()
+    O.run(depth, s, nthreads=cores, result_only=True)       # warm-up
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.run(depth, s, nthreads=cores, result_only=True)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > budget_s:
+            break
+    med = float(np.median(times))
+    return {"value": round(w * h / med / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed full {w}x{h} frame(s) of the bench workload after 1 warm-up, "
+                      f"median; C oracle (oracle/meao_oracle.c) row-parallel on {cores} threads",
+            "seconds_per_frame": round(med, 4)}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
+    ap.add_argument("--batch", type=int, default=8, help="independent frames per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-latency", action="store_true",
+                    help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    w, h, kind, cam, intensity, ao_format, desc = WORKLOADS[args.workload]
+    B = max(1, min(args.batch, _lib.MAX_BATCH))
+    ao_dtype = torch.uint8 if ao_format == _lib.AO_R8 else torch.int16
+
+    # synthetic frames of this rank (global frame index = rank*B + f), resident in HBM
+    frames = [make_frame(kind, w, h, frame_seed(0x1234ABCD, rank * B + f)) for f in range(B)]
+    depth_dev = [torch.from_numpy(f).to(dev) for f in frames]
+    out_dev = [torch.empty((h, w), dtype=ao_dtype, device=dev) for _ in range(B)]
+
+    ao = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=B,
+                          near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
+                          reversed_z=cam.reversed_z)
+    ao.intensity = intensity
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    dptr = [t.data_ptr() for t in depth_dev]
+    optr = [t.data_ptr() for t in out_dev]
+
+    def step():
+        ao.execute_device(dptr, optr, stream)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ao.set_profiling(True)          # HIP events around every pass, on the launch stream
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    pass_ms, samples = ao.pass_times_ms()
+    ao.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_pixels = float(w) * h * B * args.steps * world
+    value = total_pixels / elapsed / 1e6
+
+    # roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration
+    alg = ao.algorithmic_bytes()                 # per frame, reference storage formats
+    dominant = int(np.argmax(pass_ms))
+    passes = []
+    for k in range(_lib.NUM_PASSES):
+        if pass_ms[k] <= 0:
+            continue
+        gbps = alg[k] * B / (pass_ms[k] * 1e-3) / 1e9
+        passes.append({"kernel": _lib.PASS_NAMES[k], "ms": round(pass_ms[k], 5),
+                       "algorithmic_MB": round(alg[k] * B / 1e6, 3), "GBps": round(gbps, 1),
+                       "frac": round(gbps / HBM_PEAK_GBPS, 4)})
+    dom_gbps = alg[dominant] * B / (pass_ms[dominant] * 1e-3) / 1e9
+    kernel_ms = float(sum(pass_ms))
+    whole_gbps = sum(alg) * B / (kernel_ms * 1e-3) / 1e9
+    ren_ups_gbps = sum(alg[1:]) * B / (sum(pass_ms[1:]) * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": _lib.PASS_NAMES[dominant], "achieved": round(dom_gbps, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBPS, 4),
+                "traffic": None, "launch_ms": round(pass_ms[dominant], 5), "event_samples": samples,
+                "whole_frame": {"GBps": round(whole_gbps, 1), "frac": round(whole_gbps / HBM_PEAK_GBPS, 4)},
+                "render_plus_upsample": {"GBps": round(ren_ups_gbps, 1),
+                                         "frac": round(ren_ups_gbps / HBM_PEAK_GBPS, 4)},
+                "vs_copy_ceiling_frac": round(dom_gbps / HBM_COPY_CEILING_GBPS, 4), "passes": passes}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w, h, cam, intensity, ao_format, frames[0])
+
+    # single-frame latency (one frame per launch sequence), for context
+    latency_ms = None
+    if not args.skip_latency:
+        fence()
+        lat_iters = 20
+        t0 = time.perf_counter()
+        for _ in range(lat_iters):
+            ao.execute_device(dptr[:1], optr[:1], stream)
+        torch.cuda.synchronize(dev)
+        latency_ms = (time.perf_counter() - t0) / lat_iters * 1e3
+
+    if rank == 0:
+        line = {
+            "metric": "AO Mpixels/s (full multi-scale SSAO pipeline, depth resident in HBM)",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "width": w, "height": h, "frames_per_step_per_gpu": B,
+                       "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
+                       "numerics": "strict (bit-exact vs CPU oracle)", "sharding": f"frames x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
+            "sum_kernel_ms_per_step": round(kernel_ms, 4),
+        }
+        print(json.dumps(line), flush=True)
+    ao.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,28 @@
+# usage: bash tests/run_pmc.sh <tag> [bench args...]   -- PMC passes, one counter group per run
+set -x
+TAG=${1:-r01}; shift
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > $OUT/counters_available.txt 2>&1
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o pmc -- python $REPO/bench.py --no-cpu-baseline --skip-latency --steps 3 --warmup 1 $BENCH_ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+BENCH_ARGS="$*"
+run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+cd $REPO
+python - <<'PY'
+import csv, glob, collections, os, sys
+out = os.environ.get('OUT') or sorted(glob.glob('gpurun_out/pmc_*'))[-1]
+for f in sorted(glob.glob(out + '/*/*counter_collection.csv')):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for row in csv.DictReader(open(f)):
+        k = row['Kernel_Name'].split('(')[0][-60:]; agg[k][row['Counter_Name']] += float(row['Counter_Value']); 
+        cnt[(k,row['Counter_Name'])] += 1
+    print('==', f)
+    for k, d in agg.items():
+        print(k, {c: round(v / cnt[(k,c)], 1) for c, v in d.items()})
+PY
+find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete
