@@ -27,9 +27,9 @@ if ROOT not in sys.path:
 
 import numpy as np
 import torch  # before libmeao_hip.so: both then share torch's libamdhip64 (see _lib.py)
-import torch.distributed as dist
 
 from miniengineao_amd import AmbientOcclusion, _lib, synth
+from miniengineao_amd import distributed as mdist
 from miniengineao_amd.sharding import frame_seed
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
@@ -100,9 +100,7 @@ def main() -> int:
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL on ROCm
+    mdist.init("nccl", dev)                                      # nccl == RCCL on ROCm
 
     w, h, kind, cam, intensity, ao_format, desc = WORKLOADS[args.workload]
     B = max(1, min(args.batch, _lib.MAX_BATCH))
@@ -125,10 +123,7 @@ def main() -> int:
         ao.execute_device(dptr, optr, stream)
 
     def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+        mdist.fence(dev)     # synchronize + barrier + synchronize
 
     for _ in range(args.warmup):
         step()
@@ -142,10 +137,7 @@ def main() -> int:
     pass_ms, samples = ao.pass_times_ms()
     ao.set_profiling(False)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = mdist.max_over_ranks(elapsed, dev)
 
     total_pixels = float(w) * h * B * args.steps * world
     value = total_pixels / elapsed / 1e6
@@ -204,8 +196,7 @@ def main() -> int:
         }
         print(json.dumps(line), flush=True)
     ao.close()
-    if world > 1:
-        dist.destroy_process_group()
+    mdist.shutdown()
     return 0
 
 

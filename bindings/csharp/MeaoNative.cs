@@ -1,0 +1,124 @@
+// MeaoNative.cs -- P/Invoke declarations for libmeao_hip.so (include/meao.h, ABI version 1).
+//
+// NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT: the build image has no dotnet/mono/csc
+// (SURVEY.md, "Environment facts").  tests/test_host_mirror.py cross-checks every
+// [DllImport] below against the C header (names, arity, struct field order) instead.
+//
+// One extern per C entry point; struct layouts are sequential and mirror the C structs
+// field by field (all members are 4-byte scalars except meao_desc.bytes).
+
+using System;
+using System.Runtime.InteropServices;
+
+namespace MiniEngineAO.Native
+{
+    public enum MeaoStatus
+    {
+        Ok = 0, InvalidArgument = -1, Hip = -2, OutOfMemory = -3,
+        Unsupported = -4, NoDevice = -5, BufferTooSmall = -6
+    }
+
+    public enum MeaoAoFormat { R8 = 0, F16 = 1 }
+    public enum MeaoF16Rounding { RtzClamp = 0, Rtne = 1 }
+    public enum MeaoNumerics { Strict = 0 }
+    public enum MeaoMem { Host = 0, Device = 1 }
+    public enum MeaoFormat { F32 = 0, F16 = 1, Unorm8 = 2 }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct MeaoConfig
+    {
+        public uint struct_size;
+        public int device;
+        public int width;
+        public int height;
+        public int num_levels;
+        public int ao_format;
+        public int f16_rounding;
+        public int numerics;
+        public int max_batch;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct MeaoParams
+    {
+        public uint struct_size;
+        public float noise_filter_tolerance;
+        public float blur_tolerance;
+        public float upsample_tolerance;
+        public float thickness_modifier;
+        public float intensity;
+        public float near_clip;
+        public float far_clip;
+        public float proj00;
+        public int reversed_z;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct MeaoDesc
+    {
+        public int debug_id;
+        public int width;
+        public int height;
+        public int slices;
+        public int format;
+        public ulong bytes;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct MeaoRenderConstants
+    {
+        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 12)] public float[] inv_thickness_table;
+        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 12)] public float[] sample_weight_table;
+        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 2)] public float[] inv_slice_dimension;
+        public float reject_fadeoff;
+        public float intensity;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct MeaoUpsampleConstants
+    {
+        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 2)] public float[] inv_low_resolution;
+        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 2)] public float[] inv_high_resolution;
+        public float noise_filter_strength;
+        public float step_size;
+        public float blur_tolerance;
+        public float upsample_tolerance;
+    }
+
+    public static class Meao
+    {
+        const string Lib = "meao_hip";   // libmeao_hip.so
+        public const int AbiVersion = 1;
+        public const int MaxBatch = 16;
+        public const int NumPasses = 6;
+
+        [DllImport(Lib)] public static extern int meao_abi_version();
+        [DllImport(Lib)] public static extern IntPtr meao_status_string(int status);
+        [DllImport(Lib)] public static extern void meao_default_config(out MeaoConfig cfg);
+        [DllImport(Lib)] public static extern void meao_default_params(out MeaoParams p);
+
+        [DllImport(Lib)] public static extern int meao_level_dims(int width, int height, int level, out int out_w, out int out_h);
+        [DllImport(Lib)] public static extern int meao_zbuffer_params(ref MeaoParams p, [Out] float[] out4);
+        [DllImport(Lib)] public static extern int meao_render_constants_for(int width, int height, ref MeaoParams p, int level, out MeaoRenderConstants constants);
+        [DllImport(Lib)] public static extern int meao_upsample_constants_for(int width, int height, ref MeaoParams p, int low_level, out MeaoUpsampleConstants constants);
+        [DllImport(Lib)] public static extern int meao_describe_buffer(ref MeaoConfig cfg, int debug_id, out MeaoDesc desc);
+        [DllImport(Lib)] public static extern int meao_algorithmic_bytes(ref MeaoConfig cfg, [Out] ulong[] bytes6);
+
+        [DllImport(Lib)] public static extern int meao_create(ref MeaoConfig cfg, out IntPtr ctx);
+        [DllImport(Lib)] public static extern int meao_destroy(IntPtr ctx);
+        [DllImport(Lib)] public static extern int meao_resize(IntPtr ctx, int width, int height);
+        [DllImport(Lib)] public static extern int meao_set_params(IntPtr ctx, ref MeaoParams p);
+        [DllImport(Lib)] public static extern int meao_get_params(IntPtr ctx, out MeaoParams p);
+        [DllImport(Lib)] public static extern int meao_get_config(IntPtr ctx, out MeaoConfig cfg);
+        [DllImport(Lib)] public static extern IntPtr meao_last_error(IntPtr ctx);
+
+        [DllImport(Lib)] public static extern int meao_execute(IntPtr ctx, IntPtr depth, int depth_loc, IntPtr ao_out, int out_loc, IntPtr stream);
+        [DllImport(Lib)] public static extern int meao_execute_batch(IntPtr ctx, int n, IntPtr[] depth, int depth_loc, IntPtr[] ao_out, int out_loc, IntPtr stream);
+        [DllImport(Lib)] public static extern int meao_synchronize(IntPtr ctx, IntPtr stream);
+
+        [DllImport(Lib)] public static extern int meao_get_intermediate(IntPtr ctx, int frame, int debug_id, IntPtr dst, ulong dst_capacity, int dst_loc, out MeaoDesc desc);
+        [DllImport(Lib)] public static extern int meao_set_profiling(IntPtr ctx, int enable);
+        [DllImport(Lib)] public static extern int meao_get_pass_times(IntPtr ctx, [Out] float[] ms6, out int samples);
+        [DllImport(Lib)] public static extern int meao_selftest(IntPtr ctx, int which, out ulong mismatches);
+    }
+}

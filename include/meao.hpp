@@ -1,0 +1,153 @@
+// meao.hpp -- header-only C++ host side over the C ABI of libmeao_hip.so (include/meao.h).
+//
+// The reference's host side is a compiled C# component, MiniEngineAO.AmbientOcclusion
+// (Assets/MiniEngineAO/AmbientOcclusion.cs, "AO.cs").  No C# toolchain exists in the build
+// image, so the compiled-language host mirror is this C++ class (the C# P/Invoke source a
+// maintainer would add is bindings/csharp/).  Same six public properties, same names and
+// defaults (AO.cs:20-68); camera terms, depth input and AO output are explicit.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "meao.h"
+
+namespace MiniEngineAO {
+
+class Error : public std::runtime_error {
+public:
+    Error(int32_t status, const std::string &what) : std::runtime_error(what), status_(status) {}
+    int32_t status() const { return status_; }
+
+private:
+    int32_t status_;
+};
+
+class AmbientOcclusion {
+public:
+    // ---- Exposed properties (AO.cs:20-68) ---------------------------------------------------
+    float noiseFilterTolerance = 0.0f;   // Range(-8, 0)
+    float blurTolerance = -4.6f;         // Range(-8, -1)
+    float upsampleTolerance = -12.0f;    // Range(-12, -1)
+    float thicknessModifier = 1.0f;      // Range(1, 10)
+    float intensity = 1.0f;              // Range(0, 2)
+    bool ambientOnly = true;             // composite-side flag (AO.cs:62-68)
+
+    // ---- camera terms Unity supplied implicitly (AO.cs:563-573) -----------------------------
+    float nearClipPlane = 0.3f;
+    float farClipPlane = 1000.0f;
+    float projection00 = 0.9742786f;     // camera.projectionMatrix[0,0]
+    bool usesReversedZBuffer = true;
+
+    AmbientOcclusion(int32_t pixelWidth, int32_t pixelHeight, int32_t device = 0,
+                     meao_ao_format aoFormat = MEAO_AO_R8, int32_t maxBatch = 1, int32_t numLevels = 4,
+                     meao_f16_rounding f16Rounding = MEAO_F16_RTZ_CLAMP)
+    {
+        meao_default_config(&cfg_);
+        cfg_.device = device;
+        cfg_.width = pixelWidth;
+        cfg_.height = pixelHeight;
+        cfg_.ao_format = aoFormat;
+        cfg_.max_batch = maxBatch;
+        cfg_.num_levels = numLevels;
+        cfg_.f16_rounding = f16Rounding;
+        const int32_t rc = meao_create(&cfg_, &ctx_);
+        if (rc != MEAO_OK) throw Error(rc, meao_last_error(nullptr));
+    }
+    AmbientOcclusion(const AmbientOcclusion &) = delete;
+    AmbientOcclusion &operator=(const AmbientOcclusion &) = delete;
+    ~AmbientOcclusion() { meao_destroy(ctx_); }   // OnDestroy (AO.cs:357-381)
+
+    int32_t width() const { return cfg_.width; }
+    int32_t height() const { return cfg_.height; }
+    size_t aoTexelBytes() const { return cfg_.ao_format == MEAO_AO_R8 ? 1 : 2; }
+
+    // Device-resident depth in -> AO texture out, asynchronous on `stream`
+    // (replays what RebuildCommandBuffers records, AO.cs:496-531).
+    void Render(const void *deviceDepth, void *deviceAo, meao_stream stream = nullptr)
+    {
+        sync();
+        check(meao_execute(ctx_, deviceDepth, MEAO_MEM_DEVICE, deviceAo, MEAO_MEM_DEVICE, stream));
+    }
+
+    void RenderBatch(const std::vector<const void *> &deviceDepth, const std::vector<void *> &deviceAo,
+                     meao_stream stream = nullptr)
+    {
+        sync();
+        check(meao_execute_batch(ctx_, static_cast<int32_t>(deviceDepth.size()), deviceDepth.data(),
+                                 MEAO_MEM_DEVICE, deviceAo.data(), MEAO_MEM_DEVICE, stream));
+    }
+
+    // Host arrays in and out (synchronous).
+    void RenderHost(const float *depth, void *ao)
+    {
+        sync();
+        check(meao_execute(ctx_, depth, MEAO_MEM_HOST, ao, MEAO_MEM_HOST, nullptr));
+    }
+
+    void Resize(int32_t pixelWidth, int32_t pixelHeight)   // screen-size change (AO.cs:338-341)
+    {
+        check(meao_resize(ctx_, pixelWidth, pixelHeight));
+        cfg_.width = pixelWidth;
+        cfg_.height = pixelHeight;
+    }
+
+    void Synchronize(meao_stream stream = nullptr) { check(meao_synchronize(ctx_, stream)); }
+
+    // The _debug 1..17 views (AO.cs:787-820), copied to the host.
+    std::vector<uint8_t> DebugBuffer(int32_t debugId, meao_desc *desc = nullptr, int32_t frame = 0)
+    {
+        meao_desc d{};
+        check(meao_get_intermediate(ctx_, frame, debugId, nullptr, 0, MEAO_MEM_HOST, &d));
+        std::vector<uint8_t> data(d.bytes);
+        check(meao_get_intermediate(ctx_, frame, debugId, data.data(), d.bytes, MEAO_MEM_HOST, &d));
+        if (desc) *desc = d;
+        return data;
+    }
+
+    meao_ctx *native() { return ctx_; }
+
+private:
+    void sync()   // CheckPropertiesChanged (AO.cs:104-113): push only what changed
+    {
+        meao_params p;
+        meao_default_params(&p);
+        p.noise_filter_tolerance = noiseFilterTolerance;
+        p.blur_tolerance = blurTolerance;
+        p.upsample_tolerance = upsampleTolerance;
+        p.thickness_modifier = thicknessModifier;
+        p.intensity = intensity;
+        p.near_clip = nearClipPlane;
+        p.far_clip = farClipPlane;
+        p.proj00 = projection00;
+        p.reversed_z = usesReversedZBuffer ? 1 : 0;
+        if (!applied_valid_ || !same(p, applied_)) {
+            check(meao_set_params(ctx_, &p));
+            applied_ = p;
+            applied_valid_ = true;
+        }
+    }
+    static bool same(const meao_params &a, const meao_params &b)
+    {
+        return a.noise_filter_tolerance == b.noise_filter_tolerance && a.blur_tolerance == b.blur_tolerance &&
+               a.upsample_tolerance == b.upsample_tolerance && a.thickness_modifier == b.thickness_modifier &&
+               a.intensity == b.intensity && a.near_clip == b.near_clip && a.far_clip == b.far_clip &&
+               a.proj00 == b.proj00 && a.reversed_z == b.reversed_z;
+    }
+    void check(int32_t rc)
+    {
+        if (rc == MEAO_OK) return;
+        std::string msg = meao_last_error(ctx_);
+        if (msg.empty()) msg = meao_status_string(rc);
+        throw Error(rc, msg);
+    }
+
+    meao_ctx *ctx_ = nullptr;
+    meao_config cfg_{};
+    meao_params applied_{};
+    bool applied_valid_ = false;
+};
+
+}  // namespace MiniEngineAO

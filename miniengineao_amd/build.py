@@ -66,6 +66,25 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str
     return LIB_PATH
 
 
+DEMO_PATH = os.path.join(LIB_DIR, "ao_host_demo")
+
+
+def build_host_demo(force: bool = False) -> str:
+    """examples/ao_host_demo.cpp: plain g++ host program over include/meao.hpp + the .so."""
+    src = os.path.join(os.path.dirname(_PKG), "examples", "ao_host_demo.cpp")
+    build_lib()
+    deps = [src, os.path.join(_INCLUDE, "meao.hpp"), os.path.join(_INCLUDE, "meao.h")]
+    if not force and os.path.exists(DEMO_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(DEMO_PATH) for d in deps):
+        return DEMO_PATH
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", f"-I{_INCLUDE}", src, "-o", DEMO_PATH,
+           f"-L{LIB_DIR}", "-lmeao_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"g++ failed:\n{proc.stdout}\n{proc.stderr}")
+    return DEMO_PATH
+
+
 if __name__ == "__main__":
     path = build_lib(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
     print(path)
+    print(build_host_demo(force="--force" in sys.argv))

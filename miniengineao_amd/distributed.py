@@ -1,0 +1,75 @@
+"""Multi-GPU plumbing for the batch case: one process per GPU, frames sharded across ranks,
+no data-path collective.  torch.distributed is used only for the barrier, the max-over-ranks of
+a timed region and gathering per-frame checksums (backend "nccl" is RCCL on ROCm; "gloo" on
+CPU for tests)."""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend: str = "nccl", device: "torch.device | None" = None) -> Tuple[int, int, int]:
+    """Initialise the default process group when WORLD_SIZE > 1.  Returns (rank, world, local_rank)."""
+    rank, world, local_rank = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        kwargs = {}
+        if backend == "nccl" and device is not None:
+            kwargs["device_id"] = device
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, local_rank
+
+
+def _tensor_device(device):
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return device
+    return torch.device("cpu")
+
+
+def fence(device: "torch.device | None" = None) -> None:
+    """synchronize + barrier + synchronize: both sides of a timed region."""
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, device: "torch.device | None" = None) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_tensor_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_checksums(local: List[int], device: "torch.device | None" = None) -> List[List[int]]:
+    """All ranks' per-frame 63-bit checksums, indexed [rank][local frame]."""
+    if not dist.is_initialized():
+        return [list(local)]
+    world = dist.get_world_size()
+    n = torch.tensor([len(local)], dtype=torch.int64, device=_tensor_device(device))
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    width = max(int(c.item()) for c in counts)
+    mine = torch.zeros(max(width, 1), dtype=torch.int64, device=_tensor_device(device))
+    if local:
+        mine[: len(local)] = torch.tensor([v & 0x7FFFFFFFFFFFFFFF for v in local], dtype=torch.int64)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [[int(v) for v in out[r][: int(counts[r].item())].tolist()] for r in range(world)]
+
+
+def shutdown() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()
