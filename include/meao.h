@@ -193,9 +193,11 @@ MEAO_API int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t deb
 MEAO_API int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable);
 MEAO_API int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *out_samples);
 
-/* Exhaustive device self-tests of the storage conversions and exact-division sequences the
- * kernels rely on; returns the number of mismatching inputs in *out_mismatches.
- * which: 0 = f32->f16 RTZ_CLAMP, 1 = f32->f16 RTNE, 2 = f32->unorm8, 3 = unorm8->f32. */
+/* Exhaustive device self-tests of what bit-exactness rests on; *out_mismatches = number of
+ * inputs whose hardware result differs from the IEEE / bit-level model.
+ * which: 0 = f32->f16 RTZ_CLAMP (all 2^32), 1 = f32->f16 RTNE (all 2^32), 2 = unorm8->f32 (256),
+ *        3 = f16->f32 (65536), 4 = exact reciprocal vs 1/x (all x, 2^-100<=|x|<=2^100),
+ *        5 = exact 3/x and 9/x (same range), 6 = exact a/b on hashed pairs (2^-60<=|a|,|b|<=2^60). */
 MEAO_API int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches);
 
 #ifdef __cplusplus

@@ -41,6 +41,10 @@ struct meao_ctx {
     uint64_t stage_depth_frame = 0, stage_out_frame = 0, atlas_scratch_bytes = 0;
     unsigned long long *counter = nullptr;
 
+    // operands of every divide provably inside the exact range of the v_rcp_f32 sequences
+    // (meao_kernels.hip "Exact division"); recomputed by update_plan()
+    int exact_rcp_div = 0;
+
     const void *last_out[MEAO_MAX_BATCH] = {};   // device address of the last results (debug id 17)
     int last_frames = 0;
 
@@ -103,6 +107,28 @@ void layout_slot(meao_ctx *ctx)
     ctx->slot_bytes = off;
 }
 
+// Divides on the path: 1/LoResDB, 1/centre depth, {9,3,1,3}/(|dHi-dLo| + tol), (HiAO*sum)/total.
+// Depths are Linear01 in [near/far, 1] or the sky value (1e5 in f32; 65504 after an RTZ f16
+// store, +inf after an RTNE one); weights are <= 9/tol; total and sum are >= noise strength.
+bool exact_rcp_div_applicable(const meao_config &c, const meao_params &p, const Plan &plan)
+{
+    if (c.f16_rounding != MEAO_F16_RTZ_CLAMP) return false;               // RTNE stores inf for sky
+    const float near_over_far = p.near_clip / p.far_clip;
+    if (!(near_over_far >= 0x1p-40f)) return false;                       // smallest Linear01 depth
+    for (int k = 0; k < 4; ++k) {
+        const meao_upsample_constants &u = plan.upsample[k];
+        if (!(u.upsample_tolerance >= 0x1p-44f && u.upsample_tolerance <= 0x1p20f)) return false;  // weights <= 9 * 2^44
+        if (!(u.noise_filter_strength >= 0x1p-30f && u.noise_filter_strength <= 0x1p50f)) return false;
+    }
+    return true;
+}
+
+void update_plan(meao_ctx *ctx)
+{
+    build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->prm, &ctx->plan);
+    ctx->exact_rcp_div = exact_rcp_div_applicable(ctx->cfg, ctx->prm, ctx->plan) ? 1 : 0;
+}
+
 void release_buffers(meao_ctx *ctx)
 {
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -116,7 +142,7 @@ void release_buffers(meao_ctx *ctx)
 
 int allocate_buffers(meao_ctx *ctx)
 {
-    build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->prm, &ctx->plan);
+    update_plan(ctx);
     layout_slot(ctx);
     MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->arena), ctx->slot_bytes * ctx->cfg.max_batch));
     return MEAO_OK;
@@ -209,6 +235,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     rn.num_levels = c.num_levels;
     rn.blocks_per_frame = blocks;
     rn.f16_rtne = rtne;
+    rn.exact_rcp_div = ctx->exact_rcp_div;
     MEAO_HIP(ctx, launch_render(rn, c.ao_format, n, stream));
     if (ev) ctx->ran[MEAO_PASS_RENDER] = true;
     MEAO_HIP(ctx, mark(2));
@@ -232,6 +259,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             up.blur_tolerance = k.blur_tolerance;
             up.upsample_tolerance = k.upsample_tolerance;
             up.f16_rtne = rtne;
+            up.exact_rcp_div = ctx->exact_rcp_div;
             if (hi > 0) {   // main_blendout: blend with Occlusion<hi>, write Combined<hi>
                 up.hi_depth = slot_ptr<float>(ctx, ctx->off_low[hi - 1]);
                 up.hi_ao = slot_ptr<void>(ctx, ctx->off_occ[hi - 1]);
@@ -437,7 +465,7 @@ int32_t meao_set_params(meao_ctx *ctx, const meao_params *p)
     if (p->struct_size != sizeof(meao_params)) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_set_params: struct_size mismatch (ABI)");
     if (!params_valid(*p)) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_set_params: non-finite or degenerate parameter");
     ctx->prm = *p;
-    build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->prm, &ctx->plan);
+    update_plan(ctx);
     return MEAO_OK;
 }
 
@@ -617,7 +645,7 @@ int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *o
 
 int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches)
 {
-    if (!ctx || !out_mismatches || which < 0 || which > 3) return MEAO_ERR_INVALID_ARGUMENT;
+    if (!ctx || !out_mismatches || which < 0 || which > 6) return MEAO_ERR_INVALID_ARGUMENT;
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     if (!ctx->counter) MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counter), sizeof(unsigned long long)));

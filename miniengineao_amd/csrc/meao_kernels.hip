@@ -211,47 +211,108 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleAr
 }
 
 // ------------------------------------------------------------------------------------------
+// Exact division without the generic IEEE expansion.
+//
+// DIV_EXACT_RCP: v_rcp_f32 (1 ulp) followed by fused Newton / remainder steps.  On gfx950 these
+// sequences return the correctly rounded quotient -- bit-identical to IEEE '/' -- for
+//   rcp_strict(x)        every x with 2^-100 <= |x| <= 2^100          (exhaustive, 2^32 inputs)
+//   div_const<3|9>(x)    every such x                                 (exhaustive)
+//   div_strict(a, b)     a = 0 or 2^-60 <= |a|,|b| <= 2^60            (Markstein's theorem: the
+//                        reciprocal is correctly rounded; 1.6e10 random pairs in tools/ubench_div)
+// and are re-verified on the running device by meao_selftest(4..6).  The host selects this mode
+// only when the operands are provably inside those ranges (RTZ depth storage, so no inf from sky
+// texels; tolerances inside the component's ranges), otherwise DIV_IEEE (hipcc's expansion).
+enum { DIV_EXACT_RCP = 0, DIV_IEEE = 1 };
+
+template <int DIV>
+__device__ __forceinline__ float rcp_strict(float x)
+{
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        const float r = __builtin_amdgcn_rcpf(x);
+        const float e = mad(-x, r, 1.0f);
+        return mad(e, r, r);
+    } else {
+        return 1.0f / x;
+    }
+}
+
+template <int DIV, int K>
+__device__ __forceinline__ float div_const(float x)   // K / x, K in {1, 3, 9}
+{
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if constexpr (K == 1) return rcp_strict<DIV>(x);
+        const float r = __builtin_amdgcn_rcpf(x);
+        const float q = static_cast<float>(K) * r;
+        const float e = mad(-x, q, static_cast<float>(K));
+        return mad(e, r, q);
+    } else {
+        return static_cast<float>(K) / x;
+    }
+}
+
+template <int DIV>
+__device__ __forceinline__ float div_strict(float a, float b)
+{
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        const float r = rcp_strict<DIV>(b);
+        const float q = a * r;
+        const float e = mad(-b, q, a);
+        return mad(e, r, q);
+    } else {
+        return a / b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Render: volumetric-obscurance AO, 36-sample checker set.
 
-// TestSamplePair (REN:60-75) for two horizontally adjacent output texels.
-__device__ __forceinline__ float2v test_sample_pair(const float *centre, int offset, float2v inv_range,
-                                                    float2v neg_front, float2v reject)
+// TestSamplePair (REN:60-75) for one output texel; s1/s2 are the two opposite depth samples.
+// saturate() folds into the clamp output modifier of v_mul/v_fma; clamp(d, p, 1) with
+// 0 <= p <= 1 is v_med3_f32(d, p, 1) (same value for every input incl. NaN d -> p).
+__device__ __forceinline__ float test_sample_pair(float s1, float s2, float inv_range, float neg_front, float reject)
+{
+    const float d1 = mad(s1, inv_range, neg_front);
+    const float d2 = mad(s2, inv_range, neg_front);
+    const float p1 = sat(reject * d1);
+    const float p2 = sat(reject * d2);
+    const float acc = __builtin_amdgcn_fmed3f(d1, p2, 1.0f) + __builtin_amdgcn_fmed3f(d2, p1, 1.0f);
+    return sat(mad(-p1, p2, acc));
+}
+
+// Two horizontally adjacent texels share every LDS address: one ds_read_b64 per sample.
+__device__ __forceinline__ float2v test_sample_pair2(const float *centre, int offset, float2v inv_range,
+                                                     float neg_front, float reject)
 {
     const float2v s1 = *reinterpret_cast<const float2v *>(centre + offset);
     const float2v s2 = *reinterpret_cast<const float2v *>(centre - offset);
-    const float2v d1 = fma2(s1, inv_range, neg_front);
-    const float2v d2 = fma2(s2, inv_range, neg_front);
-    const float2v p1 = sat2(reject * d1);
-    const float2v p2 = sat2(reject * d2);
-    const float2v one = splat(1.0f);
-    const float2v acc = min2(max2(d1, p2), one) + min2(max2(d2, p1), one);
-    return sat2(fma2(-p1, p2, acc));
+    return float2v{test_sample_pair(s1.x, s2.x, inv_range.x, neg_front, reject),
+                   test_sample_pair(s1.y, s2.y, inv_range.y, neg_front, reject)};
 }
 
 // TestSamples (REN:77-110).  (X, Y) are slice-texel offsets; one slice texel is 4 level
 // texels (4x4 interleave), so the LDS offset of (dx, dy) is 4*dy*pitch + 4*dx.
 template <int X, int Y>
 __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv_depth, float inv_thickness,
-                                                float front_depth, float2v reject)
+                                                float front_depth, float reject)
 {
     constexpr int P = 4 * kRenLdsW, Q = 4;
     const float2v inv_range = splat(inv_thickness) * inv_depth;
-    const float2v neg_front = splat(-front_depth);
+    const float neg_front = -front_depth;
     if constexpr (Y == 0) {
-        return splat(0.5f) * (test_sample_pair(centre, X * Q, inv_range, neg_front, reject) +
-                              test_sample_pair(centre, X * P, inv_range, neg_front, reject));
+        return splat(0.5f) * (test_sample_pair2(centre, X * Q, inv_range, neg_front, reject) +
+                              test_sample_pair2(centre, X * P, inv_range, neg_front, reject));
     } else if constexpr (X == Y) {
-        return splat(0.5f) * (test_sample_pair(centre, X * P - X * Q, inv_range, neg_front, reject) +
-                              test_sample_pair(centre, X * P + X * Q, inv_range, neg_front, reject));
+        return splat(0.5f) * (test_sample_pair2(centre, X * P - X * Q, inv_range, neg_front, reject) +
+                              test_sample_pair2(centre, X * P + X * Q, inv_range, neg_front, reject));
     } else {
-        return splat(0.25f) * (((test_sample_pair(centre, Y * P + X * Q, inv_range, neg_front, reject) +
-                                 test_sample_pair(centre, Y * P - X * Q, inv_range, neg_front, reject)) +
-                                test_sample_pair(centre, X * P + Y * Q, inv_range, neg_front, reject)) +
-                               test_sample_pair(centre, X * P - Y * Q, inv_range, neg_front, reject));
+        return splat(0.25f) * (((test_sample_pair2(centre, Y * P + X * Q, inv_range, neg_front, reject) +
+                                 test_sample_pair2(centre, Y * P - X * Q, inv_range, neg_front, reject)) +
+                                test_sample_pair2(centre, X * P + Y * Q, inv_range, neg_front, reject)) +
+                               test_sample_pair2(centre, X * P - Y * Q, inv_range, neg_front, reject));
     }
 }
 
-template <int AOFMT, bool RTNE>
+template <int AOFMT, bool RTNE, int DIV>
 __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
 {
     __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * kRenLdsW];
@@ -305,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
     const int X = X0 + 2 * txl;
     if (X >= lw) return;
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
-    const float2v reject = splat(L.reject_fadeoff);
+    const float reject = L.reject_fadeoff;
     const bool pair_store = ((lw & 1) == 0);
 
 #pragma unroll 1
@@ -314,7 +375,7 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
         if (Y >= lh) break;
         const float *centre = &tile[(ly + kRenApron) * kRenLdsW + 2 * txl + kRenApron];
         const float2v c = *reinterpret_cast<const float2v *>(centre);
-        const float2v inv_depth = float2v{1.0f / c.x, 1.0f / c.y};   // REN:140
+        const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
         // REN:162-168, accumulation order and table slots 1,3,4,8,11,6,10
         float2v ao = splat(0.0f);
         ao = fma2(splat(L.weight[0]), test_samples<2, 0>(centre, inv_depth, L.inv_thickness[0], L.front_depth[0], reject), ao);
@@ -346,43 +407,57 @@ constexpr int kUpsRawW = kUpsLowW + 6, kUpsRawH = kUpsLowH + 6;     // 38 x 22 r
 constexpr int kUpsRawPitch = 40;
 constexpr int kUpsBlurW = kUpsLowW + 2, kUpsBlurH = kUpsLowH + 2;   // 34 x 18 blurred texels
 constexpr int kUpsBlurPitch = 36;
+constexpr int kUpsHRun = 4, kUpsHSegs = (kUpsBlurW + kUpsHRun - 1) / kUpsHRun;   // 9 runs of 4 per row
+constexpr int kUpsVRun = 3, kUpsVSegs = kUpsBlurH / kUpsVRun;                    // 6 runs of 3 per column
+static_assert(kUpsVSegs * kUpsVRun == kUpsBlurH, "V-blur runs must tile the column");
+static_assert(kUpsHSegs * kUpsRawH <= kThreads && kUpsVSegs * kUpsBlurW <= kThreads, "one blur run per lane");
+static_assert(kUpsHSegs * kUpsHRun + 4 <= kUpsRawPitch, "H-blur runs may read into the row padding only");
 
 struct BlurConsts { float step_size, blur_tolerance; };
 
-// CompareDeltas (UPS:83-87)
-__device__ __forceinline__ bool compare_deltas(const BlurConsts &k, float d1, float d2, float l1, float l2)
+// A run of N consecutive outputs of BlurHorizontally / BlurVertically (UPS:89-170) from N+4 AO
+// taps a[] and inverse depths z[]: output n is centred on tap n+2.  Deltas, squared lengths and
+// CompareDeltas results are shared between neighbouring outputs exactly as the reference
+// shares them between the 3 (2) outputs of one lane; every output only depends on its own
+// 5-tap window.  CompareDeltas UPS:83-87, SmartBlur UPS:74-81.
+template <int N>
+__device__ __forceinline__ void blur_run(const BlurConsts &k, const float (&a)[N + 4], const float (&z)[N + 4],
+                                         float (&out)[N])
 {
-    const float t = mad(d1, d2, k.step_size);
-    return t * t > (l1 * l2) * k.blur_tolerance;
-}
-
-// One output of BlurHorizontally / BlurVertically (UPS:89-170): 5 AO taps a[], 5 inverse
-// depths z[], centred on tap 2; SmartBlur is UPS:74-81.
-__device__ __forceinline__ float smart_blur5(const BlurConsts &k, const float a[5], const float z[5])
-{
-    const float d01 = z[1] - z[0], d12 = z[2] - z[1], d23 = z[3] - z[2], d34 = z[4] - z[3];
-    const float l01 = mad(d01, d01, k.step_size), l12 = mad(d12, d12, k.step_size);
-    const float l23 = mad(d23, d23, k.step_size), l34 = mad(d34, d34, k.step_size);
-    const bool left = compare_deltas(k, d01, d12, l01, l12);
-    const bool middle = compare_deltas(k, d12, d23, l12, l23);
-    const bool right = compare_deltas(k, d23, d34, l23, l34);
-    const float pc = a[2];
-    const float pb = (left | middle) ? a[1] : pc;
-    const float pa = left ? a[0] : pb;
-    const float pd = (right | middle) ? a[3] : pc;
-    const float pe = right ? a[4] : pd;
-    return ((((pa + pe) * 0.5f + pb) + pc) + pd) * 0.25f;
+    float dz[N + 3], ln[N + 3];
+    bool keep[N + 2];
+#pragma unroll
+    for (int i = 0; i < N + 3; ++i) {
+        dz[i] = z[i + 1] - z[i];
+        ln[i] = mad(dz[i], dz[i], k.step_size);
+    }
+#pragma unroll
+    for (int i = 0; i < N + 2; ++i) {
+        const float t = mad(dz[i], dz[i + 1], k.step_size);
+        keep[i] = t * t > (ln[i] * ln[i + 1]) * k.blur_tolerance;
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const bool left = keep[n], middle = keep[n + 1], right = keep[n + 2];
+        const float pc = a[n + 2];
+        const float pb = (left | middle) ? a[n + 1] : pc;
+        const float pa = left ? a[n] : pb;
+        const float pd = (right | middle) ? a[n + 3] : pc;
+        const float pe = right ? a[n + 4] : pd;
+        out[n] = ((((pa + pe) * 0.5f + pb) + pc) + pd) * 0.25f;
+    }
 }
 
 // BilateralUpsample (UPS:177-183); taps already in weight order 9,3,1,3.
+template <int DIV>
 __device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao, float d0, float d1, float d2,
                                                     float d3, float a0, float a1, float a2, float a3,
                                                     float tolerance, float noise)
 {
-    const float w0 = 9.0f / (__builtin_fabsf(hi_depth - d0) + tolerance);
-    const float w1 = 3.0f / (__builtin_fabsf(hi_depth - d1) + tolerance);
-    const float w2 = 1.0f / (__builtin_fabsf(hi_depth - d2) + tolerance);
-    const float w3 = 3.0f / (__builtin_fabsf(hi_depth - d3) + tolerance);
+    const float w0 = div_const<DIV, 9>(__builtin_fabsf(hi_depth - d0) + tolerance);
+    const float w1 = div_const<DIV, 3>(__builtin_fabsf(hi_depth - d1) + tolerance);
+    const float w2 = div_const<DIV, 1>(__builtin_fabsf(hi_depth - d2) + tolerance);
+    const float w3 = div_const<DIV, 3>(__builtin_fabsf(hi_depth - d3) + tolerance);
     float total = ((w0 + w1) + w2) + w3;
     total = total + noise;
     float sum = a0 * w0;
@@ -390,19 +465,19 @@ __device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao,
     sum = mad(a2, w2, sum);
     sum = mad(a3, w3, sum);
     sum = sum + noise;
-    return (hi_ao * sum) / total;
+    return div_strict<DIV>(hi_ao * sum, total);
 }
 
-template <int AOFMT, bool RTNE, bool FINAL>
+template <int AOFMT, bool RTNE, bool FINAL, int DIV>
 __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a)
 {
     typedef AoTexel<AOFMT> AO;
     typedef typename AO::type ao_t;
-    __shared__ float s_ao[kUpsRawH * kUpsRawPitch];     // LoResAO1 taps        (AOCache1 before blur)
-    __shared__ float s_inv[kUpsRawH * kUpsRawPitch];    // 1 / LoResDB          (DepthCache)
-    __shared__ float s_dep[kUpsRawH * kUpsRawPitch];    // LoResDB              (LoDepths gather)
-    __shared__ float s_hb[kUpsRawH * kUpsBlurPitch];    // after BlurHorizontally (AOCache2)
-    __shared__ float s_vb[kUpsBlurH * kUpsBlurPitch];   // after BlurVertically   (AOCache1)
+    __shared__ __attribute__((aligned(16))) float s_ao[kUpsRawH * kUpsRawPitch];    // LoResAO1 taps (AOCache1 before blur)
+    __shared__ __attribute__((aligned(16))) float s_inv[kUpsRawH * kUpsRawPitch];   // 1 / LoResDB   (DepthCache)
+    __shared__ __attribute__((aligned(16))) float s_dep[kUpsRawH * kUpsRawPitch];   // LoResDB       (LoDepths gather)
+    __shared__ __attribute__((aligned(16))) float s_hb[kUpsRawH * kUpsBlurPitch];   // after BlurHorizontally (AOCache2)
+    __shared__ __attribute__((aligned(16))) float s_vb[kUpsBlurH * kUpsBlurPitch];  // after BlurVertically   (AOCache1)
 
     const int frame = blockIdx.z;
     const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
@@ -421,35 +496,40 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
         const size_t idx = static_cast<size_t>(cy) * lw + cx;
         const float d = lo_depth[idx];
         s_dep[r * kUpsRawPitch + c] = d;
-        s_inv[r * kUpsRawPitch + c] = 1.0f / d;                       // UPS:67
+        s_inv[r * kUpsRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
         s_ao[r * kUpsRawPitch + c] = AO::decode(lo_ao[idx]);
     }
     __syncthreads();
 
-    // ---- BlurHorizontally: output (r, c) is centred on raw column c+2
-    for (int i = threadIdx.x; i < kUpsBlurW * kUpsRawH; i += kThreads) {
-        const int r = i / kUpsBlurW, c = i % kUpsBlurW;
-        float av[5], zv[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            av[t] = s_ao[r * kUpsRawPitch + c + t];
-            zv[t] = s_inv[r * kUpsRawPitch + c + t];
-        }
-        s_hb[r * kUpsBlurPitch + c] = smart_blur5(bk, av, zv);
+    // ---- BlurHorizontally: one run of 4 outputs per lane; output (r, c) is centred on raw
+    // column c+2.  (Columns 34, 35 of the last run are scratch: they read the row padding.)
+    if (threadIdx.x < kUpsHSegs * kUpsRawH) {
+        const int r = threadIdx.x / kUpsHSegs, c0 = (threadIdx.x % kUpsHSegs) * kUpsHRun;
+        float av[kUpsHRun + 4], zv[kUpsHRun + 4], o[kUpsHRun];
+        const float4v a0 = *reinterpret_cast<const float4v *>(&s_ao[r * kUpsRawPitch + c0]);
+        const float4v a1 = *reinterpret_cast<const float4v *>(&s_ao[r * kUpsRawPitch + c0 + 4]);
+        const float4v z0 = *reinterpret_cast<const float4v *>(&s_inv[r * kUpsRawPitch + c0]);
+        const float4v z1 = *reinterpret_cast<const float4v *>(&s_inv[r * kUpsRawPitch + c0 + 4]);
+        av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+        zv[0] = z0.x; zv[1] = z0.y; zv[2] = z0.z; zv[3] = z0.w; zv[4] = z1.x; zv[5] = z1.y; zv[6] = z1.z; zv[7] = z1.w;
+        blur_run<kUpsHRun>(bk, av, zv, o);
+        *reinterpret_cast<float4v *>(&s_hb[r * kUpsBlurPitch + c0]) = float4v{o[0], o[1], o[2], o[3]};
     }
     __syncthreads();
 
-    // ---- BlurVertically: output (r, c) is centred on H-blurred row r+2; depths come from
-    // the same virtual column (DepthCache[... + 2], UPS:141-146)
-    for (int i = threadIdx.x; i < kUpsBlurW * kUpsBlurH; i += kThreads) {
-        const int r = i / kUpsBlurW, c = i % kUpsBlurW;
-        float av[5], zv[5];
+    // ---- BlurVertically: one run of 3 outputs per lane; output (r, c) is centred on H-blurred
+    // row r+2; depths come from the same virtual column (DepthCache[... + 2], UPS:141-146).
+    if (threadIdx.x < kUpsVSegs * kUpsBlurW) {
+        const int c = threadIdx.x % kUpsBlurW, r0 = (threadIdx.x / kUpsBlurW) * kUpsVRun;
+        float av[kUpsVRun + 4], zv[kUpsVRun + 4], o[kUpsVRun];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            av[t] = s_hb[(r + t) * kUpsBlurPitch + c];
-            zv[t] = s_inv[(r + t) * kUpsRawPitch + c + 2];
+        for (int t = 0; t < kUpsVRun + 4; ++t) {
+            av[t] = s_hb[(r0 + t) * kUpsBlurPitch + c];
+            zv[t] = s_inv[(r0 + t) * kUpsRawPitch + c + 2];
         }
-        s_vb[r * kUpsBlurPitch + c] = smart_blur5(bk, av, zv);
+        blur_run<kUpsVRun>(bk, av, zv, o);
+#pragma unroll
+        for (int n = 0; n < kUpsVRun; ++n) s_vb[(r0 + n) * kUpsBlurPitch + c] = o[n];
     }
     __syncthreads();
 
@@ -460,12 +540,14 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
 
     float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            vb[rr][cc] = s_vb[(ty + rr) * kUpsBlurPitch + 2 * tx + cc];
-            dl[rr][cc] = s_dep[(ty + rr + 2) * kUpsRawPitch + 2 * tx + cc + 2];
-        }
+    for (int rr = 0; rr < 3; ++rr) {
+        const float2v v0 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * kUpsBlurPitch + 2 * tx]);
+        const float2v v1 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * kUpsBlurPitch + 2 * tx + 2]);
+        const float2v d0 = *reinterpret_cast<const float2v *>(&s_dep[(ty + rr + 2) * kUpsRawPitch + 2 * tx + 2]);
+        const float2v d1 = *reinterpret_cast<const float2v *>(&s_dep[(ty + rr + 2) * kUpsRawPitch + 2 * tx + 4]);
+        vb[rr][0] = v0.x; vb[rr][1] = v0.y; vb[rr][2] = v1.x; vb[rr][3] = v1.y;
+        dl[rr][0] = d0.x; dl[rr][1] = d0.y; dl[rr][2] = d1.x; dl[rr][3] = d1.y;
+    }
 
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
                                    : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
@@ -514,7 +596,7 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
             const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // D in vb/dl coordinates
             const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
             const int g0 = comp & 3, g1 = (comp + 1) & 3, g2 = (comp + 2) & 3, g3 = (comp + 3) & 3;
-            const float v = bilateral_upsample(
+            const float v = bilateral_upsample<DIV>(
                 hd[e], ha[e],
                 dl[rr + gy[g0]][cc + gx[g0]], dl[rr + gy[g1]][cc + gx[g1]],
                 dl[rr + gy[g2]][cc + gx[g2]], dl[rr + gy[g3]][cc + gx[g3]],
@@ -605,6 +687,39 @@ __global__ __launch_bounds__(kThreads) void selftest_f16_decode_kernel(unsigned 
     if (got != ref && !both_nan) atomicAdd(count, 1ull);
 }
 
+// which = 4: rcp_strict, 5: div_const<3>, div_const<9>, 6: div_strict on hashed operand pairs
+__device__ __forceinline__ bool in_exact_range(float x, float lo, float hi)
+{
+    const float ax = __builtin_fabsf(x);
+    return ax >= lo && ax <= hi;
+}
+
+__global__ __launch_bounds__(kThreads) void selftest_div_kernel(unsigned long long *count, int which)
+{
+    unsigned long long bad = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kThreads;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __builtin_bit_cast(float, static_cast<uint32_t>(i));
+        if (which == 4) {
+            if (!in_exact_range(x, 0x1p-100f, 0x1p100f)) continue;
+            bad += rcp_strict<DIV_EXACT_RCP>(x) != 1.0f / x;
+        } else if (which == 5) {
+            if (!in_exact_range(x, 0x1p-100f, 0x1p100f)) continue;
+            bad += div_const<DIV_EXACT_RCP, 3>(x) != 3.0f / x;
+            bad += div_const<DIV_EXACT_RCP, 9>(x) != 9.0f / x;
+        } else {
+            if (!in_exact_range(x, 0x1p-60f, 0x1p60f)) continue;
+            uint32_t h = static_cast<uint32_t>(i) * 2654435761u + 0x9E3779B9u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const uint32_t ea = 127u - 60u + (h >> 24) % 121u;     // |a| in [2^-60, 2^60]
+            const float av = __builtin_bit_cast(float, (h & 0x807fffffu) | (ea << 23));
+            bad += div_strict<DIV_EXACT_RCP>(av, x) != av / x;
+            bad += div_strict<DIV_EXACT_RCP>(0.0f, x) != 0.0f / x;
+        }
+    }
+    if (bad) atomicAdd(count, bad);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -628,31 +743,36 @@ hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStre
 {
     const dim3 grid(a.blocks_per_frame, frames, 1), block(kThreads);
     if (ao_format == MEAO_AO_R8) {
-        if (a.f16_rtne) render_kernel<MEAO_AO_R8, true><<<grid, block, 0, s>>>(a);
-        else render_kernel<MEAO_AO_R8, false><<<grid, block, 0, s>>>(a);
+        if (a.f16_rtne) render_kernel<MEAO_AO_R8, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        else if (a.exact_rcp_div) render_kernel<MEAO_AO_R8, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
+        else render_kernel<MEAO_AO_R8, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
     } else {
-        if (a.f16_rtne) render_kernel<MEAO_AO_F16, true><<<grid, block, 0, s>>>(a);
-        else render_kernel<MEAO_AO_F16, false><<<grid, block, 0, s>>>(a);
+        if (a.f16_rtne) render_kernel<MEAO_AO_F16, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        else if (a.exact_rcp_div) render_kernel<MEAO_AO_F16, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
+        else render_kernel<MEAO_AO_F16, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
     }
     return hipGetLastError();
 }
 
-template <int AOFMT, bool RTNE>
+template <int AOFMT, bool RTNE, int DIV>
 static void launch_upsample_t(const UpsampleArgs &a, bool final_pass, dim3 grid, hipStream_t s)
 {
-    if (final_pass) upsample_kernel<AOFMT, RTNE, true><<<grid, dim3(kThreads), 0, s>>>(a);
-    else upsample_kernel<AOFMT, RTNE, false><<<grid, dim3(kThreads), 0, s>>>(a);
+    if (final_pass) upsample_kernel<AOFMT, RTNE, true, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
+    else upsample_kernel<AOFMT, RTNE, false, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
 }
 
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames, hipStream_t s)
 {
     const dim3 grid(a.tiles_x * a.tiles_y, 1, frames);
+    // exact_rcp_div is only ever set together with RTZ depth storage (no inf operands)
     if (ao_format == MEAO_AO_R8) {
-        if (a.f16_rtne) launch_upsample_t<MEAO_AO_R8, true>(a, hi_depth_f16, grid, s);
-        else launch_upsample_t<MEAO_AO_R8, false>(a, hi_depth_f16, grid, s);
+        if (a.f16_rtne) launch_upsample_t<MEAO_AO_R8, true, DIV_IEEE>(a, hi_depth_f16, grid, s);
+        else if (a.exact_rcp_div) launch_upsample_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(a, hi_depth_f16, grid, s);
+        else launch_upsample_t<MEAO_AO_R8, false, DIV_IEEE>(a, hi_depth_f16, grid, s);
     } else {
-        if (a.f16_rtne) launch_upsample_t<MEAO_AO_F16, true>(a, hi_depth_f16, grid, s);
-        else launch_upsample_t<MEAO_AO_F16, false>(a, hi_depth_f16, grid, s);
+        if (a.f16_rtne) launch_upsample_t<MEAO_AO_F16, true, DIV_IEEE>(a, hi_depth_f16, grid, s);
+        else if (a.exact_rcp_div) launch_upsample_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, hi_depth_f16, grid, s);
+        else launch_upsample_t<MEAO_AO_F16, false, DIV_IEEE>(a, hi_depth_f16, grid, s);
     }
     return hipGetLastError();
 }
@@ -673,6 +793,7 @@ hipError_t launch_selftest(int which, unsigned long long *count, hipStream_t s)
     case 1: selftest_f16_kernel<true><<<dim3(4096), dim3(kThreads), 0, s>>>(count); break;
     case 2: selftest_unorm8_decode_kernel<<<dim3(1), dim3(256), 0, s>>>(count); break;
     case 3: selftest_f16_decode_kernel<<<dim3(65536 / kThreads), dim3(kThreads), 0, s>>>(count); break;
+    case 4: case 5: case 6: selftest_div_kernel<<<dim3(4096), dim3(kThreads), 0, s>>>(count, which); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -46,6 +46,7 @@ struct RenderArgs {
     int32_t num_levels;
     int32_t blocks_per_frame;
     int32_t f16_rtne;
+    int32_t exact_rcp_div;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -63,6 +64,7 @@ struct UpsampleArgs {
     int32_t tiles_x, tiles_y;
     float noise_filter_strength, step_size, blur_tolerance, upsample_tolerance;
     int32_t f16_rtne;
+    int32_t exact_rcp_div;     // operands proven inside the exact range of the v_rcp_f32 sequences
 };
 
 // ---------------------------------------------------------------------------------------

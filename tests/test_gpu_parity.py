@@ -118,7 +118,7 @@ def test_batch_matches_per_frame(oracle):
         ao.close()
 
 
-@pytest.mark.parametrize("which", [0, 1, 2, 3])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6])
 def test_hardware_conversions_exhaustive(oracle, which):
     """All 2^32 f32 -> f16 inputs (both rounding modes), all 256 UNORM8 and all 65536 f16
     decodes: hardware conversion == the bit-level model the oracle uses."""
