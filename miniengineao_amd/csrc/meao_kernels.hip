@@ -490,14 +490,38 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
     // [LX0-3, LX0+34] x [LY0-3, LY0+18], clamp addressing per texel.
-    for (int i = threadIdx.x; i < kUpsRawW * kUpsRawH; i += kThreads) {
-        const int r = i / kUpsRawW, c = i % kUpsRawW;
-        const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
-        const size_t idx = static_cast<size_t>(cy) * lw + cx;
-        const float d = lo_depth[idx];
-        s_dep[r * kUpsRawPitch + c] = d;
-        s_inv[r * kUpsRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
-        s_ao[r * kUpsRawPitch + c] = AO::decode(lo_ao[idx]);
+    const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
+    if (interior_x) {
+        // no horizontal clamping inside this tile: one aligned 16-byte depth load (+ 4 AO texels)
+        // per lane covers the 40-texel row segment [LX0-4, LX0+35]
+        if (threadIdx.x < 10 * kUpsRawH) {
+            const int r = threadIdx.x / 10, k = threadIdx.x % 10;
+            const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
+            const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
+            const float4v d4 = *reinterpret_cast<const float4v *>(lo_depth + idx);
+            const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
+            const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float av[4] = {AO::decode(a4.x), AO::decode(a4.y), AO::decode(a4.z), AO::decode(a4.w)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * k + e - 1;
+                if (c >= 0 && c < kUpsRawW) {
+                    s_dep[r * kUpsRawPitch + c] = dv[e];
+                    s_inv[r * kUpsRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
+                    s_ao[r * kUpsRawPitch + c] = av[e];
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < kUpsRawW * kUpsRawH; i += kThreads) {
+            const int r = i / kUpsRawW, c = i % kUpsRawW;
+            const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
+            const size_t idx = static_cast<size_t>(cy) * lw + cx;
+            const float d = lo_depth[idx];
+            s_dep[r * kUpsRawPitch + c] = d;
+            s_inv[r * kUpsRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
+            s_ao[r * kUpsRawPitch + c] = AO::decode(lo_ao[idx]);
+        }
     }
     __syncthreads();
 
