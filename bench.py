@@ -76,13 +76,31 @@ def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
             "seconds_per_frame": round(med, 4)}
 
 
+def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate runs by
+    tests/run_pmc.sh, corrected as MI355X_MICROARCH.md prescribes; per frame, scaled here by the
+    frames per launch).  None when no measurement exists for this workload/kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+        row = table[workload][kernel]
+        return {"bytes": int(row["bytes_per_frame"] * frames_per_launch), "source": "profiles/pmc_traffic.json",
+                "note": row.get("note", "")}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
-    ap.add_argument("--batch", type=int, default=8, help="independent frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="independent frames per step per GPU (1..16)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="batches in flight: N contexts on N HIP streams, step k on stream k mod N "
+                         "(lets the HBM-bound downsample of one batch overlap the VALU-bound passes of another)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
@@ -109,33 +127,48 @@ def main() -> int:
     # synthetic frames of this rank (global frame index = rank*B + f), resident in HBM
     frames = [make_frame(kind, w, h, frame_seed(0x1234ABCD, rank * B + f)) for f in range(B)]
     depth_dev = [torch.from_numpy(f).to(dev) for f in frames]
-    out_dev = [torch.empty((h, w), dtype=ao_dtype, device=dev) for _ in range(B)]
+    nfl = max(1, args.in_flight)
+    out_dev = [[torch.empty((h, w), dtype=ao_dtype, device=dev) for _ in range(B)] for _ in range(nfl)]
 
-    ao = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=B,
-                          near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
-                          reversed_z=cam.reversed_z)
-    ao.intensity = intensity
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctxs = []
+    for _ in range(nfl):
+        c = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=B,
+                             near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
+                             reversed_z=cam.reversed_z)
+        c.intensity = intensity
+        ctxs.append(c)
+    ao = ctxs[0]
+    tstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]
+    streams = [t.cuda_stream for t in tstreams]
+    stream = streams[0]
     dptr = [t.data_ptr() for t in depth_dev]
-    optr = [t.data_ptr() for t in out_dev]
+    optrs = [[t.data_ptr() for t in outs] for outs in out_dev]
+    optr = optrs[0]
+    counter = [0]
 
     def step():
-        ao.execute_device(dptr, optr, stream)
+        k = counter[0] % nfl
+        counter[0] += 1
+        ctxs[k].execute_device(dptr, optrs[k], streams[k])
 
     def fence():
         mdist.fence(dev)     # synchronize + barrier + synchronize
 
     for _ in range(args.warmup):
         step()
-    ao.set_profiling(True)          # HIP events around every pass, on the launch stream
+    for c in ctxs:
+        c.set_profiling(True)       # HIP events around every pass, on the launch stream
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    pass_ms, samples = ao.pass_times_ms()
-    ao.set_profiling(False)
+    per_ctx = [c.pass_times_ms() for c in ctxs]
+    samples = sum(n for _, n in per_ctx)
+    pass_ms = [sum(ms[k] * n for ms, n in per_ctx) / max(samples, 1) for k in range(_lib.NUM_PASSES)]
+    for c in ctxs:
+        c.set_profiling(False)
 
     elapsed = mdist.max_over_ranks(elapsed, dev)
 
@@ -154,12 +187,13 @@ def main() -> int:
                        "algorithmic_MB": round(alg[k] * B / 1e6, 3), "GBps": round(gbps, 1),
                        "frac": round(gbps / HBM_PEAK_GBPS, 4)})
     dom_gbps = alg[dominant] * B / (pass_ms[dominant] * 1e-3) / 1e9
+    traffic = pmc_traffic(args.workload, _lib.PASS_NAMES[dominant], B)
     kernel_ms = float(sum(pass_ms))
     whole_gbps = sum(alg) * B / (kernel_ms * 1e-3) / 1e9
     ren_ups_gbps = sum(alg[1:]) * B / (sum(pass_ms[1:]) * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": _lib.PASS_NAMES[dominant], "achieved": round(dom_gbps, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBPS, 4),
-                "traffic": None, "launch_ms": round(pass_ms[dominant], 5), "event_samples": samples,
+                "traffic": traffic, "launch_ms": round(pass_ms[dominant], 5), "event_samples": samples,
                 "whole_frame": {"GBps": round(whole_gbps, 1), "frac": round(whole_gbps / HBM_PEAK_GBPS, 4)},
                 "render_plus_upsample": {"GBps": round(ren_ups_gbps, 1),
                                          "frac": round(ren_ups_gbps / HBM_PEAK_GBPS, 4)},
@@ -189,13 +223,15 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": desc, "width": w, "height": h, "frames_per_step_per_gpu": B,
                        "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
-                       "numerics": "strict (bit-exact vs CPU oracle)", "sharding": f"frames x{world}"},
+                       "numerics": "strict (bit-exact vs CPU oracle)", "sharding": f"frames x{world}",
+                       "batches_in_flight": nfl},
             "roofline": roofline, "cpu_baseline": cpu,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "sum_kernel_ms_per_step": round(kernel_ms, 4),
         }
         print(json.dumps(line), flush=True)
-    ao.close()
+    for c in ctxs:
+        c.close()
     mdist.shutdown()
     return 0
 

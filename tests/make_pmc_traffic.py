@@ -1,0 +1,63 @@
+"""Turn the rocprofv3 --pmc passes of tests/run_pmc.sh into profiles/pmc_traffic.json.
+
+    python tests/make_pmc_traffic.py gpurun_out/pmc_<tag> <workload> <frames_per_launch>
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  Correction per MI355X_MICROARCH.md
+(HBM section): on gfx950 FETCH_SIZE tallies a 128-byte request of a wide (16 B/lane) coalesced
+stream as 64 bytes, so kernels whose reads are 16 B/lane streams are doubled; this is calibrated
+on downsample_kernel, whose input bytes are known exactly (4 B x W x H per frame, read once).
+Kernels with narrower lanes are left raw and say so.  WRITE_SIZE is used as reported (it matches
+the known output bytes of every kernel here to <0.5 %).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+# kernel-name fragment -> (bench pass name(s), FETCH_SIZE factor, note)
+KERNELS = {
+    "downsample_kernel": ("downsample", 2.0, "reads are one 16 B/lane stream: FETCH_SIZE x2 (calibrated: equals 4*W*H bytes/frame)"),
+    "render_kernel": ("render", 2.0, "window fill is 16 B/lane: FETCH_SIZE x2"),
+    "upsample_kernel<0, false, true": ("upsample_L1_to_L0", 1.0, "8 B/lane (f16 depth) + 16 B/lane + 4 B/lane reads: FETCH_SIZE left raw (uncalibrated width); raw value equals compulsory + apron bytes"),
+    "upsample_kernel<0, false, false": ("upsample_blend_passes", 1.0, "mean of the three main_blendout launches; FETCH_SIZE raw"),
+}
+
+
+def mean_counter(root, group, counter):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(root, group, "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter:
+                out[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+def main():
+    root, workload, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fetch, write = mean_counter(root, "fetch", "FETCH_SIZE"), mean_counter(root, "write", "WRITE_SIZE")
+    table = {}
+    for frag, (name, factor, note) in KERNELS.items():
+        f = [v for k, v in fetch.items() if frag in k]
+        w = [v for k, v in write.items() if frag in k]
+        if not f or not w:
+            continue
+        fb, wb = f[0] * 1024 * factor, w[0] * 1024
+        table[name] = {"bytes_per_frame": round((fb + wb) / frames), "fetch_bytes_per_frame": round(fb / frames),
+                       "write_bytes_per_frame": round(wb / frames), "fetch_size_factor": factor,
+                       "frames_per_launch": frames, "note": note}
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    try:
+        full = json.load(open(path))
+    except OSError:
+        full = {}
+    full[workload] = table
+    full["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tests/run_pmc.sh); see tests/make_pmc_traffic.py"
+    json.dump(full, open(path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(table, indent=1))
+
+
+if __name__ == "__main__":
+    main()
