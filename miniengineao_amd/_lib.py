@@ -4,14 +4,19 @@ The library is the product; this module only declares its signatures.  There is 
 fallback: if the shared object is missing the import of the hot path fails loudly, and on a
 machine without a gfx950 device ``meao_create`` returns MEAO_ERR_NO_DEVICE.
 
-HIP runtime note: if ``torch`` is going to be used in the same process, import it *before*
-this module loads the library, so both share torch's bundled ``libamdhip64.so.7`` (same
-SONAME as /opt/rocm's; the dynamic loader then resolves ours to the already-loaded copy).
+HIP runtime note: a process must hold exactly one HIP runtime.  PyTorch-ROCm wheels bundle their
+own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``, the same as /opt/rocm's).  If torch is
+installed, ``load()`` therefore maps torch's copy first (without importing torch), so that our
+library's ``NEEDED libamdhip64.so.7`` resolves to it and a later ``import torch`` reuses the same
+runtime; loading /opt/rocm's copy first would leave a later-initialised torch without GPUs.
+Without torch the RUNPATH of the library (/opt/rocm/lib) is used.
 """
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmeao_hip.so")
@@ -102,6 +107,20 @@ class MeaoError(RuntimeError):
         self.status = status
 
 
+def _share_torch_hip_runtime() -> None:
+    if "torch" in sys.modules:
+        return                                  # torch already mapped its runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load libmeao_hip.so (built by ``python -m miniengineao_amd.build``).  Raises if absent."""
     global _lib
@@ -110,6 +129,7 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m miniengineao_amd.build` "
                 "(hipcc, gfx950).  There is no CPU fallback for the SSAO hot path.")
+        _share_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if the ABI lost a symbol

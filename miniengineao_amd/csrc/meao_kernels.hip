@@ -25,6 +25,8 @@
 //    of the hi-res depth and 4-byte stores of four AO texels.
 #include "meao_kernels.hpp"
 
+#include <type_traits>
+
 namespace meao {
 namespace {
 
@@ -113,10 +115,13 @@ struct AoTexel<MEAO_AO_F16> {
     static __device__ __forceinline__ float decode(type t) { return f16_bits_to_f32(t); }
 };
 
+// Intermediates of frame f live stride_bytes * f behind frame 0's.  Pointer arithmetic (not an
+// integer round trip) so the compiler keeps the global address space and emits global_load/store.
 template <typename T>
 __device__ __forceinline__ T *frame_ptr(T *base, uint64_t stride_bytes, int frame)
 {
-    return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(base) + stride_bytes * static_cast<uint64_t>(frame));
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type byte_t;
+    return reinterpret_cast<T *>(reinterpret_cast<byte_t *>(base) + stride_bytes * static_cast<uint64_t>(frame));
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,151 @@
+"""More GPU parity: randomized configurations, the device-pointer / stream path used by
+bench.py, context independence, error behaviour, the compiled C++ host, full-size 8K fp16."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from miniengineao_amd import _lib as L
+from miniengineao_amd import synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_configurations(oracle, seed):
+    """Random size (incl. widths that are not multiples of 4: scalar load/store paths), camera,
+    component properties inside the reference's Range attributes (AO.cs:20-52), storage modes,
+    level count, with sky patches: every buffer bit-exact."""
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(1, 420)), int(rng.integers(1, 300))
+    if seed % 5 == 0:
+        w = int(rng.integers(1, 90)) * 4                      # vector paths on small images too
+    reversed_z = bool(rng.integers(0, 2))
+    cam = synth.Camera(near=float(rng.uniform(0.01, 0.6)), far=float(rng.uniform(10, 2000)),
+                       fov_y_deg=float(rng.uniform(12, 90)), reversed_z=reversed_z)
+    s = H.settings(oracle, w, h, cam=cam, ao_format=int(rng.integers(0, 2)), f16_rounding=int(rng.integers(0, 2)),
+                   num_levels=int(rng.integers(1, 5)), noise_filter_tolerance=float(rng.uniform(-8, 0)),
+                   blur_tolerance=float(rng.uniform(-8, -1)), upsample_tolerance=float(rng.uniform(-12, -1)),
+                   thickness_modifier=float(rng.uniform(1, 10)), intensity=float(rng.uniform(0, 2)))
+    depth = synth.occluder_field(w, h, seed=seed, n_rects=24, n_discs=24, cam=cam)
+    if seed % 3 == 0:                                          # sky (1e5; overflows f16)
+        x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+        depth[y0:y0 + 40, x0:x0 + 60] = 0.0 if reversed_z else 1.0
+    want = oracle.run(depth, s)
+    ao = H.component(s)
+    try:
+        got = ao.render(depth)
+        assert np.array_equal(got, want["result"]), (seed, w, h, H.diff_report("result", got, want["result"]))
+        for i in H.valid_debug_ids(s.num_levels):
+            g = ao.debug_buffer(i)
+            assert np.array_equal(g, want[H.NAMES[i]]), (seed, w, h, H.diff_report(H.NAMES[i], g, want[H.NAMES[i]]))
+    finally:
+        ao.close()
+
+
+def test_device_pointers_and_streams_with_torch(oracle):
+    """The path bench.py uses: torch owns device memory and the stream, the library gets raw
+    addresses; batched, asynchronous, results identical to the host-pointer path."""
+    import torch
+    w, h, n = 512, 288, 6
+    s = H.settings(oracle, w, h)
+    dev = torch.device("cuda", 0)
+    depths = [synth.make("S2", w, h, seed=50 + f) for f in range(n)]
+    d_dev = [torch.from_numpy(d).to(dev) for d in depths]
+    o_dev = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(n)]
+    side = torch.cuda.Stream(dev)
+    ao = H.component(s, max_batch=8)
+    try:
+        torch.cuda.synchronize(dev)
+        ao.execute_device([t.data_ptr() for t in d_dev], [t.data_ptr() for t in o_dev], side.cuda_stream)
+        ao.synchronize(side.cuda_stream)
+        for f in range(n):
+            want = oracle.run(depths[f], s, result_only=True)["result"]
+            assert np.array_equal(o_dev[f].cpu().numpy(), want), f
+        assert np.array_equal(ao.debug_buffer(17, frame=3), o_dev[3].cpu().numpy())
+    finally:
+        ao.close()
+
+
+def test_contexts_are_independent(oracle):
+    """Two differently sized contexts used alternately (the reference's shared statics,
+    AO.cs:136-137,592-593, make this unsafe there)."""
+    s1, s2 = H.settings(oracle, 200, 120, intensity=0.7), H.settings(oracle, 131, 257, thickness_modifier=4.0)
+    d1, d2 = synth.make("S2", 200, 120, seed=1), synth.make("S2", 131, 257, seed=2)
+    a1, a2 = H.component(s1), H.component(s2)
+    try:
+        w1, w2 = oracle.run(d1, s1)["result"], oracle.run(d2, s2)["result"]
+        for _ in range(3):
+            assert np.array_equal(a1.render(d1), w1)
+            assert np.array_equal(a2.render(d2), w2)
+    finally:
+        a1.close()
+        a2.close()
+
+
+def test_error_behaviour_on_device(oracle):
+    s = H.settings(oracle, 64, 48, num_levels=2)
+    ao = H.component(s, max_batch=2)
+    lib = L.load()
+    try:
+        depth = synth.make("S1", 64, 48)
+        with pytest.raises(L.MeaoError) as e:                  # nothing executed yet
+            ao.debug_buffer(2)
+        assert e.value.status == L.ERR_INVALID_ARGUMENT
+        ao.render(depth)
+        d = L.Desc()
+        small = np.zeros(10, np.uint8)
+        rc = lib.meao_get_intermediate(ao._ctx, 0, 1, small.ctypes.data, small.nbytes, L.MEM_HOST, C.byref(d))
+        assert rc == L.ERR_BUFFER_TOO_SMALL and d.bytes == 64 * 48 * 2
+        with pytest.raises(L.MeaoError) as e:                  # level 3 not rendered with num_levels=2
+            ao.debug_buffer(12)
+        assert e.value.status == L.ERR_UNSUPPORTED
+        with pytest.raises(L.MeaoError):
+            ao.debug_buffer(2, frame=1)                        # only one frame was executed
+        with pytest.raises(L.MeaoError) as e:
+            ao.render_batch([depth, depth, depth])             # n > max_batch
+        assert e.value.status == L.ERR_INVALID_ARGUMENT
+        with pytest.raises(ValueError):
+            ao.render(np.zeros((10, 10), np.float32))
+        ao.intensity = float("nan")
+        with pytest.raises(L.MeaoError):
+            ao.render(depth)
+        assert b"non-finite" in lib.meao_last_error(ao._ctx)
+    finally:
+        ao.close()
+
+
+def test_compiled_cpp_host_program(oracle, tmp_path):
+    """examples/ao_host_demo.cpp (g++, include/meao.hpp, no Python in the loop) vs the oracle."""
+    from miniengineao_amd import build
+    exe = build.build_host_demo()
+    w, h = 333, 211
+    depth = synth.make("S2", w, h, seed=77)
+    (tmp_path / "d.f32").write_bytes(depth.tobytes())
+    out = tmp_path / "ao.u8"
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(exe) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    proc = subprocess.run([exe, str(w), str(h), str(tmp_path / "d.f32"), str(out), "1.25", "2.5"],
+                          capture_output=True, text=True, env=env)
+    assert proc.returncode == 0, proc.stderr
+    s = H.settings(oracle, w, h, intensity=1.25, thickness_modifier=2.5)
+    want = oracle.run(depth, s, result_only=True)["result"]
+    got = np.frombuffer(out.read_bytes(), np.uint8).reshape(h, w)
+    assert np.array_equal(got, want), H.diff_report("result", got, want)
+
+
+def test_8k_fp16_full_frame(oracle):
+    """BASELINE config 5: 7680x4320, fp16 AO storage, full multi-scale, bit-exact."""
+    w, h = 7680, 4320
+    depth = synth.make("S2", w, h)
+    s = H.settings(oracle, w, h, ao_format=1)
+    want = oracle.run(depth, s, nthreads=os.cpu_count() or 8, result_only=True)["result"]
+    ao = H.component(s)
+    try:
+        got = ao.render(depth)
+    finally:
+        ao.close()
+    assert np.array_equal(got, want), H.diff_report("result", got, want)
