@@ -84,7 +84,26 @@ def build_host_demo(force: bool = False) -> str:
     return DEMO_PATH
 
 
+def build_tools(force: bool = False):
+    """tools/*.hip: the microbenchmarks whose results DESIGN.md quotes (VALU issue rates, exactness of
+    the v_rcp_f32 division sequences).  Stand-alone HIP programs, run on the GPU box."""
+    out = []
+    tools = os.path.join(os.path.dirname(_PKG), "tools")
+    for name, extra in (("ubench_valu", []), ("ubench_div", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"])):
+        src, dst = os.path.join(tools, name + ".hip"), os.path.join(LIB_DIR, name)
+        if not force and os.path.exists(dst) and os.path.getmtime(dst) >= os.path.getmtime(src):
+            out.append(dst)
+            continue
+        os.makedirs(LIB_DIR, exist_ok=True)
+        proc = subprocess.run([hipcc(), "--offload-arch=gfx950", "-O2", *extra, src, "-o", dst], capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{proc.stderr}")
+        out.append(dst)
+    return out
+
+
 if __name__ == "__main__":
     path = build_lib(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
     print(path)
     print(build_host_demo(force="--force" in sys.argv))
+    print(*build_tools(force="--force" in sys.argv))

@@ -19,7 +19,8 @@ def env_world() -> Tuple[int, int, int]:
 def init(backend: str = "nccl", device: "torch.device | None" = None) -> Tuple[int, int, int]:
     """Initialise the default process group when WORLD_SIZE > 1.  Returns (rank, world, local_rank)."""
     rank, world, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("MEAO_FORCE_DIST") == "1"     # exercise the collective path with one rank
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         kwargs = {}
