@@ -125,97 +125,6 @@ __device__ __forceinline__ T *frame_ptr(T *base, uint64_t stride_bytes, int fram
 }
 
 // ------------------------------------------------------------------------------------------
-// Downsample: linearize + point-downsample to L1..L4.   Tile 128 x 32 full-res texels.
-//
-// Closed form of DS1+DS2 (SURVEY 8a a4/a5): LinearZ = lin(x,y); DS2x[i,j] = lin(2i,2j);
-// DS4x = lin(4i,4j); DS8x = lin(8i,8j); DS16x = lin(16i,16j) -- every level keeps the
-// top-left texel of its block, so a lane decides what to store from its own coordinates and
-// no LDS exchange is needed.
-
-constexpr int kDsTileW = 128, kDsTileH = 32, kDsRowsPerPass = 8;
-
-__device__ __forceinline__ float linearize(float depth, float zp0, float zp1, bool reversed)
-{
-    float dist = 1.0f / mad(zp0, depth, zp1);                       // DS1:40
-    if (reversed ? (depth == 0.0f) : (depth == 1.0f)) dist = 1e5f;  // DS1:41-45
-    return dist;
-}
-
-template <bool RTNE, bool VEC>
-__global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleArgs a)
-{
-    const int frame = blockIdx.z;
-    const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
-    const float *__restrict__ depth = a.depth[frame];
-    uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
-    float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
-    float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
-    float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
-    float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
-    const int W = a.w[0], H = a.h[0];
-    const bool reversed = a.reversed_z != 0;
-
-    const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
-    const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
-    if (x0 >= W) return;
-
-    float v[kDsTileH / kDsRowsPerPass][4];
-#pragma unroll
-    for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
-        const int y = yb + k * kDsRowsPerPass;
-        v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.5f;
-        if (y < H) {
-            const float *row = depth + static_cast<size_t>(y) * W + x0;
-            if constexpr (VEC) {
-                const float4v q = *reinterpret_cast<const float4v *>(row);
-                v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (x0 + e < W) v[k][e] = row[e];
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
-        const int y = yb + k * kDsRowsPerPass;
-        if (y >= H) continue;
-        float lin[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lin[e] = linearize(v[k][e], a.zp0, a.zp1, reversed);
-
-        uint16_t *lrow = linear + static_cast<size_t>(y) * W + x0;    // LinearZ[st] = dist (DS1:46)
-        if constexpr (VEC) {
-            ushort4v h;
-            h.x = f32_to_f16_bits<RTNE>(lin[0]); h.y = f32_to_f16_bits<RTNE>(lin[1]);
-            h.z = f32_to_f16_bits<RTNE>(lin[2]); h.w = f32_to_f16_bits<RTNE>(lin[3]);
-            *reinterpret_cast<ushort4v *>(lrow) = h;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (x0 + e < W) lrow[e] = f32_to_f16_bits<RTNE>(lin[e]);
-        }
-        if ((y & 1) == 0) {                                           // DS2x (DS1:64-70)
-            float *p = low1 + static_cast<size_t>(y >> 1) * a.w[1] + (x0 >> 1);
-            if constexpr (VEC) {
-                *reinterpret_cast<float2v *>(p) = float2v{lin[0], lin[2]};
-            } else {
-                p[0] = lin[0];
-                if (x0 + 2 < W) p[1] = lin[2];
-            }
-            if ((y & 3) == 0) {                                       // DS4x (DS1:73-77)
-                low2[static_cast<size_t>(y >> 2) * a.w[2] + (x0 >> 2)] = lin[0];
-                if ((y & 7) == 0 && (x0 & 7) == 0) {                  // DS8x (DS2:35-40)
-                    low3[static_cast<size_t>(y >> 3) * a.w[3] + (x0 >> 3)] = lin[0];
-                    if ((y & 15) == 0 && (x0 & 15) == 0)              // DS16x (DS2:43-49)
-                        low4[static_cast<size_t>(y >> 4) * a.w[4] + (x0 >> 4)] = lin[0];
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Exact division without the generic IEEE expansion.
 //
 // DIV_EXACT_RCP: v_rcp_f32 (1 ulp) followed by fused Newton / remainder steps.  On gfx950 these
@@ -265,6 +174,99 @@ __device__ __forceinline__ float div_strict(float a, float b)
         return mad(e, r, q);
     } else {
         return a / b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Downsample: linearize + point-downsample to L1..L4.   Tile 128 x 32 full-res texels.
+//
+// Closed form of DS1+DS2 (SURVEY 8a a4/a5): LinearZ = lin(x,y); DS2x[i,j] = lin(2i,2j);
+// DS4x = lin(4i,4j); DS8x = lin(8i,8j); DS16x = lin(16i,16j) -- every level keeps the
+// top-left texel of its block, so a lane decides what to store from its own coordinates and
+// no LDS exchange is needed.
+
+constexpr int kDsTileW = 128, kDsTileH = 32, kDsRowsPerPass = 8;
+
+template <int DIV>
+__device__ __forceinline__ float linearize(float depth, float zp0, float zp1, bool reversed)
+{
+    // ZBufferParams.x * d + ZBufferParams.y lies in [1, far/near] for every depth in [0, 1]
+    float dist = rcp_strict<DIV>(mad(zp0, depth, zp1));              // DS1:40
+    if (reversed ? (depth == 0.0f) : (depth == 1.0f)) dist = 1e5f;  // DS1:41-45
+    return dist;
+}
+
+template <bool RTNE, bool VEC, int DIV>
+__global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleArgs a)
+{
+    const int frame = blockIdx.z;
+    const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+    const float *__restrict__ depth = a.depth[frame];
+    uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
+    float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
+    float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
+    float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
+    float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
+    const int W = a.w[0], H = a.h[0];
+    const bool reversed = a.reversed_z != 0;
+
+    const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
+    const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
+    if (x0 >= W) return;
+
+    float v[kDsTileH / kDsRowsPerPass][4];
+#pragma unroll
+    for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
+        const int y = yb + k * kDsRowsPerPass;
+        v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.5f;
+        if (y < H) {
+            const float *row = depth + static_cast<size_t>(y) * W + x0;
+            if constexpr (VEC) {
+                const float4v q = *reinterpret_cast<const float4v *>(row);
+                v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (x0 + e < W) v[k][e] = row[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
+        const int y = yb + k * kDsRowsPerPass;
+        if (y >= H) continue;
+        float lin[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], a.zp0, a.zp1, reversed);
+
+        uint16_t *lrow = linear + static_cast<size_t>(y) * W + x0;    // LinearZ[st] = dist (DS1:46)
+        if constexpr (VEC) {
+            ushort4v h;
+            h.x = f32_to_f16_bits<RTNE>(lin[0]); h.y = f32_to_f16_bits<RTNE>(lin[1]);
+            h.z = f32_to_f16_bits<RTNE>(lin[2]); h.w = f32_to_f16_bits<RTNE>(lin[3]);
+            *reinterpret_cast<ushort4v *>(lrow) = h;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x0 + e < W) lrow[e] = f32_to_f16_bits<RTNE>(lin[e]);
+        }
+        if ((y & 1) == 0) {                                           // DS2x (DS1:64-70)
+            float *p = low1 + static_cast<size_t>(y >> 1) * a.w[1] + (x0 >> 1);
+            if constexpr (VEC) {
+                *reinterpret_cast<float2v *>(p) = float2v{lin[0], lin[2]};
+            } else {
+                p[0] = lin[0];
+                if (x0 + 2 < W) p[1] = lin[2];
+            }
+            if ((y & 3) == 0) {                                       // DS4x (DS1:73-77)
+                low2[static_cast<size_t>(y >> 2) * a.w[2] + (x0 >> 2)] = lin[0];
+                if ((y & 7) == 0 && (x0 & 7) == 0) {                  // DS8x (DS2:35-40)
+                    low3[static_cast<size_t>(y >> 3) * a.w[3] + (x0 >> 3)] = lin[0];
+                    if ((y & 15) == 0 && (x0 & 15) == 0)              // DS16x (DS2:43-49)
+                        low4[static_cast<size_t>(y >> 4) * a.w[4] + (x0 >> 4)] = lin[0];
+                }
+            }
+        }
     }
 }
 
@@ -759,11 +761,14 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
     const dim3 grid(a.tiles_x * a.tiles_y, 1, frames), block(kThreads);
     const bool vec = (a.w[0] & 3) == 0;
     if (a.f16_rtne) {
-        if (vec) downsample_kernel<true, true><<<grid, block, 0, s>>>(a);
-        else downsample_kernel<true, false><<<grid, block, 0, s>>>(a);
+        if (vec) downsample_kernel<true, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        else downsample_kernel<true, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
+    } else if (a.exact_rcp_div) {
+        if (vec) downsample_kernel<false, true, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
+        else downsample_kernel<false, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
     } else {
-        if (vec) downsample_kernel<false, true><<<grid, block, 0, s>>>(a);
-        else downsample_kernel<false, false><<<grid, block, 0, s>>>(a);
+        if (vec) downsample_kernel<false, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        else downsample_kernel<false, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
     }
     return hipGetLastError();
 }

@@ -19,6 +19,7 @@ struct DownsampleArgs {
     float zp0, zp1;                      // ZBufferParams.xy
     int32_t reversed_z;
     int32_t f16_rtne;
+    int32_t exact_rcp_div;
     int32_t tiles_x, tiles_y;
 };
 
