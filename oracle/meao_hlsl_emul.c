@@ -8,7 +8,7 @@
  * TEST INFRASTRUCTURE ONLY (see meao_oracle.h).  Its only purpose is to be
  * compared bit-for-bit with the gather-form oracle (meao_oracle.c): the two
  * share nothing but the storage conversions and the host constant helpers.
- * Parity vs reference outputs remains UNPINNED (no reference goldens exist).
+ * Parity vs the reference on its own platform remains UNPINNED (see meao_oracle.h for the pins).
  *
  * Citations: DS1/DS2/REN/UPS = Assets/MiniEngineAO/Shaders/{Downsample1,
  * Downsample2,Render,Upsample}.compute, AO.cs = AmbientOcclusion.cs.

@@ -1,9 +1,11 @@
 /*
  * meao_oracle.c -- gather-form CPU restatement of the MiniEngineAO hot path.
  *
- * TEST INFRASTRUCTURE ONLY (see meao_oracle.h).  Parity vs reference outputs is
- * UNPINNED by the reference itself (it has no tests / goldens and cannot run
- * here); pinned by agreement with meao_hlsl_emul.c + analytical KATs.
+ * TEST INFRASTRUCTURE ONLY (see meao_oracle.h).  The reference has no tests or
+ * goldens and its platform (Unity/D3D) is unavailable: parity against the
+ * reference running there is UNPINNED; pinned instead by fixtures produced by
+ * interpreting the reference's own shader source (oracle/hlsl_interp.py),
+ * agreement with meao_hlsl_emul.c, and analytical KATs.
  *
  * Structure: every output texel is written as a pure function of the input
  * depth image ("gather form") -- there are no thread groups, no LDS tiles and

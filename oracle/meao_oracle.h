@@ -6,14 +6,24 @@
  * load this library, and only as the checker / reported baseline.  The
  * product path (libmeao_hip.so) never links, loads or calls it.
  *
- * PARITY PIN: the reference (keijiro/MiniEngineAO) ships no golden vectors,
- * no tests and cannot be executed here (Unity + HLSL + C#, none available),
- * so parity against reference *outputs* is unpinned.  The pin used instead
- *  is: two independently structured restatements of the
- * same source -- this file's per-pixel gather form and meao_hlsl_emul.c's
- * literal thread-group/LDS emulation -- must agree bit-for-bit on all 17
- * intermediates, plus the analytical known-answer tests derived from the
- * reference source (tests/test_oracle_kat.py).
+ * PARITY PIN: the reference (keijiro/MiniEngineAO) ships no golden vectors
+ * and no tests, and Unity / a D3D GPU / fxc are not available, so parity
+ * against outputs of the reference *running on its own platform* is unpinned.
+ * What pins the oracle instead:
+ *  (1) the reference's own shader source text (Shaders/*.compute under
+ *      /root/reference) is executed by oracle/hlsl_interp.py, driven like
+ *      AmbientOcclusion.cs drives Unity; all 17 buffers are committed as
+ *      fixtures (tests/golden/ref_*.npz, generator committed) and both
+ *      restatements must reproduce them bit for bit.  The interpreter supplies
+ *      only what a driver/GPU would: the numerics contract and the resource /
+ *      format semantics -- those remain this project's canonical reading;
+ *  (2) two independently structured restatements -- this file's per-pixel
+ *      gather form and meao_hlsl_emul.c's literal thread-group/LDS emulation --
+ *      agree bit-for-bit on all 17 intermediates at many odd sizes and modes;
+ *  (3) analytical known-answer tests derived from the reference source
+ *      (tests/test_oracle_kat.py).
+ * The host-side C# constant math (AO.cs:561-573,660-771) is restated, not
+ * executed (no C# toolchain).
  *
  * Canonical numerics (DESIGN.md "Numerics contract"): IEEE-754 binary32,
  * round-to-nearest-even, correctly rounded '/' and sqrt; an HLSL expression
