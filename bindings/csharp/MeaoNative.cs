@@ -1,4 +1,4 @@
-// MeaoNative.cs -- P/Invoke declarations for libmeao_hip.so (include/meao.h, ABI version 1).
+// MeaoNative.cs -- P/Invoke declarations for libmeao_hip.so (include/meao.h, ABI version 2).
 //
 // NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT: the build image has no dotnet/mono/csc
 // (SURVEY.md, "Environment facts").  tests/test_host_mirror.py cross-checks every
@@ -22,6 +22,7 @@ namespace MiniEngineAO.Native
     public enum MeaoF16Rounding { RtzClamp = 0, Rtne = 1 }
     public enum MeaoNumerics { Strict = 0 }
     public enum MeaoMem { Host = 0, Device = 1 }
+    public enum MeaoDepthFormat { F32 = 0, Unorm16 = 1, Unorm24 = 2, F16 = 3 }
     public enum MeaoFormat { F32 = 0, F16 = 1, Unorm8 = 2 }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -36,6 +37,7 @@ namespace MiniEngineAO.Native
         public int f16_rounding;
         public int numerics;
         public int max_batch;
+        public int depth_format;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -88,7 +90,7 @@ namespace MiniEngineAO.Native
     public static class Meao
     {
         const string Lib = "meao_hip";   // libmeao_hip.so
-        public const int AbiVersion = 1;
+        public const int AbiVersion = 2;
         public const int MaxBatch = 16;
         public const int NumPasses = 6;
 

@@ -32,7 +32,7 @@ extern "C" {
 #define MEAO_API
 #endif
 
-#define MEAO_ABI_VERSION 1
+#define MEAO_ABI_VERSION 2
 #define MEAO_MAX_BATCH 16      /* frames per batched launch */
 #define MEAO_NUM_PASSES 6      /* downsample, render, upsample x4 (see meao_pass) */
 
@@ -64,6 +64,16 @@ typedef enum meao_numerics { MEAO_NUMERICS_STRICT = 0 } meao_numerics;
 
 typedef enum meao_mem { MEAO_MEM_HOST = 0, MEAO_MEM_DEVICE = 1 } meao_mem;
 
+/* Storage of the input depth buffer.  The reference first blits _CameraDepthTexture -- whatever
+ * its format -- into an RFloat copy (Blit.shader:48-64 pass 0, AO.cs:608-614) unless D3D's
+ * resolved depth is available; here the downsample kernel decodes the format on load, so that
+ * pass does not exist.  UNORM formats decode to v / (2^n - 1), correctly rounded (what
+ * SAMPLE_DEPTH_TEXTURE returns): UNORM16 = D16, UNORM24 = the low 24 bits of a 32-bit word
+ * (D24S8 / D24X8; the high byte is ignored).  F16 decodes exactly. */
+typedef enum meao_depth_format {
+    MEAO_DEPTH_F32 = 0, MEAO_DEPTH_UNORM16 = 1, MEAO_DEPTH_UNORM24 = 2, MEAO_DEPTH_F16 = 3
+} meao_depth_format;
+
 typedef enum meao_format { MEAO_FMT_F32 = 0, MEAO_FMT_F16 = 1, MEAO_FMT_UNORM8 = 2 } meao_format;
 
 /* Kernel launches of one frame/batch, in stream order. */
@@ -86,6 +96,7 @@ typedef struct meao_config {
     int32_t f16_rounding;   /* meao_f16_rounding */
     int32_t numerics;       /* meao_numerics */
     int32_t max_batch;      /* 1..MEAO_MAX_BATCH frames resident per launch */
+    int32_t depth_format;   /* meao_depth_format of the depth pointers given to meao_execute* */
 } meao_config;
 
 /* The component's serialized properties (AO.cs:20-68; defaults there) and the camera terms
@@ -167,7 +178,8 @@ MEAO_API int32_t meao_get_config(const meao_ctx *ctx, meao_config *out);
 MEAO_API const char *meao_last_error(const meao_ctx *ctx);
 
 /* ---- the hot path (replaces the recorded "SSAO" CommandBuffer, AO.cs:496-531) ----------- */
-/* depth: width*height float32 raw device depth, row-major, tightly packed
+/* depth: width*height raw device depth texels in cfg.depth_format (default float32), row-major,
+ *        tightly packed
  *        (_CameraDepthTexture / ResolvedDepth, AO.cs:608-641).
  * ao_out: width*height AO texels in cfg.ao_format (the "AmbientOcclusion" RT, AO.cs:475).
  * *_loc: meao_mem; HOST pointers are staged through context-owned device buffers.

@@ -43,7 +43,8 @@ public:
 
     AmbientOcclusion(int32_t pixelWidth, int32_t pixelHeight, int32_t device = 0,
                      meao_ao_format aoFormat = MEAO_AO_R8, int32_t maxBatch = 1, int32_t numLevels = 4,
-                     meao_f16_rounding f16Rounding = MEAO_F16_RTZ_CLAMP)
+                     meao_f16_rounding f16Rounding = MEAO_F16_RTZ_CLAMP,
+                     meao_depth_format depthFormat = MEAO_DEPTH_F32)
     {
         meao_default_config(&cfg_);
         cfg_.device = device;
@@ -53,6 +54,7 @@ public:
         cfg_.max_batch = maxBatch;
         cfg_.num_levels = numLevels;
         cfg_.f16_rounding = f16Rounding;
+        cfg_.depth_format = depthFormat;
         const int32_t rc = meao_create(&cfg_, &ctx_);
         if (rc != MEAO_OK) throw Error(rc, meao_last_error(nullptr));
     }
@@ -81,7 +83,7 @@ public:
     }
 
     // Host arrays in and out (synchronous).
-    void RenderHost(const float *depth, void *ao)
+    void RenderHost(const void *depth, void *ao)
     {
         sync();
         check(meao_execute(ctx_, depth, MEAO_MEM_HOST, ao, MEAO_MEM_HOST, nullptr));

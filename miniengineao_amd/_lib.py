@@ -21,7 +21,7 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmeao_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_BATCH = 16
 NUM_PASSES = 6
 PASS_NAMES = ("downsample", "render", "upsample_L4_to_L3", "upsample_L3_to_L2",
@@ -34,13 +34,15 @@ AO_R8, AO_F16 = 0, 1
 F16_RTZ_CLAMP, F16_RTNE = 0, 1
 NUMERICS_STRICT = 0
 MEM_HOST, MEM_DEVICE = 0, 1
+DEPTH_F32, DEPTH_UNORM16, DEPTH_UNORM24, DEPTH_F16 = 0, 1, 2, 3
 FMT_F32, FMT_F16, FMT_UNORM8 = 0, 1, 2
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("width", C.c_int32),
                 ("height", C.c_int32), ("num_levels", C.c_int32), ("ao_format", C.c_int32),
-                ("f16_rounding", C.c_int32), ("numerics", C.c_int32), ("max_batch", C.c_int32)]
+                ("f16_rounding", C.c_int32), ("numerics", C.c_int32), ("max_batch", C.c_int32),
+                ("depth_format", C.c_int32)]
 
 
 class Params(C.Structure):

@@ -32,7 +32,8 @@ class AmbientOcclusion:
 
     def __init__(self, width: int, height: int, *, device: int = 0, num_levels: int = 4,
                  ao_format: int = L.AO_R8, f16_rounding: int = L.F16_RTZ_CLAMP,
-                 max_batch: int = 1, near_clip: float = 0.3, far_clip: float = 1000.0,
+                 max_batch: int = 1, depth_format: int = L.DEPTH_F32,
+                 near_clip: float = 0.3, far_clip: float = 1000.0,
                  projection00: Optional[float] = None, reversed_z: bool = True):
         self._lib = L.load()
         cfg = L.Config()
@@ -40,6 +41,7 @@ class AmbientOcclusion:
         cfg.device, cfg.width, cfg.height = device, width, height
         cfg.num_levels, cfg.ao_format, cfg.f16_rounding = num_levels, ao_format, f16_rounding
         cfg.max_batch = max_batch
+        cfg.depth_format = depth_format
         self._cfg = cfg
         prm = L.Params()
         self._lib.meao_default_params(C.byref(prm))
@@ -107,13 +109,16 @@ class AmbientOcclusion:
 
     # ---- the hot path ------------------------------------------------------------------
     def render(self, depth: np.ndarray) -> np.ndarray:
-        """One frame, host arrays: float32 (H, W) raw depth -> AO (H, W) uint8 / f16 bits."""
+        """One frame, host arrays: (H, W) raw depth in the configured depth_format (float32 by
+        default; uint16 / uint32 codes for UNORM16 / UNORM24 / F16 bits) -> AO (H, W) uint8 / f16 bits."""
         return self.render_batch([depth])[0]
 
     def render_batch(self, depths: Sequence[np.ndarray]) -> list:
         n = len(depths)
         self._sync_params()
-        ins = [np.ascontiguousarray(d, dtype=np.float32) for d in depths]
+        dt = {L.DEPTH_F32: np.float32, L.DEPTH_UNORM16: np.uint16, L.DEPTH_UNORM24: np.uint32,
+              L.DEPTH_F16: np.uint16}[self._cfg.depth_format]
+        ins = [np.ascontiguousarray(d, dtype=dt) for d in depths]
         for d in ins:
             if d.shape != (self.height, self.width):
                 raise ValueError(f"depth shape {d.shape} != ({self.height}, {self.width})")

@@ -89,6 +89,7 @@ bool config_valid(const meao_config &c, std::string *why)
     if (c.ao_format != MEAO_AO_R8 && c.ao_format != MEAO_AO_F16) { *why = "unknown ao_format"; return false; }
     if (c.f16_rounding != MEAO_F16_RTZ_CLAMP && c.f16_rounding != MEAO_F16_RTNE) { *why = "unknown f16_rounding"; return false; }
     if (c.max_batch < 1 || c.max_batch > MEAO_MAX_BATCH) { *why = "max_batch must be 1..MEAO_MAX_BATCH"; return false; }
+    if (c.depth_format < MEAO_DEPTH_F32 || c.depth_format > MEAO_DEPTH_F16) { *why = "unknown depth_format"; return false; }
     return true;
 }
 
@@ -192,7 +193,8 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
 
     // ---- PushDownsampleCommands (AO.cs:604-658)
     DownsampleArgs ds{};
-    for (int f = 0; f < n; ++f) ds.depth[f] = static_cast<const float *>(depth_dev[f]);
+    for (int f = 0; f < n; ++f) ds.depth[f] = depth_dev[f];
+    ds.depth_format = c.depth_format;
     ds.linear = slot_ptr<uint16_t>(ctx, ctx->off_linear);
     for (int k = 0; k < 4; ++k) ds.low[k] = slot_ptr<float>(ctx, ctx->off_low[k]);
     ds.frame_stride = ctx->slot_bytes;
@@ -317,6 +319,7 @@ void meao_default_config(meao_config *cfg)
     cfg->f16_rounding = MEAO_F16_RTZ_CLAMP;
     cfg->numerics = MEAO_NUMERICS_STRICT;
     cfg->max_batch = 1;
+    cfg->depth_format = MEAO_DEPTH_F32;
 }
 
 void meao_default_params(meao_params *p)
@@ -382,7 +385,7 @@ int32_t meao_algorithmic_bytes(const meao_config *cfg, uint64_t bytes[MEAO_NUM_P
 {
     std::string why;
     if (!cfg || !bytes || !config_valid(*cfg, &why)) return MEAO_ERR_INVALID_ARGUMENT;
-    algorithmic_bytes(cfg->width, cfg->height, cfg->num_levels, cfg->ao_format, bytes);
+    algorithmic_bytes(cfg->width, cfg->height, cfg->num_levels, cfg->ao_format, cfg->depth_format, bytes);
     return MEAO_OK;
 }
 
@@ -500,7 +503,7 @@ int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth, i
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->own_stream;
 
     const uint64_t px = static_cast<uint64_t>(ctx->cfg.width) * ctx->cfg.height;
-    const uint64_t depth_bytes = px * 4, out_bytes = px * ao_elem(ctx->cfg);
+    const uint64_t depth_bytes = px * depth_elem(ctx->cfg.depth_format), out_bytes = px * ao_elem(ctx->cfg);
     const void *depth_dev[MEAO_MAX_BATCH];
     void *out_dev[MEAO_MAX_BATCH];
     if (depth_loc == MEAO_MEM_HOST) {

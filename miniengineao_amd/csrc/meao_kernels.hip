@@ -32,6 +32,7 @@ namespace {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
 typedef uint16_t ushort4v __attribute__((ext_vector_type(4)));
 typedef uint16_t ushort2v __attribute__((ext_vector_type(2)));
 typedef uint8_t uchar4v __attribute__((ext_vector_type(4)));
@@ -91,6 +92,20 @@ __device__ __forceinline__ float unorm8_to_f32(uint32_t n)
     const float r = 1.0f / 255.0f;       // folded at compile time
     const float q = fn * r;
     const float e = mad(-255.0f, q, fn);
+    return mad(e, r, q);
+}
+
+// N-bit UNORM -> f32 == (float)n / (2^N - 1) exactly, same construction as unorm8_to_f32
+// (tests/test_abi.py checks the sequence against IEEE division for all 2^16 and 2^24 codes on
+// the CPU; fmaf is the same operation on both sides).
+template <int N>
+__device__ __forceinline__ float unorm_to_f32(uint32_t n)
+{
+    constexpr float D = static_cast<float>((1u << N) - 1u);
+    const float fn = static_cast<float>(n);
+    const float r = 1.0f / D;
+    const float q = fn * r;
+    const float e = mad(-D, q, fn);
     return mad(e, r, q);
 }
 
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleAr
 {
     const int frame = blockIdx.z;
     const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
-    const float *__restrict__ depth = a.depth[frame];
+    const void *__restrict__ depth = a.depth[frame];
     uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
     float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
     float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
@@ -214,20 +229,52 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleAr
     const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
     if (x0 >= W) return;
 
+    // The depth-copy blit of the reference (Blit.shader pass 0) is folded into this load: the
+    // texel format is decoded here (wave-uniform switch), 4 texels per lane per row.
     float v[kDsTileH / kDsRowsPerPass][4];
 #pragma unroll
     for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
         const int y = yb + k * kDsRowsPerPass;
         v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.5f;
         if (y < H) {
-            const float *row = depth + static_cast<size_t>(y) * W + x0;
-            if constexpr (VEC) {
-                const float4v q = *reinterpret_cast<const float4v *>(row);
-                v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
-            } else {
+            const size_t at = static_cast<size_t>(y) * W + x0;
+            if (a.depth_format == MEAO_DEPTH_F32) {
+                const float *row = static_cast<const float *>(depth) + at;
+                if constexpr (VEC) {
+                    const float4v q = *reinterpret_cast<const float4v *>(row);
+                    v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (x0 + e < W) v[k][e] = row[e];
+                }
+            } else if (a.depth_format == MEAO_DEPTH_UNORM24) {
+                const uint32_t *row = static_cast<const uint32_t *>(depth) + at;
+                uint32_t u[4] = {0, 0, 0, 0};
+                if constexpr (VEC) {
+                    const uint4v q = *reinterpret_cast<const uint4v *>(row);
+                    u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (x0 + e < W) u[e] = row[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] = unorm_to_f32<24>(u[e] & 0xffffffu);
+            } else {   // 16-bit texels: UNORM16 or F16
+                const uint16_t *row = static_cast<const uint16_t *>(depth) + at;
+                uint16_t u[4] = {0, 0, 0, 0};
+                if constexpr (VEC) {
+                    const ushort4v q = *reinterpret_cast<const ushort4v *>(row);
+                    u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (x0 + e < W) u[e] = row[e];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (x0 + e < W) v[k][e] = row[e];
+                    v[k][e] = a.depth_format == MEAO_DEPTH_UNORM16 ? unorm_to_f32<16>(u[e]) : f16_bits_to_f32(u[e]);
             }
         }
     }

@@ -11,7 +11,8 @@ namespace meao {
 // ---------------------------------------------------------------------------------------
 // Downsample (Downsample1.main + Downsample2.main fused; no LDS, pure streaming)
 struct DownsampleArgs {
-    const float *depth[MEAO_MAX_BATCH];  // caller-owned raw depth, one pointer per frame
+    const void *depth[MEAO_MAX_BATCH];   // caller-owned raw depth (depth_format), one pointer per frame
+    int32_t depth_format;                // meao_depth_format
     uint16_t *linear;                    // LinearDepth f16 L0, frame 0
     float *low[4];                       // LowDepth1..4 f32, frame 0
     uint64_t frame_stride;               // bytes between consecutive frames' intermediates

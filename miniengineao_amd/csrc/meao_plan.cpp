@@ -173,7 +173,12 @@ bool describe_buffer(int width, int height, int ao_format, int debug_id, meao_de
     return true;
 }
 
-void algorithmic_bytes(int width, int height, int num_levels, int ao_format,
+uint64_t depth_elem(int depth_format)
+{
+    return (depth_format == MEAO_DEPTH_F32 || depth_format == MEAO_DEPTH_UNORM24) ? 4 : 2;
+}
+
+void algorithmic_bytes(int width, int height, int num_levels, int ao_format, int depth_format,
                        uint64_t bytes[MEAO_NUM_PASSES])
 {
     uint64_t p[kNumMips];
@@ -185,7 +190,7 @@ void algorithmic_bytes(int width, int height, int num_levels, int ao_format,
     std::memset(bytes, 0, sizeof(uint64_t) * MEAO_NUM_PASSES);
     // Downsample1: read f32 L0, write f16 L0, (f32 + f16) L1, (f32 + f16) L2
     // Downsample2: read the used quarter of L2, write (f32 + f16) L3 and L4
-    bytes[MEAO_PASS_DOWNSAMPLE] = 4 * p[0] + 2 * p[0] + 6 * p[1] + 6 * p[2] + 4 * p[3] + 6 * p[3] + 6 * p[4];
+    bytes[MEAO_PASS_DOWNSAMPLE] = depth_elem(depth_format) * p[0] + 2 * p[0] + 6 * p[1] + 6 * p[2] + 4 * p[3] + 6 * p[3] + 6 * p[4];
     for (int l = 1; l <= num_levels; ++l)  // 16 f16 slices of mip l+2 in, AO of mip l out
         bytes[MEAO_PASS_RENDER] += 2 * 16 * p[l + 2] + a * p[l];
     for (int hi = num_levels - 1; hi >= 1; --hi)  // lo (f32 + AO), hi (f32 + AO), out AO

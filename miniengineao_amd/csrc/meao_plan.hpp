@@ -50,7 +50,8 @@ bool params_valid(const meao_params &p);
 void build_plan(int width, int height, int num_levels, const meao_params &p, Plan *out);
 
 bool describe_buffer(int width, int height, int ao_format, int debug_id, meao_desc *out);
-void algorithmic_bytes(int width, int height, int num_levels, int ao_format,
+uint64_t depth_elem(int depth_format);   // bytes per input depth texel
+void algorithmic_bytes(int width, int height, int num_levels, int ao_format, int depth_format,
                        uint64_t bytes[MEAO_NUM_PASSES]);
 
 }  // namespace meao

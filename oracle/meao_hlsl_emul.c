@@ -346,9 +346,9 @@ static void dispatch_upsample(const tex_t *lo_db, const tex_t *hi_db, const tex_
 /* ------------------------------------------------------------------------ */
 /* command-buffer order of AO.cs:496-531                                     */
 
-int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const float *depth, meao_oracle_buffers *out)
+int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const void *depth_in, meao_oracle_buffers *out)
 {
-    if (!d || !depth || !out) return -1;
+    if (!d || !depth_in || !out) return -1;
     if (d->width < 1 || d->height < 1 || d->num_levels < 1 || d->num_levels > 4) return -1;
     int w[7], h[7];
     for (int k = 0; k < 7; k++) meao_oracle_level_dims(d->width, d->height, k, &w[k], &h[k]);
@@ -359,6 +359,10 @@ int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const float *depth, meao_o
         (t).f16_rounding = d->f16_rounding; (t).data = (void *)(ptr); \
         if (!(t).data) { (t).data = calloc((size_t)(W) * (H) * (S), tex_elem(F)); \
                          owned[nowned++] = (t).data; fail |= !(t).data; } } while (0)
+    /* DepthCopy (AO.cs:608-614, Blit.shader pass 0): the depth texture sampled into an RFloat target */
+    float *depth = (float *)malloc((size_t)w[0] * h[0] * sizeof(float));
+    if (!depth) return -3;
+    for (size_t i = 0; i < (size_t)w[0] * h[0]; i++) depth[i] = meao_oracle_decode_depth(depth_in, i, d->depth_format);
     tex_t depth_tex = { w[0], h[0], 1, FMT_F32, 0, (void *)depth };
     tex_t linear, low[4], tiled[4], occ[4], comb[3], result;
     MK(linear, out->linear_depth, w[0], h[0], 1, FMT_F16);
@@ -370,7 +374,7 @@ int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const float *depth, meao_o
     }
     MK(result, out->result, w[0], h[0], 1, aofmt);
 #undef MK
-    if (fail) { for (int i = 0; i < nowned; i++) free(owned[i]); return -3; }
+    if (fail) { for (int i = 0; i < nowned; i++) free(owned[i]); free(depth); return -3; }
 
     ds1_res r1; r1.depth = &depth_tex; r1.linear_z = &linear; r1.reversed = d->reversed_z;
     meao_oracle_zbuffer_params(d, r1.zp);
@@ -396,5 +400,6 @@ int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const float *depth, meao_o
         lo_ao = dst;
     }
     for (int i = 0; i < nowned; i++) free(owned[i]);
+    free(depth);
     return 0;
 }

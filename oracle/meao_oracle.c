@@ -102,6 +102,17 @@ uint8_t meao_oracle_f32_to_unorm8(float x)
 
 float meao_oracle_unorm8_to_f32(uint8_t v) { return (float)v / 255.0f; }
 
+/* The depth-copy blit (Blit.shader pass 0): what sampling the depth texture returns as float. */
+float meao_oracle_decode_depth(const void *depth, uint64_t index, int32_t depth_format)
+{
+    switch (depth_format) {
+    case MEAO_ORACLE_DEPTH_UNORM16: return (float)((const uint16_t *)depth)[index] / 65535.0f;
+    case MEAO_ORACLE_DEPTH_UNORM24: return (float)(((const uint32_t *)depth)[index] & 0xffffffu) / 16777215.0f;
+    case MEAO_ORACLE_DEPTH_F16:     return meao_oracle_f16_to_f32(((const uint16_t *)depth)[index]);
+    default:                        return ((const float *)depth)[index];
+    }
+}
+
 /* AO buffer access in either storage mode */
 static inline float ao_load(const void *buf, size_t idx, int fmt)
 {
@@ -236,7 +247,7 @@ static void par_rows(int nthreads, int rows, row_fn fn, void *arg)
 /* pass 1+2: linearize, point-downsample, de-interleave  (DS1, DS2)          */
 
 typedef struct {
-    const meao_oracle_desc *d; const float *depth; float zp[4];
+    const meao_oracle_desc *d; const void *depth; float zp[4];
     int w[7], h[7];
     uint16_t *linear; float *low[4]; uint16_t *tiled[4];
 } ds_ctx;
@@ -244,7 +255,8 @@ typedef struct {
 /* DS1:37-48.  Out-of-range texture loads return 0 (DS1:39). */
 static inline float linearize(const ds_ctx *c, int x, int y)
 {
-    float dep = (x < c->w[0] && y < c->h[0]) ? c->depth[(size_t)y * c->w[0] + x] : 0.0f;
+    float dep = (x < c->w[0] && y < c->h[0])
+                    ? meao_oracle_decode_depth(c->depth, (uint64_t)y * c->w[0] + x, c->d->depth_format) : 0.0f;
     float dist = 1.0f / mad(c->zp[0], dep, c->zp[1]);
     if (c->d->reversed_z ? (dep == 0.0f) : (dep == 1.0f)) dist = 1e5f;
     return dist;
@@ -535,10 +547,11 @@ static int upsample_pass(const meao_oracle_desc *d, int low_level, int nthreads,
 /* ------------------------------------------------------------------------ */
 /* whole pipeline in the order of RebuildCommandBuffers (AO.cs:496-531)      */
 
-int32_t meao_oracle_run(const meao_oracle_desc *d, const float *depth,
+int32_t meao_oracle_run(const meao_oracle_desc *d, const void *depth,
                         meao_oracle_buffers *out, int32_t nthreads)
 {
     if (!d || !depth || !out) return -1;
+    if (d->depth_format < MEAO_ORACLE_DEPTH_F32 || d->depth_format > MEAO_ORACLE_DEPTH_F16) return -1;
     if (d->width < 1 || d->height < 1 || d->num_levels < 1 || d->num_levels > 4) return -1;
     if (d->ao_format != MEAO_ORACLE_AO_R8 && d->ao_format != MEAO_ORACLE_AO_F16) return -1;
 

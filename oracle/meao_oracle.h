@@ -10,7 +10,7 @@
  * and no tests, and Unity / a D3D GPU / fxc are not available, so parity
  * against outputs of the reference *running on its own platform* is unpinned.
  * What pins the oracle instead:
- *  (1) the reference's own shader source text (Shaders/*.compute under
+ *  (1) the reference's own shader source text (the four .compute files under
  *      /root/reference) is executed by oracle/hlsl_interp.py, driven like
  *      AmbientOcclusion.cs drives Unity; all 17 buffers are committed as
  *      fixtures (tests/golden/ref_*.npz, generator committed) and both
@@ -57,7 +57,15 @@ typedef struct meao_oracle_desc {
     float intensity;              /* AO.cs:52  default  1    */
     float near_clip, far_clip;    /* AO.cs:563 */
     float proj00;                 /* camera.projectionMatrix[0,0] (AO.cs:572) */
+    int32_t depth_format;         /* storage of the input depth, see below     */
 } meao_oracle_desc;
+
+/* Input depth storage.  The reference blits _CameraDepthTexture into an RFloat copy first
+ * (Blit.shader:48-64 pass 0, AO.cs:608-614): UNORM texels sample as v / (2^n - 1), correctly
+ * rounded; UNORM24 is the low 24 bits of a 32-bit word (D24S8/D24X8). */
+enum { MEAO_ORACLE_DEPTH_F32 = 0, MEAO_ORACLE_DEPTH_UNORM16 = 1, MEAO_ORACLE_DEPTH_UNORM24 = 2,
+       MEAO_ORACLE_DEPTH_F16 = 3 };
+float meao_oracle_decode_depth(const void *depth, uint64_t index, int32_t depth_format);
 
 /* The 17 debug-visible buffers (AO.cs:789-808) + nothing else.  Any pointer
  * may be NULL: the oracle then uses a private scratch buffer for it.
@@ -108,11 +116,11 @@ float    meao_oracle_unorm8_to_f32(uint8_t v);
 
 /* Full pipeline, gather form.  nthreads <= 1 -> scalar single core.
  * Returns 0 on success, negative on bad arguments / allocation failure. */
-int32_t meao_oracle_run(const meao_oracle_desc *d, const float *depth,
+int32_t meao_oracle_run(const meao_oracle_desc *d, const void *depth,
                         meao_oracle_buffers *out, int32_t nthreads);
 
 /* Same contract, literal HLSL thread-group emulation (meao_hlsl_emul.c). */
-int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const float *depth,
+int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const void *depth,
                            meao_oracle_buffers *out);
 
 #ifdef __cplusplus

@@ -18,6 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmeao_oracle.so")
 
 AO_R8, AO_F16 = 0, 1
+DEPTH_F32, DEPTH_UNORM16, DEPTH_UNORM24, DEPTH_F16 = 0, 1, 2, 3
+DEPTH_DTYPE = {0: np.float32, 1: np.uint16, 2: np.uint32, 3: np.uint16}
 F16_RTZ, F16_RTNE = 0, 1
 
 # debug ids of AmbientOcclusion.cs:789-808
@@ -36,7 +38,7 @@ class Desc(C.Structure):
         ("noise_filter_tolerance", C.c_float), ("blur_tolerance", C.c_float),
         ("upsample_tolerance", C.c_float), ("thickness_modifier", C.c_float),
         ("intensity", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
-        ("proj00", C.c_float),
+        ("proj00", C.c_float), ("depth_format", C.c_int32),
     ]
 
 
@@ -119,12 +121,13 @@ class Settings:
     near_clip: float = 0.1
     far_clip: float = 100.0
     proj00: float = 1.0
+    depth_format: int = DEPTH_F32
 
     def desc(self) -> Desc:
         return Desc(self.width, self.height, self.num_levels, self.ao_format, self.f16_rounding,
                     1 if self.reversed_z else 0, self.noise_filter_tolerance, self.blur_tolerance,
                     self.upsample_tolerance, self.thickness_modifier, self.intensity,
-                    self.near_clip, self.far_clip, self.proj00)
+                    self.near_clip, self.far_clip, self.proj00, self.depth_format)
 
 
 def level_dims(width: int, height: int, level: int):
@@ -163,7 +166,7 @@ def _buffers(arrs) -> Buffers:
 def run(depth: np.ndarray, s: Settings, nthreads: int = 1, emulate_hlsl: bool = False,
         result_only: bool = False):
     """Run the oracle; returns dict name -> array (all 17 buffers, or just 'result')."""
-    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    depth = np.ascontiguousarray(depth, dtype=DEPTH_DTYPE[s.depth_format])
     assert depth.shape == (s.height, s.width), (depth.shape, s.height, s.width)
     d = s.desc()
     if result_only:
@@ -208,6 +211,19 @@ def sample_thickness():
     out = (C.c_float * 12)()
     lib().meao_oracle_sample_thickness(C.byref(out))
     return np.array(list(out), dtype=np.float32)
+
+
+def encode_depth(raw: np.ndarray, depth_format: int) -> np.ndarray:
+    """Quantise float raw depth in [0,1] into a depth-buffer storage format (test inputs)."""
+    raw = np.asarray(raw, dtype=np.float64)
+    if depth_format == DEPTH_UNORM16:
+        return np.rint(raw * 65535.0).astype(np.uint16)
+    if depth_format == DEPTH_UNORM24:     # D24S8: stencil garbage in the high byte must be ignored
+        code = np.rint(raw * 16777215.0).astype(np.uint32)
+        return code | (np.uint32(0xA5) << np.uint32(24))
+    if depth_format == DEPTH_F16:
+        return raw.astype(np.float16).view(np.uint16)
+    return raw.astype(np.float32)
 
 
 def f16_bits_to_f32(bits: np.ndarray) -> np.ndarray:
