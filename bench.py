@@ -191,7 +191,8 @@ def main() -> int:
     kernel_ms = float(sum(pass_ms))
     whole_gbps = sum(alg) * B / (kernel_ms * 1e-3) / 1e9
     ren_ups_gbps = sum(alg[1:]) * B / (sum(pass_ms[1:]) * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": _lib.PASS_NAMES[dominant], "achieved": round(dom_gbps, 1),
+    roofline = {"bound": "hbm", "limiter": "valu" if dominant != 0 else "hbm",
+                "kernel": _lib.PASS_NAMES[dominant], "achieved": round(dom_gbps, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "launch_ms": round(pass_ms[dominant], 5), "event_samples": samples,
                 "whole_frame": {"GBps": round(whole_gbps, 1), "frac": round(whole_gbps / HBM_PEAK_GBPS, 4)},
