@@ -101,6 +101,9 @@ def main() -> int:
     ap.add_argument("--in-flight", type=int, default=1,
                     help="batches in flight: N contexts on N HIP streams, step k on stream k mod N "
                          "(lets the HBM-bound downsample of one batch overlap the VALU-bound passes of another)")
+    ap.add_argument("--composite", action="store_true",
+                    help="also time the next-tier composite kernel (AO x RGBA16F frame, Blit.shader pass 2); "
+                         "reported separately, never part of `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
@@ -205,6 +208,26 @@ def main() -> int:
         cpu = cpu_baseline(w, h, cam, intensity, ao_format, frames[0])
 
     # single-frame latency (one frame per launch sequence), for context
+    composite = None
+    if args.composite:
+        # next-tier consumer of the AO texture: color.rgba *= ao, 17 bytes per texel, HBM-bound
+        colors = [torch.ones((h, w, 4), dtype=torch.float16, device=dev) for _ in range(B)]
+        reps = 10
+        for f in range(B):
+            ao.composite_device(_lib.COMPOSITE_MULTIPLY, optr[f], colors[f].data_ptr(), 0, stream)
+        fence()
+        tc = time.perf_counter()
+        for _ in range(reps):
+            for f in range(B):
+                ao.composite_device(_lib.COMPOSITE_MULTIPLY, optr[f], colors[f].data_ptr(), 0, stream)
+        torch.cuda.synchronize(dev)
+        per_frame_ms = (time.perf_counter() - tc) * 1e3 / (reps * B)    # back-to-back launches, device-synchronised wall time
+        cbytes = w * h * (16 + (1 if ao_format == _lib.AO_R8 else 2))
+        cg = cbytes / (per_frame_ms * 1e-3) / 1e9
+        composite = {"kernel": "composite_multiply", "ms_per_frame": round(per_frame_ms, 5),
+                     "algorithmic_MB_per_frame": round(cbytes / 1e6, 2), "GBps": round(cg, 1),
+                     "frac": round(cg / HBM_PEAK_GBPS, 4), "bound": "hbm"}
+
     latency_ms = None
     if not args.skip_latency:
         fence()
@@ -226,7 +249,7 @@ def main() -> int:
                        "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
                        "numerics": "strict (bit-exact vs CPU oracle)", "sharding": f"frames x{world}",
                        "batches_in_flight": nfl},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "sum_kernel_ms_per_step": round(kernel_ms, 4),
         }

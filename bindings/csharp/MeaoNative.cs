@@ -23,6 +23,7 @@ namespace MiniEngineAO.Native
     public enum MeaoNumerics { Strict = 0 }
     public enum MeaoMem { Host = 0, Device = 1 }
     public enum MeaoDepthFormat { F32 = 0, Unorm16 = 1, Unorm24 = 2, F16 = 3 }
+    public enum MeaoCompositeMode { Multiply = 0, AmbientOnly = 1, Debug = 2 }
     public enum MeaoFormat { F32 = 0, F16 = 1, Unorm8 = 2 }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -122,5 +123,6 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_set_profiling(IntPtr ctx, int enable);
         [DllImport(Lib)] public static extern int meao_get_pass_times(IntPtr ctx, [Out] float[] ms6, out int samples);
         [DllImport(Lib)] public static extern int meao_selftest(IntPtr ctx, int which, out ulong mismatches);
+        [DllImport(Lib)] public static extern int meao_composite(IntPtr ctx, int mode, IntPtr ao, IntPtr color_rgba16f, IntPtr gbuffer0_rgba8, int loc, IntPtr stream);
     }
 }

@@ -199,6 +199,24 @@ MEAO_API int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t deb
                                        void *dst, uint64_t dst_capacity, int32_t dst_loc,
                                        meao_desc *out_desc);
 
+/* ---- composite: the consumer of the AO texture (PushCompositeCommands AO.cs:822-839) ----
+ * The reference composites with raster blits (Blit.shader passes 1-3) into the HDR camera target
+ * (ARGBHalf) and, in deferred ambient-only mode, GBuffer0 (ARGB32).  Canonical reading of the
+ * fixed-function blend: operands widened to f32, one f32 multiply, result rounded to the target
+ * format (f16: round-to-nearest-even, the output-merger rule; UNORM8: as the AO stores).
+ *   MULTIPLY      pass 2, "Blend Zero SrcAlpha":            color.rgba *= ao
+ *   AMBIENT_ONLY  pass 1, "Blend Zero OneMinusSrcColor, Zero OneMinusSrcAlpha", occ = 1 - ao:
+ *                 color.rgb *= (1 - occ), color.a unchanged; gbuffer0.a *= (1 - occ), rgb unchanged
+ *   DEBUG         pass 3, no blend:                         color.rgba = ao
+ * ao: width*height texels in cfg.ao_format; color: width*height RGBA16F (8 bytes per texel),
+ * updated in place; gbuffer0: width*height RGBA8, only for AMBIENT_ONLY (else NULL).
+ * All pointers share one location `loc`. */
+typedef enum meao_composite_mode {
+    MEAO_COMPOSITE_MULTIPLY = 0, MEAO_COMPOSITE_AMBIENT_ONLY = 1, MEAO_COMPOSITE_DEBUG = 2
+} meao_composite_mode;
+MEAO_API int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, void *color_rgba16f,
+                                void *gbuffer0_rgba8, int32_t loc, meao_stream stream);
+
 /* Per-pass device timing: when enabled, meao_execute* brackets every pass with HIP events on
  * the launch stream; meao_get_pass_times averages them over the executes since the last reset
  * (synchronises the stream).  ms[MEAO_NUM_PASSES]; passes not run report 0. */

@@ -35,6 +35,7 @@ F16_RTZ_CLAMP, F16_RTNE = 0, 1
 NUMERICS_STRICT = 0
 MEM_HOST, MEM_DEVICE = 0, 1
 DEPTH_F32, DEPTH_UNORM16, DEPTH_UNORM24, DEPTH_F16 = 0, 1, 2, 3
+COMPOSITE_MULTIPLY, COMPOSITE_AMBIENT_ONLY, COMPOSITE_DEBUG = 0, 1, 2
 FMT_F32, FMT_F16, FMT_UNORM8 = 0, 1, 2
 
 
@@ -98,6 +99,7 @@ SIGNATURES = {
     "meao_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
     "meao_get_pass_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float * NUM_PASSES), C.POINTER(C.c_int32)]),
     "meao_selftest": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+    "meao_composite": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 _lib = None

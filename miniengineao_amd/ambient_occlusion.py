@@ -140,6 +140,28 @@ class AmbientOcclusion:
     def synchronize(self, stream: int = 0) -> None:
         L.check(self._lib.meao_synchronize(self._ctx, C.c_void_p(stream) if stream else None), self._ctx)
 
+    # ---- composite (PushCompositeCommands, AO.cs:822-839) ------------------------------
+    def composite(self, ao: np.ndarray, color_rgba16f: np.ndarray, gbuffer0_rgba8: Optional[np.ndarray] = None,
+                  debug: bool = False) -> None:
+        """Host arrays, in place.  Mode follows the reference: debug view if ``debug`` (AO.cs:826),
+        ambient-only into GBuffer0 + the HDR target if ``ambientOnly`` and a GBuffer0 is given
+        (AO.cs:830-834), else the standard multiply (AO.cs:837)."""
+        assert color_rgba16f.dtype == np.uint16 and color_rgba16f.shape == (self.height, self.width, 4)
+        assert ao.dtype == self.ao_dtype and ao.shape == (self.height, self.width)
+        if debug:
+            mode, g = L.COMPOSITE_DEBUG, None
+        elif self._ambient_only and gbuffer0_rgba8 is not None:
+            assert gbuffer0_rgba8.dtype == np.uint8 and gbuffer0_rgba8.shape == (self.height, self.width, 4)
+            mode, g = L.COMPOSITE_AMBIENT_ONLY, gbuffer0_rgba8.ctypes.data
+        else:
+            mode, g = L.COMPOSITE_MULTIPLY, None
+        L.check(self._lib.meao_composite(self._ctx, mode, ao.ctypes.data, color_rgba16f.ctypes.data, g,
+                                         L.MEM_HOST, None), self._ctx)
+
+    def composite_device(self, mode: int, ao_ptr: int, color_ptr: int, gbuffer0_ptr: int = 0, stream: int = 0) -> None:
+        L.check(self._lib.meao_composite(self._ctx, mode, ao_ptr, color_ptr, gbuffer0_ptr or None, L.MEM_DEVICE,
+                                         C.c_void_p(stream) if stream else None), self._ctx)
+
     # ---- observability (the _debug views, AO.cs:787-820) -------------------------------
     def debug_buffer(self, debug_id: int, frame: int = 0) -> np.ndarray:
         d = L.Desc()

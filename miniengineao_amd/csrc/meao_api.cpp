@@ -647,6 +647,44 @@ int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *o
     return MEAO_OK;
 }
 
+int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, void *color_rgba16f, void *gbuffer0_rgba8,
+                       int32_t loc, meao_stream stream_)
+{
+    if (!ctx || !ao || !color_rgba16f) return MEAO_ERR_INVALID_ARGUMENT;
+    if (mode < MEAO_COMPOSITE_MULTIPLY || mode > MEAO_COMPOSITE_DEBUG) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_composite: unknown mode");
+    if (mode == MEAO_COMPOSITE_AMBIENT_ONLY && !gbuffer0_rgba8)
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_composite: AMBIENT_ONLY needs the GBuffer0 target");
+    if (loc != MEAO_MEM_HOST && loc != MEAO_MEM_DEVICE) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_composite: bad memory location");
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->own_stream;
+    const uint64_t px = static_cast<uint64_t>(ctx->cfg.width) * ctx->cfg.height;
+    const uint64_t ao_bytes = px * ao_elem(ctx->cfg), color_bytes = px * 8, g_bytes = px * 4;
+    CompositeArgs ca{};
+    ca.pixels = static_cast<int64_t>(px);
+    ca.mode = mode;
+    char *scratch = nullptr;
+    if (loc == MEAO_MEM_HOST) {     // tools / tests: stage through one temporary device buffer
+        MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&scratch), align_up(ao_bytes) + align_up(color_bytes) + g_bytes));
+        char *d_ao = scratch, *d_color = scratch + align_up(ao_bytes), *d_g = d_color + align_up(color_bytes);
+        hipError_t e = hipMemcpyAsync(d_ao, ao, ao_bytes, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_color, color_rgba16f, color_bytes, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && gbuffer0_rgba8) e = hipMemcpyAsync(d_g, gbuffer0_rgba8, g_bytes, hipMemcpyHostToDevice, stream);
+        ca.ao = d_ao; ca.color = d_color; ca.gbuffer0 = gbuffer0_rgba8 ? d_g : nullptr;
+        if (e == hipSuccess) e = launch_composite(ca, ctx->cfg.ao_format, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(color_rgba16f, d_color, color_bytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess && gbuffer0_rgba8) e = hipMemcpyAsync(gbuffer0_rgba8, d_g, g_bytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(scratch);
+        if (e != hipSuccess) return fail_hip(ctx, e, "meao_composite (host staging)");
+        return MEAO_OK;
+    }
+    ca.ao = ao; ca.color = color_rgba16f; ca.gbuffer0 = gbuffer0_rgba8;
+    MEAO_HIP(ctx, launch_composite(ca, ctx->cfg.ao_format, stream));
+    ctx->last_stream = stream;
+    return MEAO_OK;
+}
+
 int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches)
 {
     if (!ctx || !out_mismatches || which < 0 || which > 6) return MEAO_ERR_INVALID_ARGUMENT;

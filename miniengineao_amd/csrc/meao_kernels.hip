@@ -25,6 +25,7 @@
 //    of the hi-res depth and 4-byte stores of four AO texels.
 #include "meao_kernels.hpp"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace meao {
@@ -765,6 +766,73 @@ __global__ __launch_bounds__(kThreads) void selftest_f16_decode_kernel(unsigned 
     if (got != ref && !both_nan) atomicAdd(count, 1ull);
 }
 
+// ------------------------------------------------------------------------------------------
+// Composite (Blit.shader:66-134): pure streaming, 17 bytes per texel (RGBA16F read + write, AO).
+// One lane = 4 texels = two 16-byte colour loads/stores + one 4-byte (R8) AO load.
+
+__device__ __forceinline__ uint16_t f32_to_f16_rtne_bits(float x)
+{
+    return __builtin_bit_cast(uint16_t, static_cast<_Float16>(x));
+}
+
+template <int AOFMT>
+__global__ __launch_bounds__(kThreads) void composite_kernel(const CompositeArgs a)
+{
+    typedef AoTexel<AOFMT> AO;
+    typedef typename AO::type ao_t;
+    // one lane = 2 texels = one 16-byte colour load/store; consecutive lanes are contiguous
+    const int64_t pairs = (a.pixels + 1) / 2;
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; q < pairs;
+         q += static_cast<int64_t>(gridDim.x) * kThreads) {
+        const int64_t p0 = q * 2;
+        const bool full = p0 + 1 < a.pixels;
+        const ao_t *ap = static_cast<const ao_t *>(a.ao) + p0;
+        float aov[2] = {1.0f, 1.0f};
+        if (full) {
+            const typename AO::type2 a2 = *reinterpret_cast<const typename AO::type2 *>(ap);
+            aov[0] = AO::decode(a2.x); aov[1] = AO::decode(a2.y);
+        } else {
+            aov[0] = AO::decode(ap[0]);
+        }
+        uint16_t c[8] = {};
+        uint16_t *cp = static_cast<uint16_t *>(a.color) + p0 * 4;
+        if (full) {
+            const uint4v raw = *reinterpret_cast<const uint4v *>(cp);
+            c[0] = raw.x & 0xffffu; c[1] = raw.x >> 16; c[2] = raw.y & 0xffffu; c[3] = raw.y >> 16;
+            c[4] = raw.z & 0xffffu; c[5] = raw.z >> 16; c[6] = raw.w & 0xffffu; c[7] = raw.w >> 16;
+        } else {
+            for (int k = 0; k < 4; ++k) c[k] = cp[k];
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (p0 + e >= a.pixels) break;
+            const float ao = aov[e];
+            uint16_t *t = c + 4 * e;
+            if (a.mode == MEAO_COMPOSITE_DEBUG) {                        // pass 3: frag returns ao in every channel
+                t[0] = t[1] = t[2] = t[3] = f32_to_f16_rtne_bits(ao);
+            } else if (a.mode == MEAO_COMPOSITE_MULTIPLY) {              // pass 2: dst * src.a
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = f32_to_f16_rtne_bits(f16_bits_to_f32(t[k]) * ao);
+            } else {                                                     // pass 1: dst * (1 - src), src = 1 - ao
+                const float occ = 1.0f - ao;                             // Blit.shader:84
+                const float keep = 1.0f - occ;                           // OneMinusSrcColor / OneMinusSrcAlpha
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t[k] = f32_to_f16_rtne_bits(f16_bits_to_f32(t[k]) * keep);
+                uint8_t *g = static_cast<uint8_t *>(a.gbuffer0) + (p0 + e) * 4 + 3;   // GBuffer0.a = occlusion
+                *g = static_cast<uint8_t>(f32_to_unorm8(unorm8_to_f32(*g) * keep));
+            }
+        }
+        if (full) {
+            uint4v outv;
+            outv.x = c[0] | (static_cast<uint32_t>(c[1]) << 16); outv.y = c[2] | (static_cast<uint32_t>(c[3]) << 16);
+            outv.z = c[4] | (static_cast<uint32_t>(c[5]) << 16); outv.w = c[6] | (static_cast<uint32_t>(c[7]) << 16);
+            *reinterpret_cast<uint4v *>(cp) = outv;
+        } else {
+            for (int k = 0; k < 4; ++k) cp[k] = c[k];
+        }
+    }
+}
+
 // which = 4: rcp_strict, 5: div_const<3>, div_const<9>, 6: div_strict on hashed operand pairs
 __device__ __forceinline__ bool in_exact_range(float x, float lo, float hi)
 {
@@ -864,6 +932,15 @@ hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s)
     const int blocks = (n + kThreads - 1) / kThreads;
     if (a.f16_rtne) tile_atlas_kernel<true><<<dim3(blocks < 4096 ? blocks : 4096), dim3(kThreads), 0, s>>>(a);
     else tile_atlas_kernel<false><<<dim3(blocks < 4096 ? blocks : 4096), dim3(kThreads), 0, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_composite(const CompositeArgs &a, int ao_format, hipStream_t s)
+{
+    const int64_t pairs = (a.pixels + 1) / 2;
+    const int blocks = static_cast<int>(std::min<int64_t>((pairs + kThreads - 1) / kThreads, 256 * 32));
+    if (ao_format == MEAO_AO_R8) composite_kernel<MEAO_AO_R8><<<dim3(blocks), dim3(kThreads), 0, s>>>(a);
+    else composite_kernel<MEAO_AO_F16><<<dim3(blocks), dim3(kThreads), 0, s>>>(a);
     return hipGetLastError();
 }
 

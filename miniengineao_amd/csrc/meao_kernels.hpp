@@ -84,6 +84,15 @@ hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStre
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
 hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s);
+// Composite (Blit.shader passes 1-3): ao in ao_format, color RGBA16F in place, gbuffer0 RGBA8 or null.
+struct CompositeArgs {
+    const void *ao;
+    void *color;
+    void *gbuffer0;
+    int64_t pixels;
+    int32_t mode;
+};
+hipError_t launch_composite(const CompositeArgs &a, int ao_format, hipStream_t s);
 // Exhaustive conversion self-tests; *count (device) receives the number of mismatches.
 hipError_t launch_selftest(int which, unsigned long long *count, hipStream_t s);
 

@@ -545,6 +545,34 @@ static int upsample_pass(const meao_oracle_desc *d, int low_level, int nthreads,
 }
 
 /* ------------------------------------------------------------------------ */
+/* composite: the raster blits that consume the AO texture (Blit.shader:66-134) */
+
+int32_t meao_oracle_composite(int32_t width, int32_t height, int32_t ao_format, int32_t mode,
+                              const void *ao, uint16_t *color, uint8_t *gbuffer0)
+{
+    if (!ao || !color || mode < 0 || mode > 2 || (mode == 1 && !gbuffer0)) return -1;
+    size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; i++) {
+        float a = ao_load(ao, i, ao_format);               /* tex2D(_AOTexture, uv).r, point sampled */
+        uint16_t *c = color + 4 * i;
+        if (mode == 2) {                                   /* pass 3: return ao in every channel */
+            for (int k = 0; k < 4; k++) c[k] = meao_oracle_f32_to_f16(a, MEAO_ORACLE_F16_RTNE);
+        } else if (mode == 0) {                            /* pass 2: Blend Zero SrcAlpha */
+            for (int k = 0; k < 4; k++)
+                c[k] = meao_oracle_f32_to_f16(meao_oracle_f16_to_f32(c[k]) * a, MEAO_ORACLE_F16_RTNE);
+        } else {                                           /* pass 1: Blend Zero OneMinusSrc{Color,Alpha} */
+            float occ = 1.0f - a;                          /* Blit.shader:84 */
+            float keep = 1.0f - occ;
+            for (int k = 0; k < 3; k++)                    /* gbuffer3 = (occ, occ, occ, 0) */
+                c[k] = meao_oracle_f32_to_f16(meao_oracle_f16_to_f32(c[k]) * keep, MEAO_ORACLE_F16_RTNE);
+            uint8_t *g = gbuffer0 + 4 * i + 3;             /* gbuffer0 = (0, 0, 0, occ) */
+            *g = meao_oracle_f32_to_unorm8(meao_oracle_unorm8_to_f32(*g) * keep);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* whole pipeline in the order of RebuildCommandBuffers (AO.cs:496-531)      */
 
 int32_t meao_oracle_run(const meao_oracle_desc *d, const void *depth,

@@ -119,6 +119,13 @@ float    meao_oracle_unorm8_to_f32(uint8_t v);
 int32_t meao_oracle_run(const meao_oracle_desc *d, const void *depth,
                         meao_oracle_buffers *out, int32_t nthreads);
 
+/* Composite (Blit.shader passes 1-3, AO.cs:822-839): canonical reading of the fixed-function
+ * blend = operands widened to f32, one multiply, result rounded to the target format (f16 RTNE,
+ * UNORM8 as the AO stores).  mode 0 multiply, 1 ambient-only (gbuffer0 RGBA8 required), 2 debug.
+ * color: RGBA16F bit patterns, in place. */
+int32_t meao_oracle_composite(int32_t width, int32_t height, int32_t ao_format, int32_t mode,
+                              const void *ao, uint16_t *color_rgba16f, uint8_t *gbuffer0_rgba8);
+
 /* Same contract, literal HLSL thread-group emulation (meao_hlsl_emul.c). */
 int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const void *depth,
                            meao_oracle_buffers *out);

@@ -226,5 +226,18 @@ def encode_depth(raw: np.ndarray, depth_format: int) -> np.ndarray:
     return raw.astype(np.float32)
 
 
+def composite(ao: np.ndarray, color_rgba16f: np.ndarray, mode: int, ao_format: int = AO_R8,
+              gbuffer0_rgba8: np.ndarray = None):
+    """In place; mode 0 multiply, 1 ambient-only, 2 debug (Blit.shader passes 2, 1, 3)."""
+    h, w = ao.shape
+    L = lib()
+    L.meao_oracle_composite.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.meao_oracle_composite.restype = C.c_int32
+    rc = L.meao_oracle_composite(w, h, ao_format, mode, ao.ctypes.data, color_rgba16f.ctypes.data,
+                                 gbuffer0_rgba8.ctypes.data if gbuffer0_rgba8 is not None else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle composite failed: {rc}")
+
+
 def f16_bits_to_f32(bits: np.ndarray) -> np.ndarray:
     return np.asarray(bits, dtype=np.uint16).view(np.float16).astype(np.float32)

