@@ -123,6 +123,7 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_set_profiling(IntPtr ctx, int enable);
         [DllImport(Lib)] public static extern int meao_get_pass_times(IntPtr ctx, [Out] float[] ms6, out int samples);
         [DllImport(Lib)] public static extern int meao_selftest(IntPtr ctx, int which, out ulong mismatches);
+        [DllImport(Lib)] public static extern int meao_debug_view(IntPtr ctx, int frame, int debug_id, IntPtr dst, int out_loc, IntPtr stream);
         [DllImport(Lib)] public static extern int meao_composite(IntPtr ctx, int mode, IntPtr ao, IntPtr color_rgba16f, IntPtr gbuffer0_rgba8, int loc, IntPtr stream);
     }
 }

@@ -199,6 +199,15 @@ MEAO_API int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t deb
                                        void *dst, uint64_t dst_capacity, int32_t dst_loc,
                                        meao_desc *out_desc);
 
+/* The picture the reference's _debug = 1..17 mode shows (PushDebugBlitCommands AO.cs:787-820): the
+ * chosen buffer blitted into the full-resolution AO target -- point-sampled at the destination
+ * texel centres for the 2D buffers (cmd.Blit(rt, _result)), the 4x4 grid of slices for the tiled
+ * arrays (Blit.shader:136-155 pass 4), the result itself for 17.  Sampling positions are evaluated
+ * in exact integer arithmetic: source texel = floor((2x+1) * ws / (2W)); the store converts to
+ * cfg.ao_format like every AO store.  out: width*height AO texels. */
+MEAO_API int32_t meao_debug_view(meao_ctx *ctx, int32_t frame, int32_t debug_id, void *out,
+                                 int32_t out_loc, meao_stream stream);
+
 /* ---- composite: the consumer of the AO texture (PushCompositeCommands AO.cs:822-839) ----
  * The reference composites with raster blits (Blit.shader passes 1-3) into the HDR camera target
  * (ARGBHalf) and, in deferred ambient-only mode, GBuffer0 (ARGB32).  Canonical reading of the

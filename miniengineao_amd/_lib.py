@@ -99,6 +99,7 @@ SIGNATURES = {
     "meao_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
     "meao_get_pass_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float * NUM_PASSES), C.POINTER(C.c_int32)]),
     "meao_selftest": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+    "meao_debug_view": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "meao_composite": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 

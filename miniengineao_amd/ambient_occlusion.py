@@ -172,6 +172,12 @@ class AmbientOcclusion:
                                                 L.MEM_HOST, C.byref(d)), self._ctx)
         return out
 
+    def debug_view(self, debug_id: int, frame: int = 0) -> np.ndarray:
+        """What `_debug = debug_id` shows (AO.cs:787-820): the buffer blitted into the AO target."""
+        out = np.empty((self.height, self.width), self.ao_dtype)
+        L.check(self._lib.meao_debug_view(self._ctx, frame, debug_id, out.ctypes.data, L.MEM_HOST, None), self._ctx)
+        return out
+
     def set_profiling(self, enable: bool) -> None:
         L.check(self._lib.meao_set_profiling(self._ctx, 1 if enable else 0), self._ctx)
 

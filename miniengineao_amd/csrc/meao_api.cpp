@@ -37,7 +37,7 @@ struct meao_ctx {
     uint64_t off_linear = 0, off_low[4] = {}, off_occ[4] = {}, off_comb[3] = {};
 
     // lazily allocated: staging for HOST in/out, atlas scratch, selftest counter
-    char *stage_depth = nullptr, *stage_out = nullptr, *atlas_scratch = nullptr;
+    char *stage_depth = nullptr, *stage_out = nullptr, *stage_view = nullptr, *atlas_scratch = nullptr;
     uint64_t stage_depth_frame = 0, stage_out_frame = 0, atlas_scratch_bytes = 0;
     unsigned long long *counter = nullptr;
 
@@ -135,8 +135,9 @@ void release_buffers(meao_ctx *ctx)
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->stage_depth) (void)hipFree(ctx->stage_depth);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+    if (ctx->stage_view) (void)hipFree(ctx->stage_view);
     if (ctx->atlas_scratch) (void)hipFree(ctx->atlas_scratch);
-    ctx->arena = ctx->stage_depth = ctx->stage_out = ctx->atlas_scratch = nullptr;
+    ctx->arena = ctx->stage_depth = ctx->stage_out = ctx->stage_view = ctx->atlas_scratch = nullptr;
     ctx->atlas_scratch_bytes = 0;
     ctx->last_frames = 0;
 }
@@ -556,27 +557,14 @@ int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream)
     return MEAO_OK;
 }
 
-int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id, void *dst, uint64_t dst_capacity,
-                              int32_t dst_loc, meao_desc *out_desc)
+// Device address of debug buffer `debug_id` of batch slot `frame` (TiledDepth is built on demand).
+static int locate_debug_buffer(meao_ctx *ctx, int32_t frame, int32_t debug_id, const meao_desc &d, hipStream_t s,
+                               const void **out_src)
 {
-    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
-    meao_desc d{};
-    if (!describe_buffer(ctx->cfg.width, ctx->cfg.height, ctx->cfg.ao_format, debug_id, &d))
-        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: debug_id must be 1..17");
-    if (out_desc) *out_desc = d;
-    if (!dst) return MEAO_OK;
-    if (frame < 0 || frame >= ctx->last_frames)
-        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: frame not produced by the last execute");
-    if (dst_capacity < d.bytes) return fail(ctx, MEAO_ERR_BUFFER_TOO_SMALL, "meao_get_intermediate: dst_capacity < desc.bytes");
-    if (dst_loc != MEAO_MEM_HOST && dst_loc != MEAO_MEM_DEVICE) return MEAO_ERR_INVALID_ARGUMENT;
-    int rc = use_device(ctx);
-    if (rc != MEAO_OK) return rc;
-    hipStream_t s = ctx->last_stream;
     const char *slot = ctx->arena + ctx->slot_bytes * frame;
-    const void *src = nullptr;
     const int nl = ctx->cfg.num_levels;
-    if (debug_id == 1) src = slot + ctx->off_linear;
-    else if (debug_id <= 5) src = slot + ctx->off_low[debug_id - 2];
+    if (debug_id == 1) *out_src = slot + ctx->off_linear;
+    else if (debug_id <= 5) *out_src = slot + ctx->off_low[debug_id - 2];
     else if (debug_id <= 9) {
         // TiledDepth<level>: materialised on demand from LowDepth<level> (the hot path samples
         // LowDepth directly and never builds the de-interleaved arrays).
@@ -596,19 +584,75 @@ int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id, vo
         ta.pad_value = ctx->plan.render[level - 1].pad_value;
         ta.f16_rtne = ctx->cfg.f16_rounding == MEAO_F16_RTNE;
         MEAO_HIP(ctx, launch_tile_atlas(ta, s));
-        src = ctx->atlas_scratch;
+        *out_src = ctx->atlas_scratch;
     } else if (debug_id <= 13) {
-        if (debug_id - 9 > nl) return fail(ctx, MEAO_ERR_UNSUPPORTED, "meao_get_intermediate: level not rendered (num_levels)");
-        src = slot + ctx->off_occ[debug_id - 10];
+        if (debug_id - 9 > nl) return fail(ctx, MEAO_ERR_UNSUPPORTED, "debug buffer: level not rendered (num_levels)");
+        *out_src = slot + ctx->off_occ[debug_id - 10];
     } else if (debug_id <= 16) {
-        if (debug_id - 13 > nl - 1) return fail(ctx, MEAO_ERR_UNSUPPORTED, "meao_get_intermediate: level not combined (num_levels)");
-        src = slot + ctx->off_comb[debug_id - 14];
+        if (debug_id - 13 > nl - 1) return fail(ctx, MEAO_ERR_UNSUPPORTED, "debug buffer: level not combined (num_levels)");
+        *out_src = slot + ctx->off_comb[debug_id - 14];
     } else {
-        src = ctx->last_out[frame];
+        *out_src = ctx->last_out[frame];
     }
+    return MEAO_OK;
+}
+
+int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id, void *dst, uint64_t dst_capacity,
+                              int32_t dst_loc, meao_desc *out_desc)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    meao_desc d{};
+    if (!describe_buffer(ctx->cfg.width, ctx->cfg.height, ctx->cfg.ao_format, debug_id, &d))
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: debug_id must be 1..17");
+    if (out_desc) *out_desc = d;
+    if (!dst) return MEAO_OK;
+    if (frame < 0 || frame >= ctx->last_frames)
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: frame not produced by the last execute");
+    if (dst_capacity < d.bytes) return fail(ctx, MEAO_ERR_BUFFER_TOO_SMALL, "meao_get_intermediate: dst_capacity < desc.bytes");
+    if (dst_loc != MEAO_MEM_HOST && dst_loc != MEAO_MEM_DEVICE) return MEAO_ERR_INVALID_ARGUMENT;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    hipStream_t s = ctx->last_stream;
+    const void *src = nullptr;
+    rc = locate_debug_buffer(ctx, frame, debug_id, d, s, &src);
+    if (rc != MEAO_OK) return rc;
     MEAO_HIP(ctx, hipMemcpyAsync(dst, src, d.bytes,
                                  dst_loc == MEAO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
     MEAO_HIP(ctx, hipStreamSynchronize(s));
+    return MEAO_OK;
+}
+
+int32_t meao_debug_view(meao_ctx *ctx, int32_t frame, int32_t debug_id, void *out, int32_t out_loc, meao_stream stream_)
+{
+    if (!ctx || !out) return MEAO_ERR_INVALID_ARGUMENT;
+    meao_desc d{};
+    if (!describe_buffer(ctx->cfg.width, ctx->cfg.height, ctx->cfg.ao_format, debug_id, &d))
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_view: debug_id must be 1..17");
+    if (frame < 0 || frame >= ctx->last_frames)
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_view: frame not produced by the last execute");
+    if (out_loc != MEAO_MEM_HOST && out_loc != MEAO_MEM_DEVICE) return MEAO_ERR_INVALID_ARGUMENT;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    hipStream_t s = stream_ ? static_cast<hipStream_t>(stream_) : ctx->last_stream;
+    const void *src = nullptr;
+    rc = locate_debug_buffer(ctx, frame, debug_id, d, s, &src);
+    if (rc != MEAO_OK) return rc;
+    const uint64_t out_bytes = static_cast<uint64_t>(ctx->cfg.width) * ctx->cfg.height * ao_elem(ctx->cfg);
+    void *dev_out = out;
+    if (out_loc == MEAO_MEM_HOST) {   // own staging buffer: stage_out may hold the results (debug id 17)
+        if (!ctx->stage_view) MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->stage_view), align_up(out_bytes)));
+        dev_out = ctx->stage_view;
+    }
+    DebugViewArgs dv{};
+    dv.src = src; dv.dst = dev_out;
+    dv.sw = d.width; dv.sh = d.height; dv.slices = d.slices; dv.src_format = d.format;
+    dv.w = ctx->cfg.width; dv.h = ctx->cfg.height;
+    dv.f16_rtne = ctx->cfg.f16_rounding == MEAO_F16_RTNE;
+    MEAO_HIP(ctx, launch_debug_view(dv, ctx->cfg.ao_format, s));
+    if (out_loc == MEAO_MEM_HOST) {
+        MEAO_HIP(ctx, hipMemcpyAsync(out, dev_out, out_bytes, hipMemcpyDeviceToHost, s));
+        MEAO_HIP(ctx, hipStreamSynchronize(s));
+    }
     return MEAO_OK;
 }
 

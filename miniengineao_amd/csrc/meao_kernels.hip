@@ -767,6 +767,37 @@ __global__ __launch_bounds__(kThreads) void selftest_f16_decode_kernel(unsigned 
 }
 
 // ------------------------------------------------------------------------------------------
+// Debug view (AO.cs:787-820): point-sample a buffer (or the 4x4 slice grid of a tiled array,
+// Blit.shader:136-155) at the destination texel centres; integer-exact sampling positions.
+
+template <int AOFMT, bool RTNE>
+__global__ __launch_bounds__(kThreads) void debug_view_kernel(const DebugViewArgs a)
+{
+    typedef AoTexel<AOFMT> AO;
+    const int64_t n = static_cast<int64_t>(a.w) * a.h;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kThreads) {
+        const int x = static_cast<int>(i % a.w), y = static_cast<int>(i / a.w);
+        int sx, sy, sl = 0;
+        if (a.slices == 1) {                         // cmd.Blit(rt, _result): uv = (x + 0.5) / W
+            sx = static_cast<int>((static_cast<int64_t>(2 * x + 1) * a.sw) / (2 * a.w));
+            sy = static_cast<int>((static_cast<int64_t>(2 * y + 1) * a.sh) / (2 * a.h));
+        } else {                                     // uv4 = uv * 4: slice = floor(uv4), texel = frac(uv4) * dims
+            const int nx = 4 * x + 2, ny = 4 * y + 2;                  // uv4 = n / W
+            sl = nx / a.w + 4 * (ny / a.h);
+            sx = static_cast<int>((static_cast<int64_t>(nx % a.w) * a.sw) / a.w);
+            sy = static_cast<int>((static_cast<int64_t>(ny % a.h) * a.sh) / a.h);
+        }
+        const size_t at = (static_cast<size_t>(sl) * a.sh + sy) * a.sw + sx;
+        float v;
+        if (a.src_format == MEAO_FMT_F32) v = static_cast<const float *>(a.src)[at];
+        else if (a.src_format == MEAO_FMT_F16) v = f16_bits_to_f32(static_cast<const uint16_t *>(a.src)[at]);
+        else v = unorm8_to_f32(static_cast<const uint8_t *>(a.src)[at]);
+        static_cast<typename AO::type *>(a.dst)[i] = AO::template encode<RTNE>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Composite (Blit.shader:66-134): pure streaming, 17 bytes per texel (RGBA16F read + write, AO).
 // One lane = 4 texels = two 16-byte colour loads/stores + one 4-byte (R8) AO load.
 
@@ -932,6 +963,20 @@ hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s)
     const int blocks = (n + kThreads - 1) / kThreads;
     if (a.f16_rtne) tile_atlas_kernel<true><<<dim3(blocks < 4096 ? blocks : 4096), dim3(kThreads), 0, s>>>(a);
     else tile_atlas_kernel<false><<<dim3(blocks < 4096 ? blocks : 4096), dim3(kThreads), 0, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_view(const DebugViewArgs &a, int ao_format, hipStream_t s)
+{
+    const int64_t n = static_cast<int64_t>(a.w) * a.h;
+    const dim3 grid(static_cast<int>(std::min<int64_t>((n + kThreads - 1) / kThreads, 256 * 32))), block(kThreads);
+    if (ao_format == MEAO_AO_R8) {
+        if (a.f16_rtne) debug_view_kernel<MEAO_AO_R8, true><<<grid, block, 0, s>>>(a);
+        else debug_view_kernel<MEAO_AO_R8, false><<<grid, block, 0, s>>>(a);
+    } else {
+        if (a.f16_rtne) debug_view_kernel<MEAO_AO_F16, true><<<grid, block, 0, s>>>(a);
+        else debug_view_kernel<MEAO_AO_F16, false><<<grid, block, 0, s>>>(a);
+    }
     return hipGetLastError();
 }
 

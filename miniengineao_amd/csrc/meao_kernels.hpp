@@ -84,6 +84,15 @@ hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStre
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
 hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s);
+// Debug view (PushDebugBlitCommands): src in `src_format` (meao_format), [slices][sh][sw] -> dst AO W x H.
+struct DebugViewArgs {
+    const void *src;
+    void *dst;
+    int32_t sw, sh, slices, src_format;
+    int32_t w, h;
+    int32_t f16_rtne;
+};
+hipError_t launch_debug_view(const DebugViewArgs &a, int ao_format, hipStream_t s);
 // Composite (Blit.shader passes 1-3): ao in ao_format, color RGBA16F in place, gbuffer0 RGBA8 or null.
 struct CompositeArgs {
     const void *ao;

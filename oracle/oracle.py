@@ -239,5 +239,33 @@ def composite(ao: np.ndarray, color_rgba16f: np.ndarray, mode: int, ao_format: i
         raise RuntimeError(f"oracle composite failed: {rc}")
 
 
+def debug_view(buffers: dict, debug_id: int, s: "Settings") -> np.ndarray:
+    """PushDebugBlitCommands (AO.cs:787-820) over the oracle's buffers: cmd.Blit(rt, _result) point
+    sampling for 2D buffers, the 4x4 slice grid of Blit.shader:136-155 for tiled arrays; sampling
+    positions in exact integer arithmetic; the store converts like every AO store."""
+    src = buffers[BUFFER_IDS[debug_id]]
+    W, H = s.width, s.height
+    x, y = np.arange(W, dtype=np.int64)[None, :], np.arange(H, dtype=np.int64)[:, None]
+    if src.ndim == 2:
+        sh, sw = src.shape
+        vals = src[((2 * y + 1) * sh) // (2 * H), ((2 * x + 1) * sw) // (2 * W)]
+    else:
+        _, sh, sw = src.shape
+        nx, ny = 4 * x + 2, 4 * y + 2
+        vals = src[nx // W + 4 * (ny // H), ((ny % H) * sh) // H, ((nx % W) * sw) // W]
+    if src.dtype == np.float32:
+        f = vals
+    elif src.dtype == np.uint8:
+        f = vals.astype(np.float32) / np.float32(255)
+    else:
+        f = f16_bits_to_f32(vals)
+    L = lib()
+    if s.ao_format == AO_R8:
+        enc = np.vectorize(lambda v: L.meao_oracle_f32_to_unorm8(float(v)), otypes=[np.uint8])
+    else:
+        enc = np.vectorize(lambda v: L.meao_oracle_f32_to_f16(float(v), s.f16_rounding), otypes=[np.uint16])
+    return enc(f)
+
+
 def f16_bits_to_f32(bits: np.ndarray) -> np.ndarray:
     return np.asarray(bits, dtype=np.uint16).view(np.float16).astype(np.float32)
