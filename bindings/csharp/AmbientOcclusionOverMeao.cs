@@ -1,4 +1,4 @@
-// AmbientOcclusion.cs -- drop-in for the hot path of MiniEngineAO.AmbientOcclusion
+// AmbientOcclusionOverMeao.cs -- drop-in for the hot path of MiniEngineAO.AmbientOcclusion
 // (reference: Assets/MiniEngineAO/AmbientOcclusion.cs) on top of libmeao_hip.so.
 //
 // NOT COMPILED HERE (no C# toolchain in the build image); shipped as the reference-side

@@ -45,7 +45,7 @@ def test_csharp_dllimports_match_the_header():
 
 
 def test_csharp_wrapper_keeps_the_reference_surface():
-    src = open(os.path.join(ROOT, "bindings", "csharp", "AmbientOcclusion.cs")).read()
+    src = open(os.path.join(ROOT, "bindings", "csharp", "AmbientOcclusionOverMeao.cs")).read()
     assert "namespace MiniEngineAO" in src and "public sealed class AmbientOcclusion" in src
     for name in REFERENCE_PROPERTIES:
         assert re.search(r"public (float|bool) %s\b" % name, src), name
