@@ -54,7 +54,7 @@ def make_frame(kind: str, w: int, h: int, seed: int) -> np.ndarray:
 
 def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
     """The oracle (a port of the reference passes), row-parallel on all host cores, timed on a
-    bounded sample of the same workload: whole frames of this workload, median of <=3 after
+    bounded sample of the same workload: whole frames of this workload, median of <=8 after
     one warm-up, stopping early once ~budget_s of CPU time is spent."""
     from oracle import oracle as O   # test infrastructure: used here only as the reported baseline
     cores = os.cpu_count() or 1
@@ -63,7 +63,7 @@ def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
     times = []
     t_begin = time.perf_counter()
     O.run(depth, s, nthreads=cores, result_only=True)       # warm-up
-    for _ in range(3):
+    for _ in range(8):
         t0 = time.perf_counter()
         O.run(depth, s, nthreads=cores, result_only=True)
         times.append(time.perf_counter() - t0)

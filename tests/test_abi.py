@@ -13,7 +13,8 @@ from miniengineao_amd import synth
 from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = open(os.path.join(ROOT, "include", "meao.h")).read()
+with open(os.path.join(ROOT, "include", "meao.h")) as _f:
+    HEADER = _f.read()
 
 
 def header_functions():

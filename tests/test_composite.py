@@ -23,9 +23,10 @@ def test_oracle_composite_semantics(oracle):
     c0 = color.copy()
     oracle.composite(ao, c0, 0)
     a32 = ao.astype(np.float32) / np.float32(255)
-    want = (color.view(np.float16).astype(np.float32) * a32[..., None]).astype(np.float16).view(np.uint16)
+    with np.errstate(invalid="ignore"):                      # the probe texel multiplies inf by 0
+        want = (color.view(np.float16).astype(np.float32) * a32[..., None]).astype(np.float16).view(np.uint16)
     assert np.array_equal(c0[1:], want[1:])                  # numpy f32->f16 is RTNE
-    assert (c0[0, 1] == color[0, 1]).all() or True           # ao = 1 keeps the texel
+    assert (c0[0, 1] == color[0, 1]).all()                   # ao = 255/255 = 1 keeps the texel
     c2 = color.copy()
     oracle.composite(ao, c2, 2)
     assert (c2[0, 1] == 0x3c00).all() and (c2[0, 0] == 0).all()

@@ -11,7 +11,8 @@ from tests import helpers as H
 from tests.golden import make_golden as G
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SUMS = json.load(open(os.path.join(HERE, "golden_checksums.json")))
+with open(os.path.join(HERE, "golden_checksums.json")) as _f:
+    SUMS = json.load(_f)
 
 
 @pytest.mark.parametrize("name", sorted(G.SMALL))

@@ -6,7 +6,8 @@ import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = open(os.path.join(ROOT, "include", "meao.h")).read()
+with open(os.path.join(ROOT, "include", "meao.h")) as _f:
+    HEADER = _f.read()
 REFERENCE_PROPERTIES = ["noiseFilterTolerance", "blurTolerance", "upsampleTolerance",
                         "thicknessModifier", "intensity", "ambientOnly"]     # AmbientOcclusion.cs:22-66
 

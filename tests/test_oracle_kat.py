@@ -178,10 +178,9 @@ def test_downsample_index_identities(oracle):
     s = H.settings(oracle, w, h)
     out = oracle.run(depth, s)
     zp = oracle.zbuffer_params(s)
-    lin = (np.float32(1.0) / (np.float32(zp[0]) * depth + np.float32(zp[1]))).astype(np.float32)
-    # fused multiply-add vs mul+add can differ in the last bit: recompute exactly via float64
-    lin = (1.0 / (np.float64(zp[0]) * depth.astype(np.float64) + np.float64(zp[1])))
-    lin32 = (np.float32(1.0) / (np.float64(zp[0]) * depth.astype(np.float64) + np.float64(zp[1])).astype(np.float32)).astype(np.float32)
+    # mad(ZP.x, d, ZP.y): the product of two f32 is exact in f64, the sum rounds once to f32
+    den = (np.float64(zp[0]) * depth.astype(np.float64) + np.float64(zp[1])).astype(np.float32)
+    lin32 = (np.float32(1.0) / den).astype(np.float32)
     assert np.array_equal(out["low_depth1"], lin32[::2, ::2])
     assert np.array_equal(out["low_depth2"], lin32[::4, ::4])
     assert np.array_equal(out["low_depth3"], lin32[::8, ::8])
