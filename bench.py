@@ -104,6 +104,8 @@ def main() -> int:
     ap.add_argument("--composite", action="store_true",
                     help="also time the next-tier composite kernel (AO x RGBA16F frame, Blit.shader pass 2); "
                          "reported separately, never part of `value`")
+    ap.add_argument("--fast-numerics", action="store_true",
+                    help="MEAO_NUMERICS_FAST (raw v_rcp_f32 divides; NOT bit-exact, reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
@@ -137,7 +139,8 @@ def main() -> int:
     for _ in range(nfl):
         c = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=B,
                              near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
-                             reversed_z=cam.reversed_z)
+                             reversed_z=cam.reversed_z,
+                             numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT)
         c.intensity = intensity
         ctxs.append(c)
     ao = ctxs[0]
@@ -247,7 +250,7 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": desc, "width": w, "height": h, "frames_per_step_per_gpu": B,
                        "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
-                       "numerics": "strict (bit-exact vs CPU oracle)", "sharding": f"frames x{world}",
+                       "numerics": "FAST (raw rcp, not bit-exact)" if args.fast_numerics else "strict (bit-exact vs CPU oracle)", "sharding": f"frames x{world}",
                        "batches_in_flight": nfl},
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),

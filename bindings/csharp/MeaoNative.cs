@@ -20,7 +20,7 @@ namespace MiniEngineAO.Native
 
     public enum MeaoAoFormat { R8 = 0, F16 = 1 }
     public enum MeaoF16Rounding { RtzClamp = 0, Rtne = 1 }
-    public enum MeaoNumerics { Strict = 0 }
+    public enum MeaoNumerics { Strict = 0, Fast = 1 }
     public enum MeaoMem { Host = 0, Device = 1 }
     public enum MeaoDepthFormat { F32 = 0, Unorm16 = 1, Unorm24 = 2, F16 = 3 }
     public enum MeaoCompositeMode { Multiply = 0, AmbientOnly = 1, Debug = 2 }

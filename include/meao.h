@@ -59,8 +59,11 @@ typedef enum meao_ao_format { MEAO_AO_R8 = 0, MEAO_AO_F16 = 1 } meao_ao_format;
  * hardware behaviour.  Only matters for sky texels (1e5) and the last mantissa bit. */
 typedef enum meao_f16_rounding { MEAO_F16_RTZ_CLAMP = 0, MEAO_F16_RTNE = 1 } meao_f16_rounding;
 
-/* STRICT: bit-exact against the CPU oracle (IEEE '/', explicit mad fusion only). */
-typedef enum meao_numerics { MEAO_NUMERICS_STRICT = 0 } meao_numerics;
+/* STRICT (default): bit-exact against the CPU oracle (correctly rounded '/', explicit mad fusion
+ * only).  FAST: every divide is the raw 1-ulp v_rcp_f32 times the numerator; NOT bit-exact --
+ * AO texels may differ from STRICT by one storage step on a small fraction of texels; everything
+ * else (fusion, storage conversions) is unchanged.  Applies with RTZ_CLAMP depth storage. */
+typedef enum meao_numerics { MEAO_NUMERICS_STRICT = 0, MEAO_NUMERICS_FAST = 1 } meao_numerics;
 
 typedef enum meao_mem { MEAO_MEM_HOST = 0, MEAO_MEM_DEVICE = 1 } meao_mem;
 

@@ -32,7 +32,7 @@ ERR_INVALID_ARGUMENT, ERR_HIP, ERR_OUT_OF_MEMORY = -1, -2, -3
 ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL = -4, -5, -6
 AO_R8, AO_F16 = 0, 1
 F16_RTZ_CLAMP, F16_RTNE = 0, 1
-NUMERICS_STRICT = 0
+NUMERICS_STRICT, NUMERICS_FAST = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 DEPTH_F32, DEPTH_UNORM16, DEPTH_UNORM24, DEPTH_F16 = 0, 1, 2, 3
 COMPOSITE_MULTIPLY, COMPOSITE_AMBIENT_ONLY, COMPOSITE_DEBUG = 0, 1, 2

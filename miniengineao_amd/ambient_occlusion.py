@@ -32,7 +32,7 @@ class AmbientOcclusion:
 
     def __init__(self, width: int, height: int, *, device: int = 0, num_levels: int = 4,
                  ao_format: int = L.AO_R8, f16_rounding: int = L.F16_RTZ_CLAMP,
-                 max_batch: int = 1, depth_format: int = L.DEPTH_F32,
+                 max_batch: int = 1, depth_format: int = L.DEPTH_F32, numerics: int = L.NUMERICS_STRICT,
                  near_clip: float = 0.3, far_clip: float = 1000.0,
                  projection00: Optional[float] = None, reversed_z: bool = True):
         self._lib = L.load()
@@ -42,6 +42,7 @@ class AmbientOcclusion:
         cfg.num_levels, cfg.ao_format, cfg.f16_rounding = num_levels, ao_format, f16_rounding
         cfg.max_batch = max_batch
         cfg.depth_format = depth_format
+        cfg.numerics = numerics
         self._cfg = cfg
         prm = L.Params()
         self._lib.meao_default_params(C.byref(prm))

@@ -128,6 +128,8 @@ void update_plan(meao_ctx *ctx)
 {
     build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->prm, &ctx->plan);
     ctx->exact_rcp_div = exact_rcp_div_applicable(ctx->cfg, ctx->prm, ctx->plan) ? 1 : 0;
+    // MEAO_NUMERICS_FAST: raw v_rcp_f32 (2 = DIV_FAST in the kernels); RTZ storage only, like the exact mode
+    if (ctx->cfg.numerics == MEAO_NUMERICS_FAST && ctx->cfg.f16_rounding == MEAO_F16_RTZ_CLAMP) ctx->exact_rcp_div = 2;
 }
 
 void release_buffers(meao_ctx *ctx)
@@ -398,8 +400,8 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
         return fail(nullptr, MEAO_ERR_INVALID_ARGUMENT, "meao_create: struct_size mismatch (ABI)");
     std::string why;
     if (!config_valid(*cfg, &why)) return fail(nullptr, MEAO_ERR_INVALID_ARGUMENT, "meao_create: " + why);
-    if (cfg->numerics != MEAO_NUMERICS_STRICT)
-        return fail(nullptr, MEAO_ERR_UNSUPPORTED, "meao_create: only MEAO_NUMERICS_STRICT is implemented");
+    if (cfg->numerics != MEAO_NUMERICS_STRICT && cfg->numerics != MEAO_NUMERICS_FAST)
+        return fail(nullptr, MEAO_ERR_UNSUPPORTED, "meao_create: unknown numerics mode");
 
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);

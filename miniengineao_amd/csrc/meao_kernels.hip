@@ -152,7 +152,8 @@ __device__ __forceinline__ T *frame_ptr(T *base, uint64_t stride_bytes, int fram
 // and are re-verified on the running device by meao_selftest(4..6).  The host selects this mode
 // only when the operands are provably inside those ranges (RTZ depth storage, so no inf from sky
 // texels; tolerances inside the component's ranges), otherwise DIV_IEEE (hipcc's expansion).
-enum { DIV_EXACT_RCP = 0, DIV_IEEE = 1 };
+// DIV_FAST (MEAO_NUMERICS_FAST, not bit-exact): the raw 1-ulp v_rcp_f32 without correction steps.
+enum { DIV_EXACT_RCP = 0, DIV_IEEE = 1, DIV_FAST = 2 };
 
 template <int DIV>
 __device__ __forceinline__ float rcp_strict(float x)
@@ -161,6 +162,8 @@ __device__ __forceinline__ float rcp_strict(float x)
         const float r = __builtin_amdgcn_rcpf(x);
         const float e = mad(-x, r, 1.0f);
         return mad(e, r, r);
+    } else if constexpr (DIV == DIV_FAST) {
+        return __builtin_amdgcn_rcpf(x);
     } else {
         return 1.0f / x;
     }
@@ -175,6 +178,8 @@ __device__ __forceinline__ float div_const(float x)   // K / x, K in {1, 3, 9}
         const float q = static_cast<float>(K) * r;
         const float e = mad(-x, q, static_cast<float>(K));
         return mad(e, r, q);
+    } else if constexpr (DIV == DIV_FAST) {
+        return static_cast<float>(K) * __builtin_amdgcn_rcpf(x);
     } else {
         return static_cast<float>(K) / x;
     }
@@ -188,6 +193,8 @@ __device__ __forceinline__ float div_strict(float a, float b)
         const float q = a * r;
         const float e = mad(-b, q, a);
         return mad(e, r, q);
+    } else if constexpr (DIV == DIV_FAST) {
+        return a * __builtin_amdgcn_rcpf(b);
     } else {
         return a / b;
     }
@@ -909,6 +916,9 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
     if (a.f16_rtne) {
         if (vec) downsample_kernel<true, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
         else downsample_kernel<true, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
+    } else if (a.exact_rcp_div == 2) {
+        if (vec) downsample_kernel<false, true, DIV_FAST><<<grid, block, 0, s>>>(a);
+        else downsample_kernel<false, false, DIV_FAST><<<grid, block, 0, s>>>(a);
     } else if (a.exact_rcp_div) {
         if (vec) downsample_kernel<false, true, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
         else downsample_kernel<false, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
@@ -924,10 +934,12 @@ hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStre
     const dim3 grid(a.blocks_per_frame, frames, 1), block(kThreads);
     if (ao_format == MEAO_AO_R8) {
         if (a.f16_rtne) render_kernel<MEAO_AO_R8, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        else if (a.exact_rcp_div == 2) render_kernel<MEAO_AO_R8, false, DIV_FAST><<<grid, block, 0, s>>>(a);
         else if (a.exact_rcp_div) render_kernel<MEAO_AO_R8, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
         else render_kernel<MEAO_AO_R8, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
     } else {
         if (a.f16_rtne) render_kernel<MEAO_AO_F16, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        else if (a.exact_rcp_div == 2) render_kernel<MEAO_AO_F16, false, DIV_FAST><<<grid, block, 0, s>>>(a);
         else if (a.exact_rcp_div) render_kernel<MEAO_AO_F16, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
         else render_kernel<MEAO_AO_F16, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
     }
@@ -947,10 +959,12 @@ hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f
     // exact_rcp_div is only ever set together with RTZ depth storage (no inf operands)
     if (ao_format == MEAO_AO_R8) {
         if (a.f16_rtne) launch_upsample_t<MEAO_AO_R8, true, DIV_IEEE>(a, hi_depth_f16, grid, s);
+        else if (a.exact_rcp_div == 2) launch_upsample_t<MEAO_AO_R8, false, DIV_FAST>(a, hi_depth_f16, grid, s);
         else if (a.exact_rcp_div) launch_upsample_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(a, hi_depth_f16, grid, s);
         else launch_upsample_t<MEAO_AO_R8, false, DIV_IEEE>(a, hi_depth_f16, grid, s);
     } else {
         if (a.f16_rtne) launch_upsample_t<MEAO_AO_F16, true, DIV_IEEE>(a, hi_depth_f16, grid, s);
+        else if (a.exact_rcp_div == 2) launch_upsample_t<MEAO_AO_F16, false, DIV_FAST>(a, hi_depth_f16, grid, s);
         else if (a.exact_rcp_div) launch_upsample_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, hi_depth_f16, grid, s);
         else launch_upsample_t<MEAO_AO_F16, false, DIV_IEEE>(a, hi_depth_f16, grid, s);
     }

@@ -149,7 +149,7 @@ def test_argument_validation(meao_lib):
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
     bad = L.Config.from_buffer_copy(cfg); bad.max_batch = 17
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
-    bad = L.Config.from_buffer_copy(cfg); bad.numerics = 1
+    bad = L.Config.from_buffer_copy(cfg); bad.numerics = 7
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_UNSUPPORTED
     assert meao_lib.meao_destroy(None) == 0
     assert meao_lib.meao_execute(None, None, 0, None, 0, None) == L.ERR_INVALID_ARGUMENT
