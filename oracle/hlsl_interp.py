@@ -772,6 +772,12 @@ SEMANTIC_TO_VALUE = {"SV_GroupID": "Gid", "SV_GroupIndex": "GI", "SV_GroupThread
                      "SV_DispatchThreadID": "DTid"}
 
 
+def attach_semantics(prog, entry, preprocessed_src):
+    """System-value semantics of the entry point's parameters, read from the source text."""
+    sig = re.search(r"void\s+%s\s*\((.*?)\)" % re.escape(entry), preprocessed_src, re.S).group(1)
+    prog.funcs[entry].semantics = [SEMANTIC_TO_VALUE[s] for s in re.findall(r":\s*(SV_\w+)", sig)]
+
+
 def compile_kernel(source_text, kernel_name):
     """Preprocess + parse one #pragma kernel variant.  Returns (Program, entry function name)."""
     variants = kernel_variants(source_text)

@@ -10,20 +10,20 @@
  * and no tests, and Unity / a D3D GPU / fxc are not available, so parity
  * against outputs of the reference *running on its own platform* is unpinned.
  * What pins the oracle instead:
- *  (1) the reference's own shader source text (the four .compute files under
- *      /root/reference) is executed by oracle/hlsl_interp.py, driven like
- *      AmbientOcclusion.cs drives Unity; all 17 buffers are committed as
- *      fixtures (tests/golden/ref_*.npz, generator committed) and both
- *      restatements must reproduce them bit for bit.  The interpreter supplies
- *      only what a driver/GPU would: the numerics contract and the resource /
- *      format semantics -- those remain this project's canonical reading;
+ *  (1) the reference's own source text is executed: AmbientOcclusion.cs by
+ *      oracle/csharp_interp.py (against recording Unity mocks) yields the
+ *      buffer table, the ten dispatches, their bindings, constants and grids;
+ *      the four .compute files run through oracle/hlsl_interp.py.  All 17
+ *      buffers are committed as fixtures (tests/golden/ref_*.npz, generator
+ *      committed) and both restatements must reproduce them bit for bit.  The
+ *      interpreters supply only what the reference's platform would: the
+ *      numerics contract, the resource / format semantics and Unity's API
+ *      behaviour -- those remain this project's canonical reading;
  *  (2) two independently structured restatements -- this file's per-pixel
  *      gather form and meao_hlsl_emul.c's literal thread-group/LDS emulation --
  *      agree bit-for-bit on all 17 intermediates at many odd sizes and modes;
  *  (3) analytical known-answer tests derived from the reference source
  *      (tests/test_oracle_kat.py).
- * The host-side C# constant math (AO.cs:561-573,660-771) is restated, not
- * executed (no C# toolchain).
  *
  * Canonical numerics (DESIGN.md "Numerics contract"): IEEE-754 binary32,
  * round-to-nearest-even, correctly rounded '/' and sqrt; an HLSL expression

@@ -1,9 +1,11 @@
-"""Runs the REFERENCE'S OWN compute shaders (read from /root/reference, never copied) through
-oracle/hlsl_interp.py, driven the way AmbientOcclusion.cs ("AO.cs") drives Unity, and commits
-all 17 buffers as fixtures (tests/golden/ref_*.npz).  These are the closest thing to "outputs of
-the reference itself" obtainable here: the shader text is executed as written; the host constants
-(AO.cs:561-573,660-771) come from the oracle's restatement of the C#, the numerics contract and
-resource semantics are those of DESIGN.md section 2.
+"""Runs THE REFERENCE ITSELF from its source text (read from /root/reference, never copied):
+AmbientOcclusion.cs is executed by oracle/csharp_interp.py against recording Unity mocks
+(tests/golden/unity_mocks.py) and yields the render-texture allocations, the ten compute
+dispatches, their texture bindings, constant blocks and group counts; each dispatch then runs the
+reference's .compute source through oracle/hlsl_interp.py.  All 17 buffers are committed as
+fixtures (tests/golden/ref_*.npz).  What is NOT taken from the reference, because its platform
+would supply it: the numerics contract and resource/format semantics of DESIGN.md section 2, and
+Unity's API behaviour (mocked).
 
     python tests/golden/make_reference_goldens.py            # needs /root/reference (build box only)
 
@@ -37,92 +39,104 @@ CASES = {
 }
 
 
-def textures(s):
-    """The RTHandle table of AO.cs:453-475 as interpreter textures over numpy arrays."""
+AO_CS = "/root/reference/Assets/MiniEngineAO/AmbientOcclusion.cs"
+SHADER_FILES = ("Downsample1", "Downsample2", "Render", "Upsample")
+
+# shader property name -> key in the oracle's buffer dict
+ORACLE_KEY = {"LinearDepth": "linear_depth", "AmbientOcclusion": "result"}
+for _k in range(1, 5):
+    ORACLE_KEY.update({f"LowDepth{_k}": f"low_depth{_k}", f"TiledDepth{_k}": f"tiled_depth{_k}",
+                       f"Occlusion{_k}": f"occlusion{_k}", f"Combined{_k}": f"combined{_k}"})
+
+
+def shader_sources():
+    return {n: open(os.path.join(SHADERS, n + ".compute")).read() for n in SHADER_FILES}
+
+
+def kernel_numthreads(src):
+    """[numthreads] of every #pragma kernel variant, read from the shader text."""
+    out = {}
+    for name, text in src.items():
+        out[name] = {}
+        for kernel in HI.kernel_variants(text):
+            prog, entry = HI.compile_kernel(text, kernel)
+            m = HI.Machine(prog)
+            out[name][kernel] = tuple(int(m.eval(d, [])[1][0]) for d in prog.funcs[entry].numthreads)
+    return out
+
+
+def record_reference_commands(s):
+    """Run the reference's own C# (AmbientOcclusion.cs: DoLazyInitialization + RebuildCommandBuffers)
+    through oracle/csharp_interp.py against recording Unity mocks."""
+    from tests.golden import unity_mocks as U
+    src = shader_sources()
+    props = {"_noiseFilterTolerance": s.noise_filter_tolerance, "_blurTolerance": s.blur_tolerance,
+             "_upsampleTolerance": s.upsample_tolerance, "_thicknessModifier": s.thickness_modifier,
+             "_intensity": s.intensity}
+    cmd, result_rt = U.run_component(AO_CS, kernel_numthreads(src), width=s.width, height=s.height,
+                                     near=s.near_clip, far=s.far_clip, proj00=s.proj00,
+                                     reversed_z=s.reversed_z, properties=props)
+    return src, cmd, result_rt
+
+
+def textures(s, cmd, result_rt):
+    """Render textures exactly as the reference allocates them (names, dims, slices, formats come
+    from the recorded GetTemporaryRT(Array) calls and the persistent result RT).  The only
+    deviation is this project's extension: AO targets are RHalf instead of R8 when s.ao_format
+    is F16; the f32->f16 store rounding is the canonical choice of DESIGN.md section 2."""
     L = O.lib()
-    arrs = O.allocate(s)
     f16 = dict(decode=lambda v: np.float32(L.meao_oracle_f16_to_f32(int(v))),
                encode=lambda v: L.meao_oracle_f32_to_f16(float(v), s.f16_rounding))
     r8 = dict(decode=lambda v: np.float32(L.meao_oracle_unorm8_to_f32(int(v))),
               encode=lambda v: L.meao_oracle_f32_to_unorm8(float(v)))
-    ao = r8 if s.ao_format == O.AO_R8 else f16
-    tex = {}
-    for name, a in arrs.items():
-        view = a if a.ndim == 3 else a[None]
-        if a.dtype == np.float32:
-            tex[name] = HI.Texture(view)
-        elif name.startswith(("linear", "tiled")):
-            tex[name] = HI.Texture(view, **f16)
-        else:
-            tex[name] = HI.Texture(view, **ao)
+    allocs = dict(cmd.allocs)
+    allocs["AmbientOcclusion"] = (result_rt.width, result_rt.height, 1, result_rt.format._name.split(".")[-1])
+    arrs, tex = {}, {}
+    for name, (w, h, slices, fmt) in allocs.items():
+        if fmt == "R8" and s.ao_format == O.AO_F16:
+            fmt = "RHalf"
+        dt = {"RFloat": np.float32, "RHalf": np.uint16, "R8": np.uint8}[fmt]
+        a = np.zeros((slices, h, w), dt)
+        arrs[ORACLE_KEY[name]] = a if slices > 1 else a[0]
+        tex[name] = HI.Texture(a, **({} if fmt == "RFloat" else (f16 if fmt == "RHalf" else r8)))
     return arrs, tex
 
 
-def vec(*vals):
-    return ("f", [np.float32(v) for v in vals])
-
-
 def run_reference_shaders(depth, s, log=print):
-    """RebuildCommandBuffers (AO.cs:496-531) over the interpreter."""
-    src = {n: open(os.path.join(SHADERS, n + ".compute")).read()
-           for n in ("Downsample1", "Downsample2", "Render", "Upsample")}
-    arrs, tex = textures(s)
+    """The reference end to end: its C# decides allocations, bindings, constants and dispatch sizes,
+    its HLSL does the arithmetic; both are interpreted from the source text under /root/reference."""
+    assert s.num_levels == 4 and s.depth_format == O.DEPTH_F32, "the reference always runs 4 levels on an RFloat depth"
+    src, cmd, result_rt = record_reference_commands(s)
+    arrs, tex = textures(s, cmd, result_rt)
     depth_tex = HI.Texture(np.ascontiguousarray(depth, np.float32)[None])
-    dims = [O.level_dims(s.width, s.height, k) for k in range(7)]
-    t0 = time.time()
-
-    # ---- PushDownsampleCommands (AO.cs:604-658)
     rev = {"UNITY_REVERSED_Z": "1"} if s.reversed_z else {}
-    variants = HI.kernel_variants(src["Downsample1"])
-    prog = HI.Parser(HI.lex(HI.preprocess(src["Downsample1"], dict(variants["main"], **rev)))).program()
-    prog.funcs["main"].semantics = ["Gid", "GI", "GTid", "DTid"]
-    m = HI.Machine(prog)
-    m.bind = {"Depth": depth_tex, "LinearZ": tex["linear_depth"], "DS2x": tex["low_depth1"],
-              "DS4x": tex["low_depth2"], "DS2xAtlas": tex["tiled_depth1"], "DS4xAtlas": tex["tiled_depth2"]}
-    m.const = {"ZBufferParams": vec(*O.zbuffer_params(s))}
-    m.dispatch("main", (dims[4][0], dims[4][1], 1))                    # _tiledDepth2 dims (AO.cs:643)
-    prog, entry = HI.compile_kernel(src["Downsample2"], "main")
-    m = HI.Machine(prog)
-    m.bind = {"DS4x": tex["low_depth2"], "DS8x": tex["low_depth3"], "DS16x": tex["low_depth4"],
-              "DS8xAtlas": tex["tiled_depth3"], "DS16xAtlas": tex["tiled_depth4"]}
-    m.dispatch(entry, (dims[6][0], dims[6][1], 1))                     # _tiledDepth4 dims (AO.cs:657)
-    log(f"  downsample done {time.time() - t0:.1f}s")
-
-    # ---- PushRenderCommands (AO.cs:660-748), kernel main_interleaved
-    prog, entry = HI.compile_kernel(src["Render"], "main_interleaved")
-    for level in range(1, s.num_levels + 1):
-        k = O.render_constants(s, level)
+    t0 = time.time()
+    for d in cmd.dispatches:
+        text = src[d["shader"]]
+        variant = dict(HI.kernel_variants(text)[d["kernel"]], **rev)
+        entry = variant.get("MAIN", d["kernel"])
+        prog = HI.Parser(HI.lex(HI.preprocess(text, variant))).program()
+        HI.attach_semantics(prog, entry, HI.preprocess(text, variant))
         m = HI.Machine(prog)
-        m.bind = {"DepthTex": tex[f"tiled_depth{level}"], "Occlusion": tex[f"occlusion{level}"]}
-        m.const = {"gInvThicknessTable": [vec(*list(k.inv_thickness)[i:i + 4]) for i in (0, 4, 8)],
-                   "gSampleWeightTable": [vec(*list(k.sample_weight)[i:i + 4]) for i in (0, 4, 8)],
-                   "gInvSliceDimension": vec(k.inv_slice_dim[0], k.inv_slice_dim[1], 0, 0),
-                   "gRejectFadeoff": vec(k.reject_fadeoff), "gIntensity": vec(k.intensity)}
-        sw, sh = dims[level + 2]
-        m.dispatch(entry, ((sw + 7) // 8, (sh + 7) // 8, 16))          # AO.cs:742-747
-        log(f"  render level {level} done {time.time() - t0:.1f}s")
-
-    # ---- PushUpsampleCommands (AO.cs:750-785), generalised to num_levels like the oracle
-    lo_ao = tex[f"occlusion{s.num_levels}"]
-    for hi in range(s.num_levels - 1, -1, -1):
-        kernel = "main" if hi == 0 else "main_blendout"                # AO.cs:758
-        prog, entry = HI.compile_kernel(src["Upsample"], kernel)
-        k = O.upsample_constants(s, hi + 1)
-        m = HI.Machine(prog)
-        hi_db = tex["linear_depth"] if hi == 0 else tex[f"low_depth{hi}"]
-        dst = tex["result"] if hi == 0 else tex[f"combined{hi}"]
-        m.bind = {"LoResDB": tex[f"low_depth{hi + 1}"], "HiResDB": hi_db, "LoResAO1": lo_ao, "AoResult": dst}
-        if hi > 0:
-            m.bind["HiResAO"] = tex[f"occlusion{hi}"]
-        m.const = {"InvLowResolution": vec(k.inv_low_res[0], k.inv_low_res[1], 0, 0),
-                   "InvHighResolution": vec(k.inv_high_res[0], k.inv_high_res[1], 0, 0),
-                   "NoiseFilterStrength": vec(k.noise_filter_strength), "StepSize": vec(k.step_size),
-                   "kBlurTolerance": vec(k.blur_tolerance), "kUpsampleTolerance": vec(k.upsample_tolerance)}
-        hw, hh = dims[hi]
-        m.dispatch(entry, ((hw + 17) // 16, (hh + 17) // 16, 1))       # AO.cs:782-784
-        lo_ao = dst
-        log(f"  upsample -> L{hi} done {time.time() - t0:.1f}s")
-    return arrs
+        for prop, what in d["tex"].items():
+            if prop not in prog.resources:
+                continue                                  # stale binding of another kernel variant
+            if isinstance(what, str):
+                m.bind[prop] = tex[what]
+            elif type(what).__name__ == "RenderTexture":  # the persistent _result RenderTexture
+                m.bind[prop] = tex["AmbientOcclusion"]
+            else:                                         # BuiltinRenderTextureType.ResolvedDepth
+                m.bind[prop] = depth_tex
+        for name, (typ, length) in prog.uniforms.items():
+            vals = d["const"][name]
+            n = HI.parse_type(typ)[1]
+            if length is None:
+                m.const[name] = ("f", list(vals[:n]))
+            else:
+                m.const[name] = [("f", list(vals[i * n:(i + 1) * n])) for i in range(len(vals) // n)]
+        m.dispatch(entry, d["groups"])
+        log(f"  {d['shader']}.{d['kernel']} {d['groups']} done {time.time() - t0:.1f}s")
+    return arrs, cmd
 
 
 def make_depth(kind, w, h, seed, cam, sky):
@@ -143,7 +157,7 @@ def main(only=None):
         print(name)
         depth = make_depth(kind, w, h, seed, cam, sky)
         s = H.settings(O, w, h, cam=cam, **over)
-        ref = run_reference_shaders(depth, s)
+        ref, _ = run_reference_shaders(depth, s)
         want = O.run(depth, s)
         bad = [k for k in ref if not np.array_equal(ref[k], want[k])]
         print("  interpreter vs oracle: %s" % ("all 17 buffers identical" if not bad else "DIFFER: %s" % bad))

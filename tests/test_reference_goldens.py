@@ -30,18 +30,87 @@ def test_oracle_matches_reference_shader_outputs(oracle, name):
             assert np.array_equal(arr, fx[key]), H.diff_report(key, arr, fx[key])
 
 
-@pytest.mark.skipif(not os.path.isdir(R.SHADERS), reason="reference checkout not present (GPU box)")
-def test_reference_shaders_interpreted_live(oracle):
-    """Re-run the reference's .compute files through the interpreter now (not from fixtures)."""
+needs_reference = pytest.mark.skipif(not os.path.isdir(R.SHADERS), reason="reference checkout not present (GPU box)")
+
+
+@needs_reference
+def test_reference_interpreted_live(oracle):
+    """Re-run the reference now (not from fixtures): AmbientOcclusion.cs through the C# interpreter
+    records the dispatches, the .compute files run through the HLSL interpreter."""
     from miniengineao_amd import synth
     w, h = 18, 11
     cam = synth.Camera(reversed_z=False)
     depth = R.make_depth("S2", w, h, 5, cam, True)
-    s = H.settings(oracle, w, h, cam=cam, num_levels=2, intensity=0.8, thickness_modifier=3.0)
-    ref = R.run_reference_shaders(depth, s, log=lambda *_: None)
+    s = H.settings(oracle, w, h, cam=cam, intensity=0.8, thickness_modifier=3.0)
+    ref, cmd = R.run_reference_shaders(depth, s, log=lambda *_: None)
+    assert [d["kernel"] for d in cmd.dispatches] == ["main", "main"] + ["main_interleaved"] * 4 + ["main_blendout"] * 3 + ["main"]
     want = oracle.run(depth, s)
-    for i in H.valid_debug_ids(2):
+    for i in H.valid_debug_ids(4):
         assert np.array_equal(ref[H.NAMES[i]], want[H.NAMES[i]]), H.NAMES[i]
+
+
+@needs_reference
+@pytest.mark.parametrize("seed", range(6))
+def test_host_constants_from_the_reference_csharp(oracle, meao_lib, seed):
+    """The constant blocks, buffer table and dispatch grids recorded by the INTERPRETED
+    AmbientOcclusion.cs equal the oracle's restatement and the product's plan, bit for bit."""
+    import ctypes as C
+
+    from miniengineao_amd import _lib as L
+    from miniengineao_amd import synth
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(17, 4000)), int(rng.integers(9, 2200))
+    cam = synth.Camera(near=float(rng.uniform(0.01, 1)), far=float(rng.uniform(5, 2000)),
+                       fov_y_deg=float(rng.uniform(10, 100)), reversed_z=bool(seed & 1))
+    s = H.settings(oracle, w, h, cam=cam, noise_filter_tolerance=float(rng.uniform(-8, 0)),
+                   blur_tolerance=float(rng.uniform(-8, -1)), upsample_tolerance=float(rng.uniform(-12, -1)),
+                   thickness_modifier=float(rng.uniform(1, 10)), intensity=float(rng.uniform(0, 2)))
+    _, cmd, result_rt = R.record_reference_commands(s)
+    f = lambda xs: [float(x) for x in xs]               # noqa: E731
+    ds1 = cmd.dispatches[0]
+    assert f(ds1["const"]["ZBufferParams"]) == oracle.zbuffer_params(s)
+    dims = [oracle.level_dims(w, h, k) for k in range(7)]
+    assert ds1["groups"] == (dims[4][0], dims[4][1], 1) and cmd.dispatches[1]["groups"] == (dims[6][0], dims[6][1], 1)
+    p = L.Params()
+    meao_lib.meao_default_params(C.byref(p))
+    p.noise_filter_tolerance, p.blur_tolerance, p.upsample_tolerance = s.noise_filter_tolerance, s.blur_tolerance, s.upsample_tolerance
+    p.thickness_modifier, p.intensity, p.near_clip, p.far_clip = s.thickness_modifier, s.intensity, s.near_clip, s.far_clip
+    p.proj00, p.reversed_z = s.proj00, int(s.reversed_z)
+    for level, d in enumerate(cmd.dispatches[2:6], 1):
+        k = oracle.render_constants(s, level)
+        c = d["const"]
+        assert f(c["gInvThicknessTable"]) == f(k.inv_thickness) and f(c["gSampleWeightTable"]) == f(k.sample_weight)
+        assert f(c["gInvSliceDimension"][:2]) == f(k.inv_slice_dim)
+        assert f(c["gRejectFadeoff"]) == [k.reject_fadeoff] and f(c["gIntensity"]) == [k.intensity]
+        sw, sh = dims[level + 2]
+        assert d["groups"] == ((sw + 7) // 8, (sh + 7) // 8, 16)
+        assert d["tex"] == {"DepthTex": f"TiledDepth{level}", "Occlusion": f"Occlusion{level}"}
+        prod = L.RenderConstants()
+        assert meao_lib.meao_render_constants_for(w, h, C.byref(p), level, C.byref(prod)) == 0
+        assert f(prod.inv_thickness_table) == f(c["gInvThicknessTable"]) and f(prod.sample_weight_table) == f(c["gSampleWeightTable"])
+    for low, d in zip((4, 3, 2, 1), cmd.dispatches[6:]):
+        k, c = oracle.upsample_constants(s, low), d["const"]
+        assert (f(c["StepSize"]), f(c["kBlurTolerance"]), f(c["kUpsampleTolerance"]), f(c["NoiseFilterStrength"])) == \
+            ([k.step_size], [k.blur_tolerance], [k.upsample_tolerance], [k.noise_filter_strength])
+        assert f(c["InvLowResolution"][:2]) == f(k.inv_low_res) and f(c["InvHighResolution"][:2]) == f(k.inv_high_res)
+        hw, hh = dims[low - 1]
+        assert d["groups"] == ((hw + 17) // 16, (hh + 17) // 16, 1)
+        prod = L.UpsampleConstants()
+        assert meao_lib.meao_upsample_constants_for(w, h, C.byref(p), low, C.byref(prod)) == 0
+        assert (prod.step_size, prod.blur_tolerance, prod.upsample_tolerance, prod.noise_filter_strength) == \
+            (k.step_size, k.blur_tolerance, k.upsample_tolerance, k.noise_filter_strength)
+    # the buffer table (AO.cs:453-475) as the reference allocates it == meao_describe_buffer
+    cfg = L.Config()
+    meao_lib.meao_default_config(C.byref(cfg))
+    cfg.width, cfg.height = w, h
+    fmt_of = {"RFloat": L.FMT_F32, "RHalf": L.FMT_F16, "R8": L.FMT_UNORM8}
+    allocs = dict(cmd.allocs, AmbientOcclusion=(result_rt.width, result_rt.height, 1, "R8"))
+    from miniengineao_amd.ambient_occlusion import DEBUG_BUFFER_NAMES
+    for debug_id, name in DEBUG_BUFFER_NAMES.items():
+        d = L.Desc()
+        assert meao_lib.meao_describe_buffer(C.byref(cfg), debug_id, C.byref(d)) == 0
+        aw, ah, slices, fmt = allocs[name]
+        assert (d.width, d.height, d.slices, d.format) == (aw, ah, slices, fmt_of[fmt]), name
 
 
 def test_interpreter_semantics():
