@@ -70,7 +70,11 @@ def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
         if time.perf_counter() - t_begin > budget_s:
             break
     med = float(np.median(times))
+    t0 = time.perf_counter()
+    O.run(depth, s, nthreads=1, result_only=True)           # the same frame on one core (scalar C)
+    single = time.perf_counter() - t0
     return {"value": round(w * h / med / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "single_core_value": round(w * h / single / 1e6, 3),
             "sample": f"{len(times)} timed full {w}x{h} frame(s) of the bench workload after 1 warm-up, "
                       f"median; C oracle (oracle/meao_oracle.c) row-parallel on {cores} threads",
             "seconds_per_frame": round(med, 4)}

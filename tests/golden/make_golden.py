@@ -30,6 +30,8 @@ SMALL = {
 }
 # full-size frames: only 64-bit checksums of the result are stored
 LARGE = {
+    # BASELINE config 1: 1080p radial gradient, single scale (num_levels = 1), CPU plumbing case
+    "s1_1080p_single_scale": (1920, 1080, "S1", 0, synth.DEFAULT_CAMERA, dict(num_levels=1)),
     "s3_1080p": (1920, 1080, "S3", 0, synth.SPONZA_CAMERA, dict(intensity=1.1)),
     "s2_1080p": (1920, 1080, "S2", 0x1234ABCD, synth.DEFAULT_CAMERA, {}),
     "s2_4k": (3840, 2160, "S2", 0x1234ABCD, synth.DEFAULT_CAMERA, {}),
