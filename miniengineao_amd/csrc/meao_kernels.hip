@@ -6,10 +6,11 @@
 //   upsample_kernel    Upsample.main / main_blendout         (UPS:185-233)
 // (DS1/DS2/REN/UPS = Assets/MiniEngineAO/Shaders/{Downsample1,Downsample2,Render,Upsample}.compute)
 //
-// Numerics contract: binary32, RNE, IEEE '/' (hipcc's correctly rounded divide),
-// compiled with -ffp-contract=off; the only fused operations are the explicit mad()/fma2()
-// calls, placed where the HLSL source has a*b+c in one expression.  Bit-exact against
-// oracle/meao_oracle.c.
+// Numerics contract: binary32, RNE, correctly rounded '/' (exact v_rcp_f32-based
+// sequences or hipcc's IEEE expansion), compiled with -ffp-contract=off; the only fused
+// operations are the explicit mad()/fma2() calls, placed where the HLSL source has a*b+c in one
+// expression.  Bit-exact against oracle/meao_oracle.c and against the reference's own source
+// executed by oracle/{csharp,hlsl}_interp.py.
 //
 // MI355X design notes:
 //  * The 4x4 de-interleaved TiledDepth arrays are never materialised on the hot path: a
@@ -19,7 +20,8 @@
 //    samples it with a stride of 4.  Output rows are then contiguous instead of a 4-byte
 //    strided scatter of single R8 texels.
 //  * Each lane renders horizontally adjacent texel pairs so every LDS sample is one
-//    conflict-free ds_read_b64 and the arithmetic is available to the packed-f32 VALU.
+//    conflict-free ds_read_b64; saturate() folds into the clamp modifier of v_mul/v_fma and
+//    clamp(d, p, 1) is one v_med3_f32, so a sample pair costs exactly 8 VALU ops per texel.
 //  * Upsample uses 64x32 hi-res tiles (32x16 low-res + aprons): 1.5x apron amplification
 //    instead of the reference's 2.6x, all 256 lanes busy in both blur phases, 16-byte loads
 //    of the hi-res depth and 4-byte stores of four AO texels.
@@ -50,9 +52,6 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 
 __device__ __forceinline__ float2v splat(float x) { return float2v{x, x}; }
 __device__ __forceinline__ float2v fma2(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ float2v min2(float2v a, float2v b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ float2v max2(float2v a, float2v b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ float2v sat2(float2v x) { return min2(max2(x, splat(0.0f)), splat(1.0f)); }
 
 // f32 -> f16 store conversion (HalfUAV targets).  RTZ: v_cvt_pkrtz_f16_f32 rounds toward zero,
 // so finite overflow lands on 65504; RTNE: v_cvt_f16_f32 in the default rounding mode.
