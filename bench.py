@@ -108,6 +108,8 @@ def main() -> int:
     ap.add_argument("--composite", action="store_true",
                     help="also time the next-tier composite kernel (AO x RGBA16F frame, Blit.shader pass 2); "
                          "reported separately, never part of `value`")
+    ap.add_argument("--ao-format", choices=["r8", "f16"], default=None,
+                    help="override the AO storage of the workload (R8 = reference, F16 = fp16 AO)")
     ap.add_argument("--fast-numerics", action="store_true",
                     help="MEAO_NUMERICS_FAST (raw v_rcp_f32 divides; NOT bit-exact, reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,6 +132,10 @@ def main() -> int:
     mdist.init("nccl", dev)                                      # nccl == RCCL on ROCm
 
     w, h, kind, cam, intensity, ao_format, desc = WORKLOADS[args.workload]
+    if args.ao_format is not None:
+        ao_format = _lib.AO_R8 if args.ao_format == "r8" else _lib.AO_F16
+        desc = desc.replace("fp16 AO storage", "AO").replace("R8 AO", "AO") + \
+            (", R8 storage" if ao_format == _lib.AO_R8 else ", fp16 storage")
     B = max(1, min(args.batch, _lib.MAX_BATCH))
     ao_dtype = torch.uint8 if ao_format == _lib.AO_R8 else torch.int16
 
