@@ -18,7 +18,7 @@ precision -- unverifiable here, noted in DESIGN.md.)
 Supported subset: classes with fields / auto-less properties (get/set bodies) / methods /
 constructors, enums, static members, var and typed locals, const, if/else, for, foreach, switch
 with case/default/break, return, compound assignment, ++/--, casts, ternary, C operator set,
-`new T(...)`, `new T[n]`, array initialisers, indexers `a[i]` and `m[i, j]`, `out` arguments.
+`new T(...)`, `new T[n]`, `new T[n][]`, hex literals, byte/ushort casts, array initialisers, indexers `a[i]` and `m[i, j]`, `out` arguments.
 """
 from __future__ import annotations
 
@@ -30,7 +30,7 @@ import numpy as np
 F = np.float32
 
 TOKEN = re.compile(r"""
-    (?P<num>(?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?[fFdD]?|\d+[eE][+-]?\d+[fFdD]?|\d+[fFuU]?)
+    (?P<num>0[xX][0-9a-fA-F]+|(?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?[fFdD]?|\d+[eE][+-]?\d+[fFdD]?|\d+[fFuU]?)
   | (?P<str>"(?:[^"\\]|\\.)*")
   | (?P<id>[A-Za-z_]\w*)
   | (?P<op>\+\+|--|<<=|>>=|\+=|-=|\*=|/=|%=|\|=|&=|<<|>>|<=|>=|==|!=|&&|\|\||[-+*/%<>=!&|^~?:;,.(){}\[\]])
@@ -38,6 +38,8 @@ TOKEN = re.compile(r"""
 """, re.X)
 
 MODIFIERS = {"public", "private", "protected", "internal", "static", "readonly", "sealed", "const", "override", "virtual"}
+CAST_TYPES = ("int", "uint", "float", "double", "byte", "ushort", "short", "long")
+INT_TYPES = ("int", "uint", "byte", "ushort", "short", "long")
 PRIMITIVES = {"int", "uint", "float", "double", "bool", "string", "void", "var", "object"}
 
 
@@ -391,7 +393,7 @@ class Parser:
             self.next()
             return ("un", tok[1], self.unary())
         # cast: ( type ) unary      -- only primitive casts occur in the subset
-        if tok[1] == "(" and self.peek(1)[1] in ("int", "uint", "float", "double") and self.peek(2)[1] == ")":
+        if tok[1] == "(" and self.peek(1)[1] in CAST_TYPES and self.peek(2)[1] == ")":
             self.next()
             typ = self.next()[1]
             self.next()
@@ -437,6 +439,8 @@ class Parser:
     def primary(self):
         kind, val = self.next()
         if kind == "num":
+            if val[:2] in ("0x", "0X"):
+                return ("lit", int(val, 16))
             if re.search(r"[.eE]", val) or val[-1] in "fFdD":
                 return ("lit", float(val.rstrip("fFdD")) if val[-1] in "dD" else F(float(val.rstrip("fFdD"))))
             return ("lit", int(val.rstrip("uU")))
@@ -448,6 +452,10 @@ class Parser:
                 if self.accept("["):
                     n = self.expr()
                     self.expect("]")
+                    while self.peek()[1] == "[" and self.peek(1)[1] == "]":   # jagged: new T[n][]
+                        self.next()
+                        self.next()
+                        typ += "[]"
                     return ("newarray", typ, n)
                 if self.peek()[1] == "(":
                     return ("new", typ, self.args())
@@ -482,6 +490,10 @@ class EnumValue(int):
 def coerce(value, typ):
     """Implicit conversion to a declared C# type (only the numeric primitives matter here)."""
     if value is None or isinstance(value, (bool, str)):
+        return value
+    if typ.endswith("[]") and isinstance(value, list):
+        if typ[:-2] in ("float", "double"):
+            value[:] = [coerce(v, typ[:-2]) for v in value]
         return value
     if typ == "float" and isinstance(value, (int, float, np.floating)):
         return F(value)
@@ -626,7 +638,11 @@ class Interp:
         if op in ("/", "%"):
             q = abs(a) // abs(b) * (1 if (a < 0) == (b < 0) else -1)
             return q if op == "/" else a - b * q
-        return {"+": a + b, "-": a - b, "*": a * b, "<<": a << b, ">>": a >> b, "|": a | b, "&": a & b, "^": a ^ b}[op]
+        if op == "<<":
+            return a << b
+        if op == ">>":
+            return a >> b
+        return {"+": a + b, "-": a - b, "*": a * b, "|": a | b, "&": a & b, "^": a ^ b}[op]
 
     # ---- evaluation
     def lookup(self, name, env, this):
@@ -712,8 +728,9 @@ class Interp:
             return self.eval(n[2] if self.eval(n[1], env, this) else n[3], env, this)
         if tag == "cast":
             v = self.eval(n[2], env, this)
-            if n[1] in ("int", "uint"):
-                return int(v)
+            if n[1] in INT_TYPES:
+                mask = {"byte": 0xFF, "ushort": 0xFFFF}.get(n[1])
+                return int(v) & mask if mask else int(v)
             return F(v) if n[1] == "float" else float(v)
         if tag == "member":
             return self.member(self.eval(n[1], env, this), n[2])
@@ -725,7 +742,7 @@ class Interp:
             return [self.eval(i, env, this) for i in n[1]]
         if tag == "newarray":
             count = int(self.eval(n[2], env, this))
-            zero = F(0) if n[1] == "float" else (0 if n[1] in ("int", "uint") else None)
+            zero = F(0) if n[1] == "float" else (0 if n[1] in INT_TYPES else None)
             return [zero] * count
         if tag == "new":
             args = [self.eval(a, env, this) for _, a in n[2]]
