@@ -259,7 +259,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             up.lw = p.mip[hi + 1].w; up.lh = p.mip[hi + 1].h;
             up.hw = p.mip[hi].w; up.hh = p.mip[hi].h;
             up.tiles_x = (up.hw + kUpsTileW - 1) / kUpsTileW;
-            up.tiles_y = (up.hh + kUpsTileH - 1) / kUpsTileH;
+            up.tiles_y = (up.hh + ups_tile_h(hi == 0) - 1) / ups_tile_h(hi == 0);
             up.noise_filter_strength = k.noise_filter_strength;
             up.step_size = k.step_size;
             up.blur_tolerance = k.blur_tolerance;

@@ -463,16 +463,23 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
 // ------------------------------------------------------------------------------------------
 // Upsample: depth-aware 5-tap separable blur of the low-res AO + bilateral 2x upsample.
 
-constexpr int kUpsLowW = kUpsTileW / 2, kUpsLowH = kUpsTileH / 2;   // 32 x 16
-constexpr int kUpsRawW = kUpsLowW + 6, kUpsRawH = kUpsLowH + 6;     // 38 x 22 raw taps
-constexpr int kUpsRawPitch = 40;
-constexpr int kUpsBlurW = kUpsLowW + 2, kUpsBlurH = kUpsLowH + 2;   // 34 x 18 blurred texels
-constexpr int kUpsBlurPitch = 36;
-constexpr int kUpsHRun = 4, kUpsHSegs = (kUpsBlurW + kUpsHRun - 1) / kUpsHRun;   // 9 runs of 4 per row
-constexpr int kUpsVRun = 3, kUpsVSegs = kUpsBlurH / kUpsVRun;                    // 6 runs of 3 per column
-static_assert(kUpsVSegs * kUpsVRun == kUpsBlurH, "V-blur runs must tile the column");
-static_assert(kUpsHSegs * kUpsRawH <= kThreads && kUpsVSegs * kUpsBlurW <= kThreads, "one blur run per lane");
-static_assert(kUpsHSegs * kUpsHRun + 4 <= kUpsRawPitch, "H-blur runs may read into the row padding only");
+template <int TILE_H>
+struct UpsTile {
+    static constexpr int kLowW = kUpsTileW / 2, kLowH = TILE_H / 2;   // low-res texels under the tile: 32 x 16|32
+    static constexpr int kRawW = kLowW + 6, kRawH = kLowH + 6;       // raw taps: 38 x 22|38
+    static constexpr int kRawPitch = 40;
+    static constexpr int kBlurW = kLowW + 2, kBlurH = kLowH + 2;     // blurred texels: 34 x 18|34
+    static constexpr int kBlurPitch = 36;
+    static constexpr int kHRun = 4, kHSegs = (kBlurW + kHRun - 1) / kHRun;   // 9 runs of 4 per row
+    static constexpr int kVRun = (kBlurH % 3 == 0) ? 3 : 4;                  // 6 runs of 3 | 9 runs of 4 per column
+    static constexpr int kVSegs = (kBlurH + kVRun - 1) / kVRun;
+    // V-blur runs of the last segment may read (and produce) rows past the window: allocate them
+    static constexpr int kVRows = kVSegs * kVRun;                                 // rows of s_vb
+    static constexpr int kRawRows = (kVRows + 4 > kRawH) ? kVRows + 4 : kRawH;    // rows of s_ao / s_inv / s_hb
+    static_assert(kUpsTileW == 64 && TILE_H % 32 == 0, "bilateral phase: 16 x 16 lanes of 4 x 2 texels per pass");
+    static_assert(kHSegs * kHRun + 4 <= kRawPitch, "H-blur runs may read into the row padding only");
+    static_assert(kVRows * kBlurPitch <= kRawRows * kRawPitch, "s_vb aliases s_ao");
+};
 
 struct BlurConsts { float step_size, blur_tolerance; };
 
@@ -534,15 +541,17 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
 {
     typedef AoTexel<AOFMT> AO;
     typedef typename AO::type ao_t;
-    __shared__ __attribute__((aligned(16))) float s_ao[kUpsRawH * kUpsRawPitch];    // LoResAO1 taps (AOCache1 before blur)
-    __shared__ __attribute__((aligned(16))) float s_inv[kUpsRawH * kUpsRawPitch];   // 1 / LoResDB   (DepthCache)
-    __shared__ __attribute__((aligned(16))) float s_dep[kUpsRawH * kUpsRawPitch];   // LoResDB       (LoDepths gather)
-    __shared__ __attribute__((aligned(16))) float s_hb[kUpsRawH * kUpsBlurPitch];   // after BlurHorizontally (AOCache2)
-    __shared__ __attribute__((aligned(16))) float s_vb[kUpsBlurH * kUpsBlurPitch];  // after BlurVertically   (AOCache1)
+    constexpr int kTileH = ups_tile_h(FINAL);
+    typedef UpsTile<kTileH> T;
+    __shared__ __attribute__((aligned(16))) float s_ao[T::kRawRows * T::kRawPitch];    // LoResAO1 taps (AOCache1 before blur)
+    __shared__ __attribute__((aligned(16))) float s_inv[T::kRawRows * T::kRawPitch];   // 1 / LoResDB   (DepthCache)
+    __shared__ __attribute__((aligned(16))) float s_dep[T::kRawH * T::kRawPitch];      // LoResDB       (LoDepths gather)
+    __shared__ __attribute__((aligned(16))) float s_hb[T::kRawRows * T::kBlurPitch];   // after BlurHorizontally (AOCache2)
+    float *const s_vb = s_ao;   // after BlurVertically (AOCache1): the raw taps are dead once H-blurred
 
     const int frame = blockIdx.z;
     const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
-    const int HX0 = tile_x * kUpsTileW, HY0 = tile_y * kUpsTileH;
+    const int HX0 = tile_x * kUpsTileW, HY0 = tile_y * kTileH;
     const int LX0 = HX0 >> 1, LY0 = HY0 >> 1;
     const int lw = a.lw, lh = a.lh, hw = a.hw, hh = a.hh;
     const float *__restrict__ lo_depth = frame_ptr(a.lo_depth, a.frame_stride, frame);
@@ -550,13 +559,13 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
-    // [LX0-3, LX0+34] x [LY0-3, LY0+18], clamp addressing per texel.
+    // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
     const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
     if (interior_x) {
         // no horizontal clamping inside this tile: one aligned 16-byte depth load (+ 4 AO texels)
         // per lane covers the 40-texel row segment [LX0-4, LX0+35]
-        if (threadIdx.x < 10 * kUpsRawH) {
-            const int r = threadIdx.x / 10, k = threadIdx.x % 10;
+        for (int i = threadIdx.x; i < 10 * T::kRawH; i += kThreads) {
+            const int r = i / 10, k = i % 10;
             const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
             const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
             const float4v d4 = *reinterpret_cast<const float4v *>(lo_depth + idx);
@@ -566,138 +575,145 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * k + e - 1;
-                if (c >= 0 && c < kUpsRawW) {
-                    s_dep[r * kUpsRawPitch + c] = dv[e];
-                    s_inv[r * kUpsRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
-                    s_ao[r * kUpsRawPitch + c] = av[e];
+                if (c >= 0 && c < T::kRawW) {
+                    s_dep[r * T::kRawPitch + c] = dv[e];
+                    s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
+                    s_ao[r * T::kRawPitch + c] = av[e];
                 }
             }
         }
     } else {
-        for (int i = threadIdx.x; i < kUpsRawW * kUpsRawH; i += kThreads) {
-            const int r = i / kUpsRawW, c = i % kUpsRawW;
+        for (int i = threadIdx.x; i < T::kRawW * T::kRawH; i += kThreads) {
+            const int r = i / T::kRawW, c = i % T::kRawW;
             const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
             const size_t idx = static_cast<size_t>(cy) * lw + cx;
             const float d = lo_depth[idx];
-            s_dep[r * kUpsRawPitch + c] = d;
-            s_inv[r * kUpsRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
-            s_ao[r * kUpsRawPitch + c] = AO::decode(lo_ao[idx]);
+            s_dep[r * T::kRawPitch + c] = d;
+            s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
+            s_ao[r * T::kRawPitch + c] = AO::decode(lo_ao[idx]);
         }
     }
     __syncthreads();
 
-    // ---- BlurHorizontally: one run of 4 outputs per lane; output (r, c) is centred on raw
-    // column c+2.  (Columns 34, 35 of the last run are scratch: they read the row padding.)
-    if (threadIdx.x < kUpsHSegs * kUpsRawH) {
-        const int r = threadIdx.x / kUpsHSegs, c0 = (threadIdx.x % kUpsHSegs) * kUpsHRun;
-        float av[kUpsHRun + 4], zv[kUpsHRun + 4], o[kUpsHRun];
-        const float4v a0 = *reinterpret_cast<const float4v *>(&s_ao[r * kUpsRawPitch + c0]);
-        const float4v a1 = *reinterpret_cast<const float4v *>(&s_ao[r * kUpsRawPitch + c0 + 4]);
-        const float4v z0 = *reinterpret_cast<const float4v *>(&s_inv[r * kUpsRawPitch + c0]);
-        const float4v z1 = *reinterpret_cast<const float4v *>(&s_inv[r * kUpsRawPitch + c0 + 4]);
+    // ---- BlurHorizontally: runs of 4 outputs; output (r, c) is centred on raw column c+2.
+    // (Columns 34, 35 of the last run are scratch: they read the row padding.)
+    for (int i = threadIdx.x; i < T::kHSegs * T::kRawH; i += kThreads) {
+        const int r = i / T::kHSegs, c0 = (i % T::kHSegs) * T::kHRun;
+        float av[T::kHRun + 4], zv[T::kHRun + 4], o[T::kHRun];
+        const float4v a0 = *reinterpret_cast<const float4v *>(&s_ao[r * T::kRawPitch + c0]);
+        const float4v a1 = *reinterpret_cast<const float4v *>(&s_ao[r * T::kRawPitch + c0 + 4]);
+        const float4v z0 = *reinterpret_cast<const float4v *>(&s_inv[r * T::kRawPitch + c0]);
+        const float4v z1 = *reinterpret_cast<const float4v *>(&s_inv[r * T::kRawPitch + c0 + 4]);
         av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
         zv[0] = z0.x; zv[1] = z0.y; zv[2] = z0.z; zv[3] = z0.w; zv[4] = z1.x; zv[5] = z1.y; zv[6] = z1.z; zv[7] = z1.w;
-        blur_run<kUpsHRun>(bk, av, zv, o);
-        *reinterpret_cast<float4v *>(&s_hb[r * kUpsBlurPitch + c0]) = float4v{o[0], o[1], o[2], o[3]};
+        blur_run<T::kHRun>(bk, av, zv, o);
+        *reinterpret_cast<float4v *>(&s_hb[r * T::kBlurPitch + c0]) = float4v{o[0], o[1], o[2], o[3]};
     }
     __syncthreads();
 
-    // ---- BlurVertically: one run of 3 outputs per lane; output (r, c) is centred on H-blurred
-    // row r+2; depths come from the same virtual column (DepthCache[... + 2], UPS:141-146).
-    if (threadIdx.x < kUpsVSegs * kUpsBlurW) {
-        const int c = threadIdx.x % kUpsBlurW, r0 = (threadIdx.x / kUpsBlurW) * kUpsVRun;
-        float av[kUpsVRun + 4], zv[kUpsVRun + 4], o[kUpsVRun];
+    // ---- BlurVertically: runs of T::kVRun outputs; output (r, c) is centred on H-blurred row
+    // r+2; depths come from the same virtual column (DepthCache[... + 2], UPS:141-146).  Rows
+    // >= T::kBlurH of the last run are scratch: they read rows past the window (never used).
+    // s_vb aliases s_ao, which nothing reads after the barrier above.
+    for (int i = threadIdx.x; i < T::kVSegs * T::kBlurW; i += kThreads) {
+        const int c = i % T::kBlurW, r0 = (i / T::kBlurW) * T::kVRun;
+        float av[T::kVRun + 4], zv[T::kVRun + 4], o[T::kVRun];
 #pragma unroll
-        for (int t = 0; t < kUpsVRun + 4; ++t) {
-            av[t] = s_hb[(r0 + t) * kUpsBlurPitch + c];
-            zv[t] = s_inv[(r0 + t) * kUpsRawPitch + c + 2];
+        for (int t = 0; t < T::kVRun + 4; ++t) {
+            av[t] = s_hb[(r0 + t) * T::kBlurPitch + c];
+            zv[t] = s_inv[(r0 + t) * T::kRawPitch + c + 2];
         }
-        blur_run<kUpsVRun>(bk, av, zv, o);
+        blur_run<T::kVRun>(bk, av, zv, o);
 #pragma unroll
-        for (int n = 0; n < kUpsVRun; ++n) s_vb[(r0 + n) * kUpsBlurPitch + c] = o[n];
+        for (int n = 0; n < T::kVRun; ++n) s_vb[(r0 + n) * T::kBlurPitch + c] = o[n];
     }
     __syncthreads();
 
-    // ---- bilateral upsample: lane = 4 x 2 hi-res texels
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int hx0 = HX0 + 4 * tx, hy0 = HY0 + 2 * ty;
-    if (hx0 >= hw || hy0 >= hh) return;
-
-    float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-        const float2v v0 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * kUpsBlurPitch + 2 * tx]);
-        const float2v v1 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * kUpsBlurPitch + 2 * tx + 2]);
-        const float2v d0 = *reinterpret_cast<const float2v *>(&s_dep[(ty + rr + 2) * kUpsRawPitch + 2 * tx + 2]);
-        const float2v d1 = *reinterpret_cast<const float2v *>(&s_dep[(ty + rr + 2) * kUpsRawPitch + 2 * tx + 4]);
-        vb[rr][0] = v0.x; vb[rr][1] = v0.y; vb[rr][2] = v1.x; vb[rr][3] = v1.y;
-        dl[rr][0] = d0.x; dl[rr][1] = d0.y; dl[rr][2] = d1.x; dl[rr][3] = d1.y;
-    }
-
+    // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
                                    : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
     const bool vec_ok = (hw & 3) == 0;
     // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
     constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
+    const int tx = threadIdx.x & 15;
+    const int hx0 = HX0 + 4 * tx;
+    if (hx0 >= hw) return;
+#pragma unroll 1
+    for (int pass = 0; pass < kTileH / 32; ++pass) {
+        const int ty = (threadIdx.x >> 4) + 16 * pass;
+        const int hy0 = HY0 + 2 * ty;
+        if (hy0 >= hh) return;
+
+        float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const float2v v0 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx]);
+            const float2v v1 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx + 2]);
+            const float2v d0 = *reinterpret_cast<const float2v *>(&s_dep[(ty + rr + 2) * T::kRawPitch + 2 * tx + 2]);
+            const float2v d1 = *reinterpret_cast<const float2v *>(&s_dep[(ty + rr + 2) * T::kRawPitch + 2 * tx + 4]);
+            vb[rr][0] = v0.x; vb[rr][1] = v0.y; vb[rr][2] = v1.x; vb[rr][3] = v1.y;
+            dl[rr][0] = d0.x; dl[rr][1] = d0.y; dl[rr][2] = d1.x; dl[rr][3] = d1.y;
+        }
 
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int hy = hy0 + f;
-        if (hy >= hh) break;
-        const size_t hrow = static_cast<size_t>(hy) * hw + hx0;
-        float hd[4], ha[4] = {1.0f, 1.0f, 1.0f, 1.0f};                  // HiSSAOs = 1 in "main" (UPS:222)
-        if constexpr (FINAL) {
-            const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
-            if (vec_ok) {
-                const ushort4v q = *reinterpret_cast<const ushort4v *>(p);
-                hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
-                hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
-            } else {
+        for (int f = 0; f < 2; ++f) {
+            const int hy = hy0 + f;
+            if (hy >= hh) break;
+            const size_t hrow = static_cast<size_t>(hy) * hw + hx0;
+            float hd[4], ha[4] = {1.0f, 1.0f, 1.0f, 1.0f};                  // HiSSAOs = 1 in "main" (UPS:222)
+            if constexpr (FINAL) {
+                const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
+                if (vec_ok) {
+                    const ushort4v q = *reinterpret_cast<const ushort4v *>(p);
+                    hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
+                    hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hd[e] = (hx0 + e < hw) ? f16_bits_to_f32(p[e]) : 1.0f;
-            }
-        } else {
-            const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
-            const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
-            if (vec_ok) {
-                const float4v d4 = *reinterpret_cast<const float4v *>(p);
-                hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
-                const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(q);
-                ha[0] = AO::decode(a4.x); ha[1] = AO::decode(a4.y);
-                ha[2] = AO::decode(a4.z); ha[3] = AO::decode(a4.w);
+                    for (int e = 0; e < 4; ++e) hd[e] = (hx0 + e < hw) ? f16_bits_to_f32(p[e]) : 1.0f;
+                }
             } else {
+                const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
+                const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
+                if (vec_ok) {
+                    const float4v d4 = *reinterpret_cast<const float4v *>(p);
+                    hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
+                    const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(q);
+                    ha[0] = AO::decode(a4.x); ha[1] = AO::decode(a4.y);
+                    ha[2] = AO::decode(a4.z); ha[3] = AO::decode(a4.w);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    hd[e] = (hx0 + e < hw) ? p[e] : 1.0f;
-                    ha[e] = (hx0 + e < hw) ? AO::decode(q[e]) : 1.0f;
+                    for (int e = 0; e < 4; ++e) {
+                        hd[e] = (hx0 + e < hw) ? p[e] : 1.0f;
+                        ha[e] = (hx0 + e < hw) ? AO::decode(q[e]) : 1.0f;
+                    }
                 }
             }
-        }
-        ao_t res[4];
+            ao_t res[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // hi texel (4tx+e, 2ty+f) is written by dispatch thread D = ((hx+1)>>1, (hy+1)>>1)
-            // through Gather component comp (UPS:229-232); its taps are rotated by comp.
-            const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // D in vb/dl coordinates
-            const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
-            const int g0 = comp & 3, g1 = (comp + 1) & 3, g2 = (comp + 2) & 3, g3 = (comp + 3) & 3;
-            const float v = bilateral_upsample<DIV>(
-                hd[e], ha[e],
-                dl[rr + gy[g0]][cc + gx[g0]], dl[rr + gy[g1]][cc + gx[g1]],
-                dl[rr + gy[g2]][cc + gx[g2]], dl[rr + gy[g3]][cc + gx[g3]],
-                vb[rr + gy[g0]][cc + gx[g0]], vb[rr + gy[g1]][cc + gx[g1]],
-                vb[rr + gy[g2]][cc + gx[g2]], vb[rr + gy[g3]][cc + gx[g3]],
-                a.upsample_tolerance, a.noise_filter_strength);
-            res[e] = AO::template encode<RTNE>(v);
-        }
-        ao_t *o = dst + hrow;
-        if (vec_ok) {
-            typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
-            *reinterpret_cast<typename AO::type4 *>(o) = r4;
-        } else {
+            for (int e = 0; e < 4; ++e) {
+                // hi texel (4tx+e, 2ty+f) is written by dispatch thread D = ((hx+1)>>1, (hy+1)>>1)
+                // through Gather component comp (UPS:229-232); its taps are rotated by comp.
+                const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // D in vb/dl coordinates
+                const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+                const int g0 = comp & 3, g1 = (comp + 1) & 3, g2 = (comp + 2) & 3, g3 = (comp + 3) & 3;
+                const float v = bilateral_upsample<DIV>(
+                    hd[e], ha[e],
+                    dl[rr + gy[g0]][cc + gx[g0]], dl[rr + gy[g1]][cc + gx[g1]],
+                    dl[rr + gy[g2]][cc + gx[g2]], dl[rr + gy[g3]][cc + gx[g3]],
+                    vb[rr + gy[g0]][cc + gx[g0]], vb[rr + gy[g1]][cc + gx[g1]],
+                    vb[rr + gy[g2]][cc + gx[g2]], vb[rr + gy[g3]][cc + gx[g3]],
+                    a.upsample_tolerance, a.noise_filter_strength);
+                res[e] = AO::template encode<RTNE>(v);
+            }
+            ao_t *o = dst + hrow;
+            if (vec_ok) {
+                typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
+                *reinterpret_cast<typename AO::type4 *>(o) = r4;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (hx0 + e < hw) o[e] = res[e];
+                for (int e = 0; e < 4; ++e)
+                    if (hx0 + e < hw) o[e] = res[e];
+            }
         }
     }
 }

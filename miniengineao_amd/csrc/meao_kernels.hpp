@@ -53,7 +53,11 @@ struct RenderArgs {
 
 // ---------------------------------------------------------------------------------------
 // Upsample (Upsample.main / main_blendout)
-constexpr int kUpsTileW = 64, kUpsTileH = 32;   // hi-res texels per workgroup
+// Hi-res texels per workgroup.  The full-resolution pass (L1 -> L0, "main") uses 64 x 64: smaller
+// blur aprons and better lane use in the blur phases; the three blend passes have few tiles per
+// frame and run faster with 64 x 32 (measured on one MI355X, see profiles/README.md).
+constexpr int kUpsTileW = 64;
+constexpr int ups_tile_h(bool final_pass) { return final_pass ? 64 : 32; }
 
 struct UpsampleArgs {
     const float *lo_depth;     // LoResDB  f32
