@@ -24,9 +24,12 @@ HEADERS = ["meao_plan.hpp", "meao_kernels.hpp"]
 # -ffp-contract=off: the only fused multiply-adds are the explicit mad()/fma2() calls, which
 # is what makes the kernels bit-exact against the oracle.  Correctly rounded '/' and sqrt are
 # hipcc's default; the flag is spelled out because parity depends on it.
+# -fno-slp-vectorize: the SLP vectorizer pairs scalar f32 ops into v_pk_* at the price of v_mov
+# shuffles; on MI355X v_pk_* issues in ~4.7 cycles vs 2 x 3.0, so the shuffles eat the gain
+# (A/B on one box: upsample 1-2 % faster without it).  Explicit float2 code still uses v_pk_*.
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize",
     "-fvisibility=hidden", "-Wall", "-Wextra", "-Wno-unused-parameter",
 ]
 
