@@ -155,11 +155,10 @@ static void dispatch_downsample2(const tex_t *ds4x, tex_t *ds8x, tex_t *ds8x_atl
 }
 
 /* ------------------------------------------------------------------------ */
-/* Render.main_interleaved (REN:112-177): TILE_DIM 16, 8x8 threads           */
+/* Render.main_interleaved (REN:112-177): TILE_DIM 16, 8x8 threads;           */
+/* Render.main (WIDE_SAMPLING, REN:22,27-29,46-50): TILE_DIM 32, 16x16 threads */
 
-enum { REN_TILE = 16 };
-
-typedef struct { const float *lds; const meao_oracle_render_consts *cb; } ren_thread;
+typedef struct { const float *lds; const meao_oracle_render_consts *cb; int tile_dim, wide; } ren_thread;
 
 static float ren_pair(const ren_thread *t, float front_depth, float inv_range, unsigned base, int offset)
 {
@@ -174,9 +173,11 @@ static float ren_pair(const ren_thread *t, float front_depth, float inv_range, u
 static float ren_samples(const ren_thread *t, unsigned centre, unsigned x, unsigned y,
                          float inv_depth, float inv_thickness)
 {
+    if (t->wide) { x <<= 1; y <<= 1; }      /* REN:79-82 */
     float inv_range = inv_thickness * inv_depth;
     float front_depth = inv_thickness - 0.5f;
     int X = (int)x, Y = (int)y;
+    const int REN_TILE = t->tile_dim;
     if (y == 0)
         return 0.5f * (ren_pair(t, front_depth, inv_range, centre, X) +
                        ren_pair(t, front_depth, inv_range, centre, X * REN_TILE));
@@ -189,39 +190,49 @@ static float ren_samples(const ren_thread *t, unsigned centre, unsigned x, unsig
                     ren_pair(t, front_depth, inv_range, centre, X * REN_TILE - Y));
 }
 
+/* wide = 0: main_interleaved on a 16-slice atlas; wide = 1: main on a 2D texture.
+ * exhaustive: the SAMPLE_EXHAUSTIVELY term list (REN:146-157) instead of the checker set. */
 static void dispatch_render(const tex_t *depth_tex, tex_t *occlusion,
-                            const meao_oracle_render_consts *cb,
+                            const meao_oracle_render_consts *cb, int wide, int exhaustive,
                             int groups_x, int groups_y, int groups_z)
 {
-    /* (weight/thickness table slot, x, y) in accumulation order, REN:162-168 */
-    static const unsigned plan[7][3] = {
+    /* (weight/thickness table slot, x, y) in accumulation order, REN:162-168 / REN:146-157 */
+    static const unsigned checker[7][3] = {
         { 1, 2, 0 }, { 3, 4, 0 }, { 4, 1, 1 }, { 8, 2, 2 }, { 11, 3, 3 }, { 6, 1, 3 }, { 10, 2, 4 } };
+    static const unsigned all68[12][3] = {
+        { 0, 1, 0 }, { 1, 2, 0 }, { 2, 3, 0 }, { 3, 4, 0 }, { 4, 1, 1 }, { 8, 2, 2 }, { 11, 3, 3 },
+        { 5, 1, 2 }, { 6, 1, 3 }, { 7, 1, 4 }, { 9, 2, 3 }, { 10, 2, 4 } };
+    const unsigned (*plan)[3] = exhaustive ? all68 : checker;
+    const int terms = exhaustive ? 12 : 7;
+    const int tile = wide ? 32 : 16, tc = wide ? 16 : 8;      /* TILE_DIM, THREAD_COUNT_X/Y */
+    const int apron = wide ? 7 : 3, centre_off = wide ? 8 : 4;
     for (int gz = 0; gz < groups_z; gz++)
     for (int gy = 0; gy < groups_y; gy++)
     for (int gx = 0; gx < groups_x; gx++) {
-        float samples[REN_TILE * REN_TILE];
-        for (int gi = 0; gi < 64; gi++) {
-            int tx = gi & 7, ty = gi >> 3;
-            int dx = gx * 8 + tx, dy = gy * 8 + ty;
-            float u = (float)(dx + tx - 3) * cb->inv_slice_dim[0];
-            float v = (float)(dy + ty - 3) * cb->inv_slice_dim[1];
+        float samples[32 * 32];
+        for (int gi = 0; gi < tc * tc; gi++) {
+            int tx = gi % tc, ty = gi / tc;
+            int dx = gx * tc + tx, dy = gy * tc + ty;
+            float u = (float)(dx + tx - apron) * cb->inv_slice_dim[0];
+            float v = (float)(dy + ty - apron) * cb->inv_slice_dim[1];
             f4 g = tex_gather(depth_tex, u, v, gz);
-            int dst = tx * 2 + ty * 2 * REN_TILE;
+            int dst = tx * 2 + ty * 2 * tile;
             samples[dst] = g.w; samples[dst + 1] = g.z;
-            samples[dst + REN_TILE] = g.x; samples[dst + REN_TILE + 1] = g.y;
+            samples[dst + tile] = g.x; samples[dst + tile + 1] = g.y;
         }
         /* barrier */
-        for (int gi = 0; gi < 64; gi++) {
-            int tx = gi & 7, ty = gi >> 3;
-            ren_thread th = { samples, cb };
-            unsigned centre = (unsigned)(tx + ty * REN_TILE + 4 * REN_TILE + 4);
+        for (int gi = 0; gi < tc * tc; gi++) {
+            int tx = gi % tc, ty = gi / tc;
+            ren_thread th = { samples, cb, tile, wide };
+            unsigned centre = (unsigned)(tx + ty * tile + centre_off * tile + centre_off);
             float inv_depth = 1.0f / samples[centre];
             float ao = 0.0f;
-            for (int n = 0; n < 7; n++)
+            for (int n = 0; n < terms; n++)
                 ao = fmaf(cb->sample_weight[plan[n][0]],
                           ren_samples(&th, centre, plan[n][1], plan[n][2], inv_depth,
                                       cb->inv_thickness[plan[n][0]]), ao);
-            int ox = ((gx * 8 + tx) << 2) | (gz & 3), oy = ((gy * 8 + ty) << 2) | (gz >> 2);
+            int ox = gx * tc + tx, oy = gy * tc + ty;                        /* REN:174 */
+            if (!wide) { ox = (ox << 2) | (gz & 3); oy = (oy << 2) | (gz >> 2); }   /* REN:172 */
             tex_store(occlusion, ox, oy, 0, fmaf(cb->intensity, ao - 1.0f, 1.0f));
         }
     }
@@ -281,7 +292,8 @@ static float ups_bilateral(const meao_oracle_upsample_consts *cb, float hi_depth
 }
 
 static void dispatch_upsample(const tex_t *lo_db, const tex_t *hi_db, const tex_t *lo_ao,
-                              const tex_t *hi_ao /* NULL: kernel "main" */, tex_t *result,
+                              const tex_t *lo_ao2 /* non-NULL: main_premin* */,
+                              const tex_t *hi_ao /* NULL: kernel "main" / "main_premin" */, tex_t *result,
                               const meao_oracle_upsample_consts *cb, int groups_x, int groups_y)
 {
     ups_group *g = (ups_group *)calloc(1, sizeof *g);
@@ -299,6 +311,10 @@ static void dispatch_upsample(const tex_t *lo_db, const tex_t *hi_db, const tex_
             float v = (float)(dy + ty - 2) * cb->inv_low_res[1];
             int idx = (tx << 1) | (ty << 5);
             f4 ao = tex_gather(lo_ao, u, v, 0);
+            if (lo_ao2) {                                /* COMBINE_LOWER_RESOLUTIONS, UPS:58-60 */
+                f4 b = tex_gather(lo_ao2, u, v, 0);
+                ao.x = fminf(ao.x, b.x); ao.y = fminf(ao.y, b.y); ao.z = fminf(ao.z, b.z); ao.w = fminf(ao.w, b.w);
+            }
             g->ao_cache1[idx] = ao.w; g->ao_cache1[idx + 1] = ao.z;
             g->ao_cache1[idx + 16] = ao.x; g->ao_cache1[idx + 17] = ao.y;
             f4 dp = tex_gather(lo_db, u, v, 0);
@@ -364,13 +380,17 @@ int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const void *depth_in, meao
     if (!depth) return -3;
     for (size_t i = 0; i < (size_t)w[0] * h[0]; i++) depth[i] = meao_oracle_decode_depth(depth_in, i, d->depth_format);
     tex_t depth_tex = { w[0], h[0], 1, FMT_F32, 0, (void *)depth };
-    tex_t linear, low[4], tiled[4], occ[4], comb[3], result;
+    tex_t linear, low[4], tiled[4], occ[4], comb[3], result, hq[4];
+    memset(hq, 0, sizeof hq);
+    if (d->hq_levels < 0 || d->hq_levels > d->num_levels) return -1;
     MK(linear, out->linear_depth, w[0], h[0], 1, FMT_F16);
     for (int k = 1; k <= 4; k++) {
         MK(low[k - 1], out->low_depth[k - 1], w[k], h[k], 1, FMT_F32);
         MK(tiled[k - 1], out->tiled_depth[k - 1], w[k + 2], h[k + 2], 16, FMT_F16);
         MK(occ[k - 1], out->occlusion[k - 1], w[k], h[k], 1, aofmt);
         if (k <= 3) MK(comb[k - 1], out->combined[k - 1], w[k], h[k], 1, aofmt);
+        if (k > d->num_levels - d->hq_levels && k <= d->num_levels)
+            MK(hq[k - 1], out->occlusion_hq[k - 1], w[k], h[k], 1, aofmt);
     }
     MK(result, out->result, w[0], h[0], 1, aofmt);
 #undef MK
@@ -385,7 +405,13 @@ int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const void *depth_in, meao
         meao_oracle_render_consts cb;
         meao_oracle_render_constants(d, k, &cb);
         const tex_t *src = &tiled[k - 1];                /* AO.cs:744-746, numthreads 8,8,1 */
-        dispatch_render(src, &occ[k - 1], &cb, (src->w + 7) / 8, (src->h + 7) / 8, src->slices);
+        const int all = d->sample_set == MEAO_ORACLE_SAMPLES_EXHAUSTIVE;
+        dispatch_render(src, &occ[k - 1], &cb, 0, all, (src->w + 7) / 8, (src->h + 7) / 8, src->slices);
+        if (hq[k - 1].data) {                            /* Render.main on LowDepth<k>, numthreads 16,16,1 */
+            meao_oracle_render_constants_hq(d, k, &cb);
+            src = &low[k - 1];
+            dispatch_render(src, &hq[k - 1], &cb, 1, all, (src->w + 15) / 16, (src->h + 15) / 16, 1);
+        }
     }
 
     const tex_t *lo_ao = &occ[d->num_levels - 1];
@@ -395,7 +421,7 @@ int32_t meao_hlsl_emul_run(const meao_oracle_desc *d, const void *depth_in, meao
         const tex_t *hi_db = hi ? &low[hi - 1] : &linear;
         const tex_t *hi_ao = hi ? &occ[hi - 1] : NULL;
         tex_t *dst = hi ? &comb[hi - 1] : &result;
-        dispatch_upsample(&low[hi], hi_db, lo_ao, hi_ao, dst, &cb,
+        dispatch_upsample(&low[hi], hi_db, lo_ao, hq[hi].data ? &hq[hi] : NULL, hi_ao, dst, &cb,
                           (hi_db->w + 17) / 16, (hi_db->h + 17) / 16);   /* AO.cs:782-783 */
         lo_ao = dst;
     }

@@ -165,26 +165,31 @@ void meao_oracle_sample_thickness(float t[12])
     t[11] = unity_sqrt(1.0f - c - c);
 }
 
-void meao_oracle_render_constants(const meao_oracle_desc *d, int32_t level,
-                                  meao_oracle_render_consts *out)
+static void render_constants(const meao_oracle_desc *d, int32_t source_level, int tiled,
+                             meao_oracle_render_consts *out)
 {
     int32_t sw, sh;
-    meao_oracle_level_dims(d->width, d->height, level + 2, &sw, &sh);
+    meao_oracle_level_dims(d->width, d->height, source_level, &sw, &sh);
     float thick[12];
     meao_oracle_sample_thickness(thick);
 
     float tan_half_fov_h = 1.0f / d->proj00;                       /* AO.cs:572 */
     float thickness_multiplier = 2.0f * tan_half_fov_h;            /* AO.cs:678 */
     thickness_multiplier = thickness_multiplier * 10.0f;
-    thickness_multiplier = thickness_multiplier / (float)sw;       /* tiled source: no extra x2 */
+    thickness_multiplier = thickness_multiplier / (float)sw;
+    if (!tiled) thickness_multiplier = thickness_multiplier * 2.0f;          /* AO.cs:679 */
+    if (d->single_pass_stereo) thickness_multiplier = thickness_multiplier * 2.0f;   /* AO.cs:680 */
     float inverse_range_factor = 1.0f / thickness_multiplier;      /* AO.cs:683 */
     for (int i = 0; i < 12; i++)
         out->inv_thickness[i] = inverse_range_factor / thick[i];   /* AO.cs:688 */
 
     static const float count[12] = { 4, 4, 4, 4, 4, 8, 8, 8, 4, 8, 8, 4 };  /* AO.cs:696-707 */
     for (int i = 0; i < 12; i++) out->sample_weight[i] = count[i] * thick[i];
-    out->sample_weight[0] = 0; out->sample_weight[2] = 0; out->sample_weight[5] = 0;
-    out->sample_weight[7] = 0; out->sample_weight[9] = 0;          /* AO.cs:711-715 */
+    if (d->sample_set != MEAO_ORACLE_SAMPLES_EXHAUSTIVE) {         /* AO.cs:709-715 ("FIXME: should we
+                                                                    * support SAMPLE_EXHAUSTIVELY mode?") */
+        out->sample_weight[0] = 0; out->sample_weight[2] = 0; out->sample_weight[5] = 0;
+        out->sample_weight[7] = 0; out->sample_weight[9] = 0;
+    }
     float total = 0.0f;
     for (int i = 0; i < 12; i++) total += out->sample_weight[i];   /* AO.cs:718-721 */
     for (int i = 0; i < 12; i++) out->sample_weight[i] /= total;   /* AO.cs:723-724 */
@@ -193,6 +198,16 @@ void meao_oracle_render_constants(const meao_oracle_desc *d, int32_t level,
     out->inv_slice_dim[1] = 1.0f / (float)sh;
     out->reject_fadeoff = -1.0f / d->thickness_modifier;           /* AO.cs:733 */
     out->intensity = d->intensity;                                 /* AO.cs:734 */
+}
+
+void meao_oracle_render_constants(const meao_oracle_desc *d, int32_t level, meao_oracle_render_consts *out)
+{
+    render_constants(d, level + 2, 1, out);     /* source = TiledDepth<level>, dims of mip level+2 */
+}
+
+void meao_oracle_render_constants_hq(const meao_oracle_desc *d, int32_t level, meao_oracle_render_consts *out)
+{
+    render_constants(d, level, 0, out);         /* source = LowDepth<level> */
 }
 
 void meao_oracle_upsample_constants(const meao_oracle_desc *d, int32_t low_level,
@@ -308,14 +323,17 @@ static void ds_tile_rows(void *arg, int y0, int y1)
 
 typedef struct {
     const meao_oracle_desc *d; meao_oracle_render_consts k;
-    const uint16_t *tiled; int sw, sh;      /* atlas slice dims */
+    const uint16_t *tiled; int sw, sh;      /* atlas slice dims (interleaved) / source dims (wide) */
+    const float *flat;                      /* non-NULL: Render.main on a non-tiled f32 source    */
     void *out; int ow, oh;                  /* Occlusion<level> dims */
 } ren_ctx;
 
-/* slice texel with per-slice clamp addressing (REN:118-131 Gather + clamp) */
+/* slice texel with per-slice clamp addressing (REN:118-131 Gather + clamp); Render.main
+ * (REN:116,121) gathers from the 2D source with the same clamp */
 static inline float ren_tap(const ren_ctx *c, int s, int x, int y)
 {
     x = clampi(x, 0, c->sw - 1); y = clampi(y, 0, c->sh - 1);
+    if (c->flat) return c->flat[(size_t)y * c->sw + x];
     return meao_oracle_f16_to_f32(c->tiled[((size_t)s * c->sh + y) * c->sw + x]);
 }
 
@@ -336,6 +354,7 @@ static inline float test_sample_pair(const ren_ctx *c, int s, int cx, int cy, in
 static inline float test_samples(const ren_ctx *c, int s, int cx, int cy, int x, int y,
                                  float inv_depth, float inv_thickness)
 {
+    if (c->flat) { x <<= 1; y <<= 1; }          /* WIDE_SAMPLING, REN:79-82 */
     float inv_range = inv_thickness * inv_depth;
     float front = inv_thickness - 0.5f;
     if (y == 0) {
@@ -359,16 +378,24 @@ static void ren_rows(void *arg, int y0, int y1)
 {
     ren_ctx *c = (ren_ctx *)arg;
     /* sample order and table indices of the 36-sample checker set, REN:162-168 */
-    static const int sx[7] = { 2, 4, 1, 2, 3, 1, 2 };
-    static const int sy[7] = { 0, 0, 1, 2, 3, 3, 4 };
-    static const int ti[7] = { 1, 3, 4, 8, 11, 6, 10 };
+    static const int sx36[7] = { 2, 4, 1, 2, 3, 1, 2 };
+    static const int sy36[7] = { 0, 0, 1, 2, 3, 3, 4 };
+    static const int ti36[7] = { 1, 3, 4, 8, 11, 6, 10 };
+    /* SAMPLE_EXHAUSTIVELY, 68 samples, REN:146-157 */
+    static const int sx68[12] = { 1, 2, 3, 4, 1, 2, 3, 1, 1, 1, 2, 2 };
+    static const int sy68[12] = { 0, 0, 0, 0, 1, 2, 3, 2, 3, 4, 3, 4 };
+    static const int ti68[12] = { 0, 1, 2, 3, 4, 8, 11, 5, 6, 7, 9, 10 };
+    const int all = c->d->sample_set == MEAO_ORACLE_SAMPLES_EXHAUSTIVE;
+    const int *sx = all ? sx68 : sx36, *sy = all ? sy68 : sy36, *ti = all ? ti68 : ti36;
+    const int terms = all ? 12 : 7;
     for (int Y = y0; Y < y1; Y++) {
         for (int X = 0; X < c->ow; X++) {
-            /* OutPixel = DTid.xy<<2 | (z&3, z>>2)  (REN:172)  inverted */
+            /* OutPixel = DTid.xy<<2 | (z&3, z>>2)  (REN:172)  inverted; Render.main: OutPixel = DTid.xy */
             int s = (X & 3) | ((Y & 3) << 2), cx = X >> 2, cy = Y >> 2;
+            if (c->flat) { s = 0; cx = X; cy = Y; }
             float inv_depth = 1.0f / ren_tap(c, s, cx, cy);        /* REN:140 */
             float ao = 0.0f;
-            for (int n = 0; n < 7; n++)
+            for (int n = 0; n < terms; n++)
                 ao = mad(c->k.sample_weight[ti[n]],
                          test_samples(c, s, cx, cy, sx[n], sy[n], inv_depth, c->k.inv_thickness[ti[n]]),
                          ao);
@@ -385,6 +412,7 @@ typedef struct {
     const meao_oracle_desc *d; meao_oracle_upsample_consts k;
     int lw, lh, hw, hh;
     const float *low_depth; const void *low_ao;
+    const void *low_ao2;                     /* LoResAO2 of main_premin* (UPS:23,25), or NULL */
     const float *hi_depth32; const uint16_t *hi_depth16; const void *hi_ao;   /* hi_ao NULL: main */
     void *out;
     float *inv_depth;  /* [lh][lw]                 1/LoResDB           UPS:67 */
@@ -427,6 +455,8 @@ static void ups_prefetch_rows(void *arg, int y0, int y1)
         for (int x = 0; x < c->lw; x++) {
             size_t i = (size_t)y * c->lw + x;
             c->ao[i] = ao_load(c->low_ao, i, c->d->ao_format);
+            if (c->low_ao2)                                        /* COMBINE_LOWER_RESOLUTIONS UPS:58-60 */
+                c->ao[i] = fminf(c->ao[i], ao_load(c->low_ao2, i, c->d->ao_format));
             c->inv_depth[i] = 1.0f / c->low_depth[i];
         }
 }
@@ -516,7 +546,7 @@ static void ups_bilateral_rows(void *arg, int y0, int y1)
 }
 
 static int upsample_pass(const meao_oracle_desc *d, int low_level, int nthreads,
-                         const float *low_depth, const void *low_ao,
+                         const float *low_depth, const void *low_ao, const void *low_ao2,
                          const float *hi_depth32, const uint16_t *hi_depth16, const void *hi_ao,
                          void *out)
 {
@@ -525,7 +555,7 @@ static int upsample_pass(const meao_oracle_desc *d, int low_level, int nthreads,
     meao_oracle_upsample_constants(d, low_level, &c.k);
     meao_oracle_level_dims(d->width, d->height, low_level, &c.lw, &c.lh);
     meao_oracle_level_dims(d->width, d->height, low_level - 1, &c.hw, &c.hh);
-    c.low_depth = low_depth; c.low_ao = low_ao;
+    c.low_depth = low_depth; c.low_ao = low_ao; c.low_ao2 = low_ao2;
     c.hi_depth32 = hi_depth32; c.hi_depth16 = hi_depth16; c.hi_ao = hi_ao; c.out = out;
     size_t n = (size_t)c.lw * c.lh;
     c.inv_depth = (float *)malloc(n * 4);
@@ -582,6 +612,8 @@ int32_t meao_oracle_run(const meao_oracle_desc *d, const void *depth,
     if (d->depth_format < MEAO_ORACLE_DEPTH_F32 || d->depth_format > MEAO_ORACLE_DEPTH_F16) return -1;
     if (d->width < 1 || d->height < 1 || d->num_levels < 1 || d->num_levels > 4) return -1;
     if (d->ao_format != MEAO_ORACLE_AO_R8 && d->ao_format != MEAO_ORACLE_AO_F16) return -1;
+    if (d->hq_levels < 0 || d->hq_levels > d->num_levels) return -1;
+    if (d->sample_set != MEAO_ORACLE_SAMPLES_CHECKER && d->sample_set != MEAO_ORACLE_SAMPLES_EXHAUSTIVE) return -1;
 
     ds_ctx ds; memset(&ds, 0, sizeof ds);
     ds.d = d; ds.depth = depth;
@@ -593,12 +625,14 @@ int32_t meao_oracle_run(const meao_oracle_desc *d, const void *depth,
 #define GET(ptr, bytes) ((ptr) ? (void *)(ptr) : (owned[nowned] = malloc(bytes), fail |= !owned[nowned], owned[nowned++]))
     size_t ab = ao_bytes(d->ao_format);
     ds.linear = (uint16_t *)GET(out->linear_depth, (size_t)ds.w[0] * ds.h[0] * 2);
-    void *occ[4], *comb[3], *res;
+    void *occ[4], *comb[3], *res, *hq[4] = { NULL, NULL, NULL, NULL };
     for (int k = 1; k <= 4; k++) {
         ds.low[k - 1] = (float *)GET(out->low_depth[k - 1], (size_t)ds.w[k] * ds.h[k] * 4);
         ds.tiled[k - 1] = (uint16_t *)GET(out->tiled_depth[k - 1], (size_t)ds.w[k + 2] * ds.h[k + 2] * 16 * 2);
         occ[k - 1] = GET(out->occlusion[k - 1], (size_t)ds.w[k] * ds.h[k] * ab);
         if (k <= 3) comb[k - 1] = GET(out->combined[k - 1], (size_t)ds.w[k] * ds.h[k] * ab);
+        if (k > d->num_levels - d->hq_levels && k <= d->num_levels)
+            hq[k - 1] = GET(out->occlusion_hq[k - 1], (size_t)ds.w[k] * ds.h[k] * ab);
     }
     res = GET(out->result, (size_t)ds.w[0] * ds.h[0] * ab);
 #undef GET
@@ -615,17 +649,24 @@ int32_t meao_oracle_run(const meao_oracle_desc *d, const void *depth,
             r.tiled = ds.tiled[k - 1]; r.sw = ds.w[k + 2]; r.sh = ds.h[k + 2];
             r.out = occ[k - 1]; r.ow = ds.w[k]; r.oh = ds.h[k];
             par_rows(nthreads, r.oh, ren_rows, &r);
+            if (hq[k - 1]) {                                         /* Render.main on LowDepth<k> */
+                memset(&r, 0, sizeof r);
+                r.d = d; meao_oracle_render_constants_hq(d, k, &r.k);
+                r.flat = ds.low[k - 1]; r.sw = ds.w[k]; r.sh = ds.h[k];
+                r.out = hq[k - 1]; r.ow = ds.w[k]; r.oh = ds.h[k];
+                par_rows(nthreads, r.oh, ren_rows, &r);
+            }
         }
 
         /* AO.cs:528-531 generalised to num_levels: deepest rendered level is the
          * first low-res AO; each step blends with the next finer Occlusion. */
         const void *low_ao = occ[d->num_levels - 1];
         for (int hi = d->num_levels - 1; hi >= 1 && !rc; hi--) {
-            rc = upsample_pass(d, hi + 1, nthreads, ds.low[hi], low_ao,
+            rc = upsample_pass(d, hi + 1, nthreads, ds.low[hi], low_ao, hq[hi],
                                ds.low[hi - 1], NULL, occ[hi - 1], comb[hi - 1]);
             low_ao = comb[hi - 1];
         }
-        if (!rc) rc = upsample_pass(d, 1, nthreads, ds.low[0], low_ao, NULL, ds.linear, NULL, res);
+        if (!rc) rc = upsample_pass(d, 1, nthreads, ds.low[0], low_ao, hq[0], NULL, ds.linear, NULL, res);
     }
     for (int i = 0; i < nowned; i++) free(owned[i]);
     return rc;

@@ -58,7 +58,16 @@ typedef struct meao_oracle_desc {
     float near_clip, far_clip;    /* AO.cs:563 */
     float proj00;                 /* camera.projectionMatrix[0,0] (AO.cs:572) */
     int32_t depth_format;         /* storage of the input depth, see below     */
+    /* ---- variants the reference carries but never (or only in VR) dispatches ---- */
+    int32_t single_pass_stereo;   /* AO.cs:392-401,680: double-wide frame, ThicknessMultiplier x2 */
+    int32_t hq_levels;            /* 0..num_levels: the coarsest hq_levels levels additionally run
+                                   * Render.main (wide, non-interleaved, REN:22,27-29,46-50) on
+                                   * LowDepth<k> and min-combine it in Upsample.main_premin*
+                                   * (UPS:23,25,58-60); 0 = the reference's wiring */
+    int32_t sample_set;           /* 0 = 36-sample checker (REN:160-169), 1 = SAMPLE_EXHAUSTIVELY
+                                   * (68 samples, all 12 weights, REN:144-159) */
 } meao_oracle_desc;
+enum { MEAO_ORACLE_SAMPLES_CHECKER = 0, MEAO_ORACLE_SAMPLES_EXHAUSTIVE = 1 };
 
 /* Input depth storage.  The reference blits _CameraDepthTexture into an RFloat copy first
  * (Blit.shader:48-64 pass 0, AO.cs:608-614): UNORM texels sample as v / (2^n - 1), correctly
@@ -77,6 +86,7 @@ typedef struct meao_oracle_buffers {
     void     *occlusion[4];    /* id 10..13 AO, L1..L4                   */
     void     *combined[3];     /* id 14..16 AO, L1..L3                   */
     void     *result;          /* id 17     AO, L0                       */
+    void     *occlusion_hq[4]; /* id 18..21 AO, L1..L4: Render.main on LowDepth<k> (hq_levels) */
 } meao_oracle_buffers;
 
 /* Constant blocks, exactly what AO.cs uploads per dispatch. */
@@ -104,6 +114,10 @@ void meao_oracle_sample_thickness(float out[12]);
 /* level = 1..4: source atlas is TiledDepth<level> (dims of mip level+2). */
 void meao_oracle_render_constants(const meao_oracle_desc *d, int32_t level,
                                   meao_oracle_render_consts *out);
+/* level = 1..4: source is the non-tiled LowDepth<level> (PushRenderCommands with
+ * !source.isTiled, AO.cs:679): ThicknessMultiplier x2, inv_slice_dim = 1 / dims(level). */
+void meao_oracle_render_constants_hq(const meao_oracle_desc *d, int32_t level,
+                                     meao_oracle_render_consts *out);
 /* low_level = mip level of the low-res input (1..4), high = low_level-1. */
 void meao_oracle_upsample_constants(const meao_oracle_desc *d, int32_t low_level,
                                     meao_oracle_upsample_consts *out);

@@ -29,6 +29,9 @@ BUFFER_IDS = {
     10: "occlusion1", 11: "occlusion2", 12: "occlusion3", 13: "occlusion4",
     14: "combined1", 15: "combined2", 16: "combined3", 17: "result",
 }
+# not in the reference's _debug list: the Render.main (wide) targets of the hq_levels variant
+HQ_BUFFER_IDS = {18: "occlusion_hq1", 19: "occlusion_hq2", 20: "occlusion_hq3", 21: "occlusion_hq4"}
+SAMPLES_CHECKER, SAMPLES_EXHAUSTIVE = 0, 1
 
 
 class Desc(C.Structure):
@@ -39,6 +42,7 @@ class Desc(C.Structure):
         ("upsample_tolerance", C.c_float), ("thickness_modifier", C.c_float),
         ("intensity", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
         ("proj00", C.c_float), ("depth_format", C.c_int32),
+        ("single_pass_stereo", C.c_int32), ("hq_levels", C.c_int32), ("sample_set", C.c_int32),
     ]
 
 
@@ -46,7 +50,7 @@ class Buffers(C.Structure):
     _fields_ = [
         ("linear_depth", C.c_void_p), ("low_depth", C.c_void_p * 4),
         ("tiled_depth", C.c_void_p * 4), ("occlusion", C.c_void_p * 4),
-        ("combined", C.c_void_p * 3), ("result", C.c_void_p),
+        ("combined", C.c_void_p * 3), ("result", C.c_void_p), ("occlusion_hq", C.c_void_p * 4),
     ]
 
 
@@ -89,6 +93,7 @@ def lib():
         L.meao_oracle_level_dims.argtypes = [C.c_int32, C.c_int32, C.c_int32,
                                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.meao_oracle_render_constants.argtypes = [C.POINTER(Desc), C.c_int32, C.POINTER(RenderConsts)]
+        L.meao_oracle_render_constants_hq.argtypes = [C.POINTER(Desc), C.c_int32, C.POINTER(RenderConsts)]
         L.meao_oracle_upsample_constants.argtypes = [C.POINTER(Desc), C.c_int32, C.POINTER(UpsampleConsts)]
         L.meao_oracle_zbuffer_params.argtypes = [C.POINTER(Desc), C.POINTER(C.c_float * 4)]
         L.meao_oracle_sample_thickness.argtypes = [C.POINTER(C.c_float * 12)]
@@ -122,12 +127,19 @@ class Settings:
     far_clip: float = 100.0
     proj00: float = 1.0
     depth_format: int = DEPTH_F32
+    single_pass_stereo: bool = False     # AO.cs:392-401,680
+    hq_levels: int = 0                   # coarsest N levels also run Render.main + main_premin*
+    sample_set: int = SAMPLES_CHECKER    # or SAMPLES_EXHAUSTIVE (REN:144-159)
+
+    def hq_level_list(self):
+        return [k for k in range(1, self.num_levels + 1) if k > self.num_levels - self.hq_levels]
 
     def desc(self) -> Desc:
         return Desc(self.width, self.height, self.num_levels, self.ao_format, self.f16_rounding,
                     1 if self.reversed_z else 0, self.noise_filter_tolerance, self.blur_tolerance,
                     self.upsample_tolerance, self.thickness_modifier, self.intensity,
-                    self.near_clip, self.far_clip, self.proj00, self.depth_format)
+                    self.near_clip, self.far_clip, self.proj00, self.depth_format,
+                    1 if self.single_pass_stereo else 0, self.hq_levels, self.sample_set)
 
 
 def level_dims(width: int, height: int, level: int):
@@ -147,6 +159,8 @@ def allocate(s: Settings):
         if k <= 3:
             out[f"combined{k}"] = np.zeros((dims[k][1], dims[k][0]), ao_dt)
     out["result"] = np.zeros((dims[0][1], dims[0][0]), ao_dt)
+    for k in s.hq_level_list():
+        out[f"occlusion_hq{k}"] = np.zeros((dims[k][1], dims[k][0]), ao_dt)
     return out
 
 
@@ -160,6 +174,9 @@ def _buffers(arrs) -> Buffers:
         if k < 3:
             b.combined[k] = arrs[f"combined{k + 1}"].ctypes.data
     b.result = arrs["result"].ctypes.data
+    for k in range(4):
+        if f"occlusion_hq{k + 1}" in arrs:
+            b.occlusion_hq[k] = arrs[f"occlusion_hq{k + 1}"].ctypes.data
     return b
 
 
@@ -190,6 +207,13 @@ def render_constants(s: Settings, level: int) -> RenderConsts:
     out = RenderConsts()
     d = s.desc()
     lib().meao_oracle_render_constants(C.byref(d), level, C.byref(out))
+    return out
+
+
+def render_constants_hq(s: Settings, level: int) -> RenderConsts:
+    out = RenderConsts()
+    d = s.desc()
+    lib().meao_oracle_render_constants_hq(C.byref(d), level, C.byref(out))
     return out
 
 

@@ -11,6 +11,15 @@ Unity's API behaviour (mocked).
 
 The fixtures travel to the GPU box; tests/test_reference_goldens.py checks the oracle (CPU) and
 the HIP path (GPU) against them bit for bit.
+
+Variants the reference carries but its host never dispatches are pinned at the
+shader level: Render.main (wide), SAMPLE_EXHAUSTIVELY and Upsample.main_premin* run from the
+reference's source text; their constants come from the reference's own PushRenderCommands /
+PushUpsampleCommands (called through the C# interpreter with a non-tiled source where needed).
+What the reference does NOT contain and is therefore this project's wiring (following the
+Microsoft MiniEngine original): which levels get a Render.main pass and that its output is the
+LoResAO2 of the next upsample; the un-zeroed weight table of the exhaustive set (AO.cs:709 FIXME).
+Single-pass stereo IS a reference host path (AO.cs:392-401,680) and is recorded from the C#.
 """
 import os
 import sys
@@ -31,6 +40,10 @@ SHADERS = "/root/reference/Assets/MiniEngineAO/Shaders"
 
 # name -> (w, h, generator, seed, camera, settings overrides, sky block)
 CASES = {
+    "ref_stereo_2x24x27": (48, 27, "S2", 23, synth.DEFAULT_CAMERA, dict(single_pass_stereo=True), False),
+    "ref_hq4_45x31": (45, 31, "S2", 24, synth.DEFAULT_CAMERA, dict(hq_levels=4, intensity=1.2), True),
+    "ref_hq2_exhaustive_52x38_f16": (52, 38, "S2", 25, synth.Camera(reversed_z=False),
+                                     dict(hq_levels=2, sample_set=1, ao_format=1, thickness_modifier=1.5), False),
     "ref_s2_37x29_r8": (37, 29, "S2", 21, synth.DEFAULT_CAMERA, {}, False),
     "ref_s2_70x41_f16_rtne_convz": (70, 41, "S2", 22, synth.Camera(reversed_z=False),
                                     dict(ao_format=1, f16_rounding=1, intensity=1.3, thickness_modifier=2.0,
@@ -46,7 +59,8 @@ SHADER_FILES = ("Downsample1", "Downsample2", "Render", "Upsample")
 ORACLE_KEY = {"LinearDepth": "linear_depth", "AmbientOcclusion": "result"}
 for _k in range(1, 5):
     ORACLE_KEY.update({f"LowDepth{_k}": f"low_depth{_k}", f"TiledDepth{_k}": f"tiled_depth{_k}",
-                       f"Occlusion{_k}": f"occlusion{_k}", f"Combined{_k}": f"combined{_k}"})
+                       f"Occlusion{_k}": f"occlusion{_k}", f"Combined{_k}": f"combined{_k}",
+                       f"OcclusionHQ{_k}": f"occlusion_hq{_k}"})
 
 
 def shader_sources():
@@ -65,7 +79,7 @@ def kernel_numthreads(src):
     return out
 
 
-def record_reference_commands(s):
+def record_reference_commands(s, want_interp=False):
     """Run the reference's own C# (AmbientOcclusion.cs: DoLazyInitialization + RebuildCommandBuffers)
     through oracle/csharp_interp.py against recording Unity mocks."""
     from tests.golden import unity_mocks as U
@@ -73,10 +87,29 @@ def record_reference_commands(s):
     props = {"_noiseFilterTolerance": s.noise_filter_tolerance, "_blurTolerance": s.blur_tolerance,
              "_upsampleTolerance": s.upsample_tolerance, "_thicknessModifier": s.thickness_modifier,
              "_intensity": s.intensity}
-    cmd, result_rt = U.run_component(AO_CS, kernel_numthreads(src), width=s.width, height=s.height,
-                                     near=s.near_clip, far=s.far_clip, proj00=s.proj00,
-                                     reversed_z=s.reversed_z, properties=props)
-    return src, cmd, result_rt
+    stereo = bool(s.single_pass_stereo)
+    assert not stereo or s.width % 2 == 0
+    out = U.run_component(AO_CS, kernel_numthreads(src), width=s.width // 2 if stereo else s.width,
+                          height=s.height, near=s.near_clip, far=s.far_clip, proj00=s.proj00,
+                          reversed_z=s.reversed_z, properties=props, stereo=stereo, want_interp=True)
+    cmd, result_rt, it, comp = out
+    return (src, cmd, result_rt, it, comp) if want_interp else (src, cmd, result_rt)
+
+
+def hq_render_commands(s, it, comp, level):
+    """The reference's PushRenderCommands (AO.cs:660-747) with the NON-tiled LowDepth<level> as the
+    source: yields the constant block of the !source.isTiled branch (AO.cs:679).  The method always
+    picks main_interleaved; the kernel name and group counts are replaced by Render.main's."""
+    from tests.golden import unity_mocks as U
+    cls = comp.cls
+    tan = it.call_method(comp, cls, "CalculateTanHalfFovHeight", [])
+    cmd = U.CommandBuffer()
+    it.call_method(comp, cls, "PushRenderCommands",
+                   [cmd, comp.f[f"_lowDepth{level}"], comp.f[f"_occlusion{level}"], tan])
+    d = cmd.dispatches[-1]
+    w, h = O.level_dims(s.width, s.height, level)
+    return {"shader": "Render", "kernel": "main", "groups": ((w + 15) // 16, (h + 15) // 16, 1),
+            "tex": {"DepthTex": f"LowDepth{level}", "Occlusion": f"OcclusionHQ{level}"}, "const": d["const"]}
 
 
 def textures(s, cmd, result_rt):
@@ -91,6 +124,8 @@ def textures(s, cmd, result_rt):
               encode=lambda v: L.meao_oracle_f32_to_unorm8(float(v)))
     allocs = dict(cmd.allocs)
     allocs["AmbientOcclusion"] = (result_rt.width, result_rt.height, 1, result_rt.format._name.split(".")[-1])
+    for k in s.hq_level_list():                               # this project's extra targets
+        allocs[f"OcclusionHQ{k}"] = allocs[f"Occlusion{k}"]
     arrs, tex = {}, {}
     for name, (w, h, slices, fmt) in allocs.items():
         if fmt == "R8" and s.ao_format == O.AO_F16:
@@ -102,18 +137,46 @@ def textures(s, cmd, result_rt):
     return arrs, tex
 
 
+def variant_dispatches(s, cmd, it, comp):
+    """The recorded dispatch list, re-wired for the variants (see the module docstring)."""
+    out = []
+    hq = s.hq_level_list()
+    exhaustive = s.sample_set == O.SAMPLES_EXHAUSTIVE
+    for d in cmd.dispatches:
+        d = dict(d, tex=dict(d["tex"]), const=dict(d["const"]), defines={})
+        if d["shader"] == "Render":
+            level = int(d["tex"]["Occlusion"][-1])
+            renders = [d] + ([hq_render_commands(s, it, comp, level)] if level in hq else [])
+            for r in renders:
+                r.setdefault("defines", {})
+                if exhaustive:                                # AO.cs:709 FIXME: the host never builds this table
+                    consts = (O.render_constants_hq if r["kernel"] == "main" else O.render_constants)(s, level)
+                    r["const"] = dict(r["const"], gSampleWeightTable=[np.float32(v) for v in consts.sample_weight])
+                    r["defines"] = {"SAMPLE_EXHAUSTIVELY": "1"}
+                out.append(r)
+            continue
+        if d["shader"] == "Upsample":
+            low_level = int(d["tex"]["LoResDB"][-1])
+            if low_level in hq:
+                d["kernel"] = {"main": "main_premin", "main_blendout": "main_premin_blendout"}[d["kernel"]]
+                d["tex"]["LoResAO2"] = f"OcclusionHQ{low_level}"
+        out.append(d)
+    return out
+
+
 def run_reference_shaders(depth, s, log=print):
     """The reference end to end: its C# decides allocations, bindings, constants and dispatch sizes,
     its HLSL does the arithmetic; both are interpreted from the source text under /root/reference."""
-    assert s.num_levels == 4 and s.depth_format == O.DEPTH_F32, "the reference always runs 4 levels on an RFloat depth"
-    src, cmd, result_rt = record_reference_commands(s)
+    assert s.depth_format == O.DEPTH_F32, "the reference runs on an RFloat depth"
+    assert s.num_levels == 4, "the reference always runs 4 levels"
+    src, cmd, result_rt, it, comp = record_reference_commands(s, want_interp=True)
     arrs, tex = textures(s, cmd, result_rt)
     depth_tex = HI.Texture(np.ascontiguousarray(depth, np.float32)[None])
     rev = {"UNITY_REVERSED_Z": "1"} if s.reversed_z else {}
     t0 = time.time()
-    for d in cmd.dispatches:
+    for d in variant_dispatches(s, cmd, it, comp):
         text = src[d["shader"]]
-        variant = dict(HI.kernel_variants(text)[d["kernel"]], **rev)
+        variant = dict(HI.kernel_variants(text)[d["kernel"]], **rev, **d.get("defines", {}))
         entry = variant.get("MAIN", d["kernel"])
         prog = HI.Parser(HI.lex(HI.preprocess(text, variant))).program()
         HI.attach_semantics(prog, entry, HI.preprocess(text, variant))
@@ -160,7 +223,7 @@ def main(only=None):
         ref, _ = run_reference_shaders(depth, s)
         want = O.run(depth, s)
         bad = [k for k in ref if not np.array_equal(ref[k], want[k])]
-        print("  interpreter vs oracle: %s" % ("all 17 buffers identical" if not bad else "DIFFER: %s" % bad))
+        print("  interpreter vs oracle: %s" % ("all %d buffers identical" % len(ref) if not bad else "DIFFER: %s" % bad))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), depth=depth, **ref)
 
 

@@ -143,14 +143,18 @@ class CommandBuffer:
         return lambda *a: self.raster.append(key)
 
 
-def run_component(ao_cs_path, numthreads, *, width, height, near, far, proj00, reversed_z, properties):
+def run_component(ao_cs_path, numthreads, *, width, height, near, far, proj00, reversed_z, properties,
+                  stereo=False, want_interp=False):
     """Instantiate the reference's AmbientOcclusion class from its source, run
     DoLazyInitialization() and RebuildCommandBuffers() against the mocks, return the render
     CommandBuffer mock (allocations + dispatches) and the size/format of the persistent result RT.
-    properties: serialized field name -> value (e.g. {"_intensity": 1.1})."""
+    properties: serialized field name -> value (e.g. {"_intensity": 1.1}).
+    stereo: single-pass stereo as the component detects it (AO.cs:392-401): camera.stereoEnabled,
+    no target texture, one draw per frame; width is then the per-eye pixelWidth.
+    want_interp: also return the interpreter and the component instance."""
     classes = CS.load(ao_cs_path)
     camera = Any("camera", pixelWidth=int(width), pixelHeight=int(height), nearClipPlane=F(near),
-                 farClipPlane=F(far), projectionMatrix=Matrix(proj00), stereoEnabled=False,
+                 farClipPlane=F(far), projectionMatrix=Matrix(proj00), stereoEnabled=bool(stereo),
                  targetTexture=None, allowHDR=True, actualRenderingPath=Any("RenderingPath.DeferredShading"))
     system_info = Any("SystemInfo", usesReversedZBuffer=bool(reversed_z),
                       graphicsDeviceType=Any("GraphicsDeviceType.Direct3D11"))   # resolved depth: no copy blit
@@ -177,9 +181,14 @@ def run_component(ao_cs_path, numthreads, *, width, height, near, far, proj00, r
                           ("_renderCompute", "Render"), ("_upsampleCompute", "Upsample")):
         comp.f[field] = ComputeShader(shader, numthreads[shader])
     comp.f["_blitShader"] = Any("BlitShader")
+    if stereo:
+        assert "_drawCountPerFrame" in comp.f
+        comp.f["_drawCountPerFrame"] = 1
     cls = classes["AmbientOcclusion"]
     it.call_method(comp, cls, "DoLazyInitialization", [])
     it.call_method(comp, cls, "RebuildCommandBuffers", [])
     cmd = comp.f["_renderCommand"]
     result_rt = comp.f["_result"].f["_rt"]
+    if want_interp:
+        return cmd, result_rt, it, comp
     return cmd, result_rt
