@@ -38,6 +38,7 @@ namespace MiniEngineAO
         public float farClipPlane = 1000;
         public float projection00 = 0.9742786f;     // camera.projectionMatrix[0, 0]
         public bool usesReversedZBuffer = true;     // SystemInfo.usesReversedZBuffer
+        public bool singlePassStereoEnabled = false; // AO.cs:392-401; pixelWidth is then the double-wide eye pair
 
         IntPtr _ctx;
         MeaoConfig _cfg;
@@ -47,8 +48,10 @@ namespace MiniEngineAO
         public int width { get { return _cfg.width; } }
         public int height { get { return _cfg.height; } }
 
+        // hqLevels / sampleSet: variants the reference's shaders carry but its host never dispatches.
         public AmbientOcclusion(int pixelWidth, int pixelHeight, int device = 0,
-                                MeaoAoFormat aoFormat = MeaoAoFormat.R8, int maxBatch = 1)
+                                MeaoAoFormat aoFormat = MeaoAoFormat.R8, int maxBatch = 1,
+                                int hqLevels = 0, MeaoSampleSet sampleSet = MeaoSampleSet.Checker)
         {
             Meao.meao_default_config(out _cfg);
             _cfg.device = device;
@@ -56,6 +59,8 @@ namespace MiniEngineAO
             _cfg.height = pixelHeight;
             _cfg.ao_format = (int)aoFormat;
             _cfg.max_batch = maxBatch;
+            _cfg.hq_levels = hqLevels;
+            _cfg.sample_set = (int)sampleSet;
             Check(Meao.meao_create(ref _cfg, out _ctx));
         }
 
@@ -79,6 +84,7 @@ namespace MiniEngineAO
             p.far_clip = farClipPlane;
             p.proj00 = projection00;
             p.reversed_z = usesReversedZBuffer ? 1 : 0;
+            p.single_pass_stereo = singlePassStereoEnabled ? 1 : 0;
             if (!_haveApplied || !p.Equals(_applied))
             {
                 Check(Meao.meao_set_params(_ctx, ref p));

@@ -1,4 +1,4 @@
-// MeaoNative.cs -- P/Invoke declarations for libmeao_hip.so (include/meao.h, ABI version 2).
+// MeaoNative.cs -- P/Invoke declarations for libmeao_hip.so (include/meao.h, ABI version 3).
 //
 // NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT: the build image has no dotnet/mono/csc
 // (SURVEY.md, "Environment facts").  tests/test_host_mirror.py cross-checks every
@@ -25,6 +25,7 @@ namespace MiniEngineAO.Native
     public enum MeaoDepthFormat { F32 = 0, Unorm16 = 1, Unorm24 = 2, F16 = 3 }
     public enum MeaoCompositeMode { Multiply = 0, AmbientOnly = 1, Debug = 2 }
     public enum MeaoFormat { F32 = 0, F16 = 1, Unorm8 = 2 }
+    public enum MeaoSampleSet { Checker = 0, Exhaustive = 1 }
 
     [StructLayout(LayoutKind.Sequential)]
     public struct MeaoConfig
@@ -39,6 +40,8 @@ namespace MiniEngineAO.Native
         public int numerics;
         public int max_batch;
         public int depth_format;
+        public int hq_levels;
+        public int sample_set;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -54,6 +57,7 @@ namespace MiniEngineAO.Native
         public float far_clip;
         public float proj00;
         public int reversed_z;
+        public int single_pass_stereo;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -91,9 +95,11 @@ namespace MiniEngineAO.Native
     public static class Meao
     {
         const string Lib = "meao_hip";   // libmeao_hip.so
-        public const int AbiVersion = 2;
+        public const int AbiVersion = 3;
         public const int MaxBatch = 16;
-        public const int NumPasses = 6;
+        public const int NumPasses = 7;
+        public const int DebugOcclusionHq1 = 18;
+        public const int NumBuffers = 21;
 
         [DllImport(Lib)] public static extern int meao_abi_version();
         [DllImport(Lib)] public static extern IntPtr meao_status_string(int status);
@@ -103,9 +109,10 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_level_dims(int width, int height, int level, out int out_w, out int out_h);
         [DllImport(Lib)] public static extern int meao_zbuffer_params(ref MeaoParams p, [Out] float[] out4);
         [DllImport(Lib)] public static extern int meao_render_constants_for(int width, int height, ref MeaoParams p, int level, out MeaoRenderConstants constants);
+        [DllImport(Lib)] public static extern int meao_render_constants_variant(int width, int height, ref MeaoParams p, int level, int source_tiled, int sample_set, out MeaoRenderConstants constants);
         [DllImport(Lib)] public static extern int meao_upsample_constants_for(int width, int height, ref MeaoParams p, int low_level, out MeaoUpsampleConstants constants);
         [DllImport(Lib)] public static extern int meao_describe_buffer(ref MeaoConfig cfg, int debug_id, out MeaoDesc desc);
-        [DllImport(Lib)] public static extern int meao_algorithmic_bytes(ref MeaoConfig cfg, [Out] ulong[] bytes6);
+        [DllImport(Lib)] public static extern int meao_algorithmic_bytes(ref MeaoConfig cfg, [Out] ulong[] bytes7);
 
         [DllImport(Lib)] public static extern int meao_create(ref MeaoConfig cfg, out IntPtr ctx);
         [DllImport(Lib)] public static extern int meao_destroy(IntPtr ctx);
@@ -121,7 +128,7 @@ namespace MiniEngineAO.Native
 
         [DllImport(Lib)] public static extern int meao_get_intermediate(IntPtr ctx, int frame, int debug_id, IntPtr dst, ulong dst_capacity, int dst_loc, out MeaoDesc desc);
         [DllImport(Lib)] public static extern int meao_set_profiling(IntPtr ctx, int enable);
-        [DllImport(Lib)] public static extern int meao_get_pass_times(IntPtr ctx, [Out] float[] ms6, out int samples);
+        [DllImport(Lib)] public static extern int meao_get_pass_times(IntPtr ctx, [Out] float[] ms7, out int samples);
         [DllImport(Lib)] public static extern int meao_selftest(IntPtr ctx, int which, out ulong mismatches);
         [DllImport(Lib)] public static extern int meao_debug_view(IntPtr ctx, int frame, int debug_id, IntPtr dst, int out_loc, IntPtr stream);
         [DllImport(Lib)] public static extern int meao_composite(IntPtr ctx, int mode, IntPtr ao, IntPtr color_rgba16f, IntPtr gbuffer0_rgba8, int loc, IntPtr stream);

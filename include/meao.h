@@ -32,9 +32,9 @@ extern "C" {
 #define MEAO_API
 #endif
 
-#define MEAO_ABI_VERSION 2
+#define MEAO_ABI_VERSION 3
 #define MEAO_MAX_BATCH 16      /* frames per batched launch */
-#define MEAO_NUM_PASSES 6      /* downsample, render, upsample x4 (see meao_pass) */
+#define MEAO_NUM_PASSES 7      /* downsample, render, upsample x4, render_hq (see meao_pass) */
 
 typedef struct meao_ctx meao_ctx;
 typedef void *meao_stream;     /* hipStream_t; NULL = the context's own stream */
@@ -79,6 +79,18 @@ typedef enum meao_depth_format {
 
 typedef enum meao_format { MEAO_FMT_F32 = 0, MEAO_FMT_F16 = 1, MEAO_FMT_UNORM8 = 2 } meao_format;
 
+/* Sample set of the AO render.  CHECKER = what the reference dispatches (36 samples,
+ * Render.compute:160-169).  EXHAUSTIVE = the shader's SAMPLE_EXHAUSTIVELY branch (68 samples, all
+ * 12 table slots, Render.compute:144-159), which the reference's host never enables (AO.cs:709
+ * "FIXME: should we support SAMPLE_EXHAUSTIVELY mode?"): the weight table is then the un-zeroed
+ * AO.cs:696-707 table, normalised the same way. */
+typedef enum meao_sample_set { MEAO_SAMPLES_CHECKER = 0, MEAO_SAMPLES_EXHAUSTIVE = 1 } meao_sample_set;
+
+/* Buffers beyond the reference's 17 debug ids: the Render.main (wide) targets of the hq_levels
+ * variant, OcclusionHQ1..4 (AO format, dims of L1..L4). */
+#define MEAO_DEBUG_OCCLUSION_HQ1 18
+#define MEAO_NUM_BUFFERS 21
+
 /* Kernel launches of one frame/batch, in stream order. */
 typedef enum meao_pass {
     MEAO_PASS_DOWNSAMPLE = 0,  /* Downsample1.main + Downsample2.main fused  (AO.cs:627-657) */
@@ -86,7 +98,9 @@ typedef enum meao_pass {
     MEAO_PASS_UPSAMPLE_3 = 2,  /* Upsample.main_blendout L4 -> L3             (AO.cs:528) */
     MEAO_PASS_UPSAMPLE_2 = 3,  /* Upsample.main_blendout L3 -> L2             (AO.cs:529) */
     MEAO_PASS_UPSAMPLE_1 = 4,  /* Upsample.main_blendout L2 -> L1             (AO.cs:530) */
-    MEAO_PASS_UPSAMPLE_0 = 5   /* Upsample.main          L1 -> L0 result      (AO.cs:531) */
+    MEAO_PASS_UPSAMPLE_0 = 5,  /* Upsample.main          L1 -> L0 result      (AO.cs:531) */
+    MEAO_PASS_RENDER_HQ = 6    /* Render.main (wide) on LowDepth<k>, all hq levels, one grid; launched
+                                * right after MEAO_PASS_RENDER (cfg.hq_levels > 0 only) */
 } meao_pass;
 
 /* What DoLazyInitialization + RTHandle sizing fix per instance (AO.cs:440-476,276-281). */
@@ -100,6 +114,14 @@ typedef struct meao_config {
     int32_t numerics;       /* meao_numerics */
     int32_t max_batch;      /* 1..MEAO_MAX_BATCH frames resident per launch */
     int32_t depth_format;   /* meao_depth_format of the depth pointers given to meao_execute* */
+    /* Variants present in the reference's shaders but never dispatched by its host (0 = reference): */
+    int32_t hq_levels;      /* 0..num_levels.  The coarsest hq_levels levels additionally run
+                             * Render.main (WIDE_SAMPLING, non-interleaved; Render.compute:22,27-29,
+                             * 46-50) on LowDepth<k>, and the upsample that consumes level k becomes
+                             * Upsample.main_premin / main_premin_blendout (Upsample.compute:23,25,58-60):
+                             * LoResAO1 = min(LoResAO1, that render).  Wiring as in the Microsoft
+                             * MiniEngine original (its quality levels = hq_levels 0..4). */
+    int32_t sample_set;     /* meao_sample_set */
 } meao_config;
 
 /* The component's serialized properties (AO.cs:20-68; defaults there) and the camera terms
@@ -114,11 +136,14 @@ typedef struct meao_params {
     float near_clip, far_clip;      /* camera.nearClipPlane / farClipPlane  AO.cs:563 */
     float proj00;                   /* camera.projectionMatrix[0,0]         AO.cs:572 */
     int32_t reversed_z;             /* SystemInfo.usesReversedZBuffer       AO.cs:564 */
+    int32_t single_pass_stereo;     /* singlePassStereoEnabled (AO.cs:392-401): the frame is the double-wide
+                                     * eye pair (cfg.width = 2 * camera.pixelWidth, AO.cs:339,502) and
+                                     * ThicknessMultiplier doubles (AO.cs:680) */
 } meao_params;
 
 /* Description of one of the 17 debug-visible buffers (AO.cs:789-808). */
 typedef struct meao_desc {
-    int32_t debug_id;       /* 1..17 */
+    int32_t debug_id;       /* 1..17, or 18..21 = OcclusionHQ1..4 */
     int32_t width, height;
     int32_t slices;         /* 16 for TiledDepth1..4 (AO.cs:154), else 1 */
     int32_t format;         /* meao_format */
@@ -159,10 +184,15 @@ MEAO_API int32_t meao_zbuffer_params(const meao_params *p, float out[4]);
 /* PushRenderCommands constant math (AO.cs:660-734) for level 1..4. */
 MEAO_API int32_t meao_render_constants_for(int32_t width, int32_t height, const meao_params *p,
                                            int32_t level, meao_render_constants *out);
+/* The same for the variants: source_tiled = 0 -> the source is the non-tiled LowDepth<level>
+ * (the !source.isTiled branch, AO.cs:679); sample_set = meao_sample_set. */
+MEAO_API int32_t meao_render_constants_variant(int32_t width, int32_t height, const meao_params *p,
+                                               int32_t level, int32_t source_tiled, int32_t sample_set,
+                                               meao_render_constants *out);
 /* PushUpsampleCommands constant math (AO.cs:750-771); low_level 1..4 is the mip of LoResDB. */
 MEAO_API int32_t meao_upsample_constants_for(int32_t width, int32_t height, const meao_params *p,
                                              int32_t low_level, meao_upsample_constants *out);
-/* Buffer table (AO.cs:453-475): dims/format/bytes of debug buffer 1..17. */
+/* Buffer table (AO.cs:453-475): dims/format/bytes of debug buffer 1..17 (and 18..21, OcclusionHQ1..4). */
 MEAO_API int32_t meao_describe_buffer(const meao_config *cfg, int32_t debug_id, meao_desc *out);
 /* Compulsory traffic of each pass in the reference's storage formats (SURVEY.md 8d,
  * BASELINE.md 3): the numerator of the roofline fraction.  bytes[MEAO_NUM_PASSES]. */
@@ -197,7 +227,8 @@ MEAO_API int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream);
 
 /* ---- observability (replaces the _debug 1..17 views, AO.cs:787-820) --------------------- */
 /* Copies debug buffer `debug_id` of batch slot `frame` (as left by the last execute) to dst
- * in the reference's layout (TiledDepth: [16][h][w]).  dst may be NULL to query desc only. */
+ * in the reference's layout (TiledDepth: [16][h][w]).  dst may be NULL to query desc only.
+ * Ids 18..21 (OcclusionHQ<k>) exist only for the levels cfg.hq_levels enables. */
 MEAO_API int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id,
                                        void *dst, uint64_t dst_capacity, int32_t dst_loc,
                                        meao_desc *out_desc);

@@ -40,11 +40,15 @@ public:
     float farClipPlane = 1000.0f;
     float projection00 = 0.9742786f;     // camera.projectionMatrix[0,0]
     bool usesReversedZBuffer = true;
+    bool singlePassStereoEnabled = false;   // AO.cs:392-401: pixelWidth is then the double-wide eye pair
 
+    // hqLevels / sampleSet: variants the reference's shaders carry but its host never dispatches
+    // (Render.main wide + Upsample.main_premin*, SAMPLE_EXHAUSTIVELY); 0 = the reference's wiring.
     AmbientOcclusion(int32_t pixelWidth, int32_t pixelHeight, int32_t device = 0,
                      meao_ao_format aoFormat = MEAO_AO_R8, int32_t maxBatch = 1, int32_t numLevels = 4,
                      meao_f16_rounding f16Rounding = MEAO_F16_RTZ_CLAMP,
-                     meao_depth_format depthFormat = MEAO_DEPTH_F32)
+                     meao_depth_format depthFormat = MEAO_DEPTH_F32, int32_t hqLevels = 0,
+                     meao_sample_set sampleSet = MEAO_SAMPLES_CHECKER)
     {
         meao_default_config(&cfg_);
         cfg_.device = device;
@@ -55,6 +59,8 @@ public:
         cfg_.num_levels = numLevels;
         cfg_.f16_rounding = f16Rounding;
         cfg_.depth_format = depthFormat;
+        cfg_.hq_levels = hqLevels;
+        cfg_.sample_set = sampleSet;
         const int32_t rc = meao_create(&cfg_, &ctx_);
         if (rc != MEAO_OK) throw Error(rc, meao_last_error(nullptr));
     }
@@ -98,7 +104,7 @@ public:
 
     void Synchronize(meao_stream stream = nullptr) { check(meao_synchronize(ctx_, stream)); }
 
-    // The _debug 1..17 views (AO.cs:787-820), copied to the host.
+    // The _debug 1..17 views (AO.cs:787-820) and OcclusionHQ1..4 (18..21), copied to the host.
     std::vector<uint8_t> DebugBuffer(int32_t debugId, meao_desc *desc = nullptr, int32_t frame = 0)
     {
         meao_desc d{};
@@ -125,6 +131,7 @@ private:
         p.far_clip = farClipPlane;
         p.proj00 = projection00;
         p.reversed_z = usesReversedZBuffer ? 1 : 0;
+        p.single_pass_stereo = singlePassStereoEnabled ? 1 : 0;
         if (!applied_valid_ || !same(p, applied_)) {
             check(meao_set_params(ctx_, &p));
             applied_ = p;
@@ -136,7 +143,7 @@ private:
         return a.noise_filter_tolerance == b.noise_filter_tolerance && a.blur_tolerance == b.blur_tolerance &&
                a.upsample_tolerance == b.upsample_tolerance && a.thickness_modifier == b.thickness_modifier &&
                a.intensity == b.intensity && a.near_clip == b.near_clip && a.far_clip == b.far_clip &&
-               a.proj00 == b.proj00 && a.reversed_z == b.reversed_z;
+               a.proj00 == b.proj00 && a.reversed_z == b.reversed_z && a.single_pass_stereo == b.single_pass_stereo;
     }
     void check(int32_t rc)
     {

@@ -21,11 +21,12 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmeao_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_BATCH = 16
-NUM_PASSES = 6
+NUM_PASSES = 7
 PASS_NAMES = ("downsample", "render", "upsample_L4_to_L3", "upsample_L3_to_L2",
-              "upsample_L2_to_L1", "upsample_L1_to_L0")
+              "upsample_L2_to_L1", "upsample_L1_to_L0", "render_hq")
+PASS_STREAM_ORDER = (0, 1, 6, 2, 3, 4, 5)     # render_hq runs right after render
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_HIP, ERR_OUT_OF_MEMORY = -1, -2, -3
@@ -37,13 +38,16 @@ MEM_HOST, MEM_DEVICE = 0, 1
 DEPTH_F32, DEPTH_UNORM16, DEPTH_UNORM24, DEPTH_F16 = 0, 1, 2, 3
 COMPOSITE_MULTIPLY, COMPOSITE_AMBIENT_ONLY, COMPOSITE_DEBUG = 0, 1, 2
 FMT_F32, FMT_F16, FMT_UNORM8 = 0, 1, 2
+SAMPLES_CHECKER, SAMPLES_EXHAUSTIVE = 0, 1
+DEBUG_OCCLUSION_HQ1 = 18
+NUM_BUFFERS = 21
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("width", C.c_int32),
                 ("height", C.c_int32), ("num_levels", C.c_int32), ("ao_format", C.c_int32),
                 ("f16_rounding", C.c_int32), ("numerics", C.c_int32), ("max_batch", C.c_int32),
-                ("depth_format", C.c_int32)]
+                ("depth_format", C.c_int32), ("hq_levels", C.c_int32), ("sample_set", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -51,7 +55,7 @@ class Params(C.Structure):
                 ("blur_tolerance", C.c_float), ("upsample_tolerance", C.c_float),
                 ("thickness_modifier", C.c_float), ("intensity", C.c_float),
                 ("near_clip", C.c_float), ("far_clip", C.c_float), ("proj00", C.c_float),
-                ("reversed_z", C.c_int32)]
+                ("reversed_z", C.c_int32), ("single_pass_stereo", C.c_int32)]
 
 
 class Desc(C.Structure):
@@ -80,6 +84,8 @@ SIGNATURES = {
     "meao_level_dims": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "meao_zbuffer_params": (C.c_int32, [C.POINTER(Params), C.POINTER(C.c_float * 4)]),
     "meao_render_constants_for": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(Params), C.c_int32, C.POINTER(RenderConstants)]),
+    "meao_render_constants_variant": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(Params), C.c_int32, C.c_int32,
+                                                  C.c_int32, C.POINTER(RenderConstants)]),
     "meao_upsample_constants_for": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(Params), C.c_int32, C.POINTER(UpsampleConstants)]),
     "meao_describe_buffer": (C.c_int32, [C.POINTER(Config), C.c_int32, C.POINTER(Desc)]),
     "meao_algorithmic_bytes": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_uint64 * NUM_PASSES)]),

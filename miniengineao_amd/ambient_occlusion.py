@@ -25,6 +25,8 @@ DEBUG_BUFFER_NAMES = {
     10: "Occlusion1", 11: "Occlusion2", 12: "Occlusion3", 13: "Occlusion4",
     14: "Combined1", 15: "Combined2", 16: "Combined3", 17: "AmbientOcclusion",
 }
+# beyond the reference's list: the Render.main (wide) targets of the hq_levels variant
+HQ_BUFFER_NAMES = {18: "OcclusionHQ1", 19: "OcclusionHQ2", 20: "OcclusionHQ3", 21: "OcclusionHQ4"}
 
 
 class AmbientOcclusion:
@@ -34,7 +36,11 @@ class AmbientOcclusion:
                  ao_format: int = L.AO_R8, f16_rounding: int = L.F16_RTZ_CLAMP,
                  max_batch: int = 1, depth_format: int = L.DEPTH_F32, numerics: int = L.NUMERICS_STRICT,
                  near_clip: float = 0.3, far_clip: float = 1000.0,
-                 projection00: Optional[float] = None, reversed_z: bool = True):
+                 projection00: Optional[float] = None, reversed_z: bool = True,
+                 hq_levels: int = 0, sample_set: int = L.SAMPLES_CHECKER, single_pass_stereo: bool = False):
+        """hq_levels / sample_set / single_pass_stereo: variants the reference's shaders and host carry
+        but its command buffer never (or only in VR) uses; see include/meao.h.  ``width`` is the
+        double-wide eye pair when single_pass_stereo is set (AO.cs:339)."""
         self._lib = L.load()
         cfg = L.Config()
         self._lib.meao_default_config(C.byref(cfg))
@@ -43,6 +49,7 @@ class AmbientOcclusion:
         cfg.max_batch = max_batch
         cfg.depth_format = depth_format
         cfg.numerics = numerics
+        cfg.hq_levels, cfg.sample_set = hq_levels, sample_set
         self._cfg = cfg
         prm = L.Params()
         self._lib.meao_default_params(C.byref(prm))
@@ -50,6 +57,7 @@ class AmbientOcclusion:
         if projection00 is not None:
             prm.proj00 = projection00
         prm.reversed_z = 1 if reversed_z else 0
+        prm.single_pass_stereo = 1 if single_pass_stereo else 0
         self._prm = prm
         self._ambient_only = True          # AO.cs:68; composite-only flag, kept for surface parity
         self._debug = 0                    # AO.cs:60
@@ -90,6 +98,8 @@ class AmbientOcclusion:
     projection00 = property(lambda s: s._get("proj00"), lambda s, v: s._set("proj00", float(v)))
     usesReversedZBuffer = property(lambda s: bool(s._get("reversed_z")),
                                    lambda s, v: s._set("reversed_z", 1 if v else 0))
+    singlePassStereoEnabled = property(lambda s: bool(s._get("single_pass_stereo")),       # AO.cs:392-401
+                                       lambda s, v: s._set("single_pass_stereo", 1 if v else 0))
 
     # ---- geometry ----------------------------------------------------------------------
     width = property(lambda s: s._cfg.width)

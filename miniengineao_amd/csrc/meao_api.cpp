@@ -35,6 +35,7 @@ struct meao_ctx {
     char *arena = nullptr;
     uint64_t slot_bytes = 0;
     uint64_t off_linear = 0, off_low[4] = {}, off_occ[4] = {}, off_comb[3] = {};
+    uint64_t off_hq[4] = {};                  // OcclusionHQ<k>: only the levels cfg.hq_levels enables
 
     // lazily allocated: staging for HOST in/out, atlas scratch, selftest counter
     char *stage_depth = nullptr, *stage_out = nullptr, *stage_view = nullptr, *atlas_scratch = nullptr;
@@ -90,6 +91,8 @@ bool config_valid(const meao_config &c, std::string *why)
     if (c.f16_rounding != MEAO_F16_RTZ_CLAMP && c.f16_rounding != MEAO_F16_RTNE) { *why = "unknown f16_rounding"; return false; }
     if (c.max_batch < 1 || c.max_batch > MEAO_MAX_BATCH) { *why = "max_batch must be 1..MEAO_MAX_BATCH"; return false; }
     if (c.depth_format < MEAO_DEPTH_F32 || c.depth_format > MEAO_DEPTH_F16) { *why = "unknown depth_format"; return false; }
+    if (c.hq_levels < 0 || c.hq_levels > c.num_levels) { *why = "hq_levels must be 0..num_levels"; return false; }
+    if (c.sample_set != MEAO_SAMPLES_CHECKER && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE) { *why = "unknown sample_set"; return false; }
     return true;
 }
 
@@ -105,6 +108,8 @@ void layout_slot(meao_ctx *ctx)
     for (int k = 1; k <= 4; ++k) ctx->off_low[k - 1] = take(px(k) * 4);
     for (int k = 1; k <= 4; ++k) ctx->off_occ[k - 1] = take(px(k) * ao_elem(ctx->cfg));
     for (int k = 1; k <= 3; ++k) ctx->off_comb[k - 1] = take(px(k) * ao_elem(ctx->cfg));
+    for (int k = 1; k <= 4; ++k)
+        ctx->off_hq[k - 1] = level_has_hq(ctx->cfg.num_levels, ctx->cfg.hq_levels, k) ? take(px(k) * ao_elem(ctx->cfg)) : 0;
     ctx->slot_bytes = off;
 }
 
@@ -126,7 +131,7 @@ bool exact_rcp_div_applicable(const meao_config &c, const meao_params &p, const 
 
 void update_plan(meao_ctx *ctx)
 {
-    build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->prm, &ctx->plan);
+    build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->cfg.sample_set, ctx->prm, &ctx->plan);
     ctx->exact_rcp_div = exact_rcp_div_applicable(ctx->cfg, ctx->prm, ctx->plan) ? 1 : 0;
     // MEAO_NUMERICS_FAST: raw v_rcp_f32 (2 = DIV_FAST in the kernels); RTZ storage only, like the exact mode
     if (ctx->cfg.numerics == MEAO_NUMERICS_FAST && ctx->cfg.f16_rounding == MEAO_F16_RTZ_CLAMP) ctx->exact_rcp_div = 2;
@@ -161,6 +166,11 @@ int use_device(meao_ctx *ctx)
 template <typename T>
 T *slot_ptr(meao_ctx *ctx, uint64_t off) { return reinterpret_cast<T *>(ctx->arena + off); }
 
+// Launch order on the stream; event i / i+1 of an execute bracket kStreamOrder[i].
+constexpr int kStreamOrder[MEAO_NUM_PASSES] = {MEAO_PASS_DOWNSAMPLE, MEAO_PASS_RENDER, MEAO_PASS_RENDER_HQ,
+                                               MEAO_PASS_UPSAMPLE_3, MEAO_PASS_UPSAMPLE_2, MEAO_PASS_UPSAMPLE_1,
+                                               MEAO_PASS_UPSAMPLE_0};
+
 void fold_profile(meao_ctx *ctx)
 {
     // events of the buffered executes are complete once the last one is
@@ -168,10 +178,11 @@ void fold_profile(meao_ctx *ctx)
     if (ctx->ring_fill == 0) return;
     (void)hipEventSynchronize(ctx->events[(ctx->ring_fill - 1) * per + MEAO_NUM_PASSES]);
     for (int r = 0; r < ctx->ring_fill; ++r) {
-        for (int k = 0; k < MEAO_NUM_PASSES; ++k) {
+        for (int i = 0; i < MEAO_NUM_PASSES; ++i) {
+            const int k = kStreamOrder[i];
             if (!ctx->ran[k]) continue;
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ctx->events[r * per + k], ctx->events[r * per + k + 1]) == hipSuccess)
+            if (hipEventElapsedTime(&ms, ctx->events[r * per + i], ctx->events[r * per + i + 1]) == hipSuccess)
                 ctx->pass_ms_sum[k] += ms;
         }
         ++ctx->pass_samples;
@@ -192,7 +203,8 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         ev = &ctx->events[ctx->ring_fill * per];
         std::memset(ctx->ran, 0, sizeof ctx->ran);
     }
-    auto mark = [&](int k) -> hipError_t { return ev ? hipEventRecord(ev[k], stream) : hipSuccess; };
+    int slot_index = 0;   // position in kStreamOrder
+    auto mark = [&]() -> hipError_t { return ev ? hipEventRecord(ev[slot_index++], stream) : hipSuccess; };
 
     // ---- PushDownsampleCommands (AO.cs:604-658)
     DownsampleArgs ds{};
@@ -209,42 +221,49 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     ds.exact_rcp_div = ctx->exact_rcp_div;
     ds.tiles_x = (p.mip[0].w + 127) / 128;
     ds.tiles_y = (p.mip[0].h + 31) / 32;
-    MEAO_HIP(ctx, mark(0));
+    MEAO_HIP(ctx, mark());
     MEAO_HIP(ctx, launch_downsample(ds, n, stream));
     if (ev) ctx->ran[MEAO_PASS_DOWNSAMPLE] = true;
-    MEAO_HIP(ctx, mark(1));
+    MEAO_HIP(ctx, mark());
 
-    // ---- PushRenderCommands x num_levels (AO.cs:519-522) as one grid
-    RenderArgs rn{};
-    int blocks = 0;
-    for (int l = 1; l <= c.num_levels; ++l) {
-        RenderLevelArgs &L = rn.level[l - 1];
-        const RenderLevelPlan &rp = p.render[l - 1];
-        L.src = slot_ptr<float>(ctx, ctx->off_low[l - 1]);
-        L.dst = slot_ptr<void>(ctx, ctx->off_occ[l - 1]);
-        L.lw = p.mip[l].w; L.lh = p.mip[l].h;
-        L.sw = p.mip[l + 2].w; L.sh = p.mip[l + 2].h;
-        L.tiles_x = (L.lw + kRenTileW - 1) / kRenTileW;
-        L.tiles_y = (L.lh + kRenTileH - 1) / kRenTileH;
-        L.block_begin = blocks;
-        blocks += L.tiles_x * L.tiles_y;
-        L.pad_value = rp.pad_value;
-        for (int t = 0; t < kNumRenderTerms; ++t) {
-            L.inv_thickness[t] = rp.inv_thickness[t];
-            L.front_depth[t] = rp.front_depth[t];
-            L.weight[t] = rp.weight[t];
+    // ---- PushRenderCommands x num_levels (AO.cs:519-522) as one grid; then Render.main (wide)
+    // on LowDepth<k> for the levels cfg.hq_levels enables, also one grid
+    for (int wide = 0; wide < 2; ++wide) {
+        RenderArgs rn{};
+        int blocks = 0, count = 0;
+        for (int l = 1; l <= c.num_levels; ++l) {
+            if (wide && !level_has_hq(c.num_levels, c.hq_levels, l)) continue;
+            RenderLevelArgs &L = rn.level[count++];
+            const RenderLevelPlan &rp = wide ? p.render_hq[l - 1] : p.render[l - 1];
+            L.src = slot_ptr<float>(ctx, ctx->off_low[l - 1]);
+            L.dst = slot_ptr<void>(ctx, wide ? ctx->off_hq[l - 1] : ctx->off_occ[l - 1]);
+            L.lw = p.mip[l].w; L.lh = p.mip[l].h;
+            L.sw = p.mip[l + 2].w; L.sh = p.mip[l + 2].h;
+            L.tiles_x = (L.lw + kRenTileW - 1) / kRenTileW;
+            L.tiles_y = (L.lh + kRenTileH - 1) / kRenTileH;
+            L.block_begin = blocks;
+            blocks += L.tiles_x * L.tiles_y;
+            L.pad_value = rp.pad_value;
+            for (int t = 0; t < rp.terms; ++t) {
+                L.inv_thickness[t] = rp.inv_thickness[t];
+                L.front_depth[t] = rp.front_depth[t];
+                L.weight[t] = rp.weight[t];
+            }
+            L.reject_fadeoff = rp.cb.reject_fadeoff;
+            L.intensity = rp.cb.intensity;
         }
-        L.reject_fadeoff = rp.cb.reject_fadeoff;
-        L.intensity = rp.cb.intensity;
+        rn.frame_stride = ctx->slot_bytes;
+        rn.num_levels = count;
+        rn.blocks_per_frame = blocks;
+        rn.f16_rtne = rtne;
+        rn.exact_rcp_div = ctx->exact_rcp_div;
+        rn.exhaustive = c.sample_set == MEAO_SAMPLES_EXHAUSTIVE;
+        if (count > 0) {
+            MEAO_HIP(ctx, wide ? launch_render_wide(rn, c.ao_format, n, stream) : launch_render(rn, c.ao_format, n, stream));
+            if (ev) ctx->ran[wide ? MEAO_PASS_RENDER_HQ : MEAO_PASS_RENDER] = true;
+        }
+        MEAO_HIP(ctx, mark());
     }
-    rn.frame_stride = ctx->slot_bytes;
-    rn.num_levels = c.num_levels;
-    rn.blocks_per_frame = blocks;
-    rn.f16_rtne = rtne;
-    rn.exact_rcp_div = ctx->exact_rcp_div;
-    MEAO_HIP(ctx, launch_render(rn, c.ao_format, n, stream));
-    if (ev) ctx->ran[MEAO_PASS_RENDER] = true;
-    MEAO_HIP(ctx, mark(2));
 
     // ---- PushUpsampleCommands chain (AO.cs:528-531), generalised to num_levels
     const void *lo_ao = slot_ptr<void>(ctx, ctx->off_occ[c.num_levels - 1]);
@@ -255,6 +274,8 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             const meao_upsample_constants &k = p.upsample[hi];   // low level = hi + 1
             up.lo_depth = slot_ptr<float>(ctx, ctx->off_low[hi]);
             up.lo_ao = lo_ao;
+            // main_premin*: the Render.main output of the low level is min-combined in PrefetchData
+            up.lo_ao2 = level_has_hq(c.num_levels, c.hq_levels, hi + 1) ? slot_ptr<void>(ctx, ctx->off_hq[hi]) : nullptr;
             up.frame_stride = ctx->slot_bytes;
             up.lw = p.mip[hi + 1].w; up.lh = p.mip[hi + 1].h;
             up.hw = p.mip[hi].w; up.hh = p.mip[hi].h;
@@ -279,7 +300,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             MEAO_HIP(ctx, launch_upsample(up, c.ao_format, hi == 0, n, stream));
             if (ev) ctx->ran[pass] = true;
         }
-        MEAO_HIP(ctx, mark(pass + 1));
+        MEAO_HIP(ctx, mark());
     }
     if (ev) ++ctx->ring_fill;
     for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
@@ -363,7 +384,17 @@ int32_t meao_render_constants_for(int32_t width, int32_t height, const meao_para
 {
     if (width < 1 || height < 1 || !p || !out || level < 1 || level > 4 || !params_valid(*p))
         return MEAO_ERR_INVALID_ARGUMENT;
-    render_constants(width, height, *p, level, out);
+    render_constants(width, height, *p, level, true, MEAO_SAMPLES_CHECKER, out);
+    return MEAO_OK;
+}
+
+int32_t meao_render_constants_variant(int32_t width, int32_t height, const meao_params *p, int32_t level,
+                                      int32_t source_tiled, int32_t sample_set, meao_render_constants *out)
+{
+    if (width < 1 || height < 1 || !p || !out || level < 1 || level > 4 || !params_valid(*p))
+        return MEAO_ERR_INVALID_ARGUMENT;
+    if (sample_set != MEAO_SAMPLES_CHECKER && sample_set != MEAO_SAMPLES_EXHAUSTIVE) return MEAO_ERR_INVALID_ARGUMENT;
+    render_constants(width, height, *p, level, source_tiled != 0, sample_set, out);
     return MEAO_OK;
 }
 
@@ -388,7 +419,7 @@ int32_t meao_algorithmic_bytes(const meao_config *cfg, uint64_t bytes[MEAO_NUM_P
 {
     std::string why;
     if (!cfg || !bytes || !config_valid(*cfg, &why)) return MEAO_ERR_INVALID_ARGUMENT;
-    algorithmic_bytes(cfg->width, cfg->height, cfg->num_levels, cfg->ao_format, cfg->depth_format, bytes);
+    algorithmic_bytes(cfg->width, cfg->height, cfg->num_levels, cfg->hq_levels, cfg->ao_format, cfg->depth_format, bytes);
     return MEAO_OK;
 }
 
@@ -593,8 +624,13 @@ static int locate_debug_buffer(meao_ctx *ctx, int32_t frame, int32_t debug_id, c
     } else if (debug_id <= 16) {
         if (debug_id - 13 > nl - 1) return fail(ctx, MEAO_ERR_UNSUPPORTED, "debug buffer: level not combined (num_levels)");
         *out_src = slot + ctx->off_comb[debug_id - 14];
-    } else {
+    } else if (debug_id == 17) {
         *out_src = ctx->last_out[frame];
+    } else {
+        const int level = debug_id - MEAO_DEBUG_OCCLUSION_HQ1 + 1;
+        if (!level_has_hq(nl, ctx->cfg.hq_levels, level))
+            return fail(ctx, MEAO_ERR_UNSUPPORTED, "debug buffer: this level has no Render.main pass (hq_levels)");
+        *out_src = slot + ctx->off_hq[level - 1];
     }
     return MEAO_OK;
 }
@@ -605,7 +641,7 @@ int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id, vo
     if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
     meao_desc d{};
     if (!describe_buffer(ctx->cfg.width, ctx->cfg.height, ctx->cfg.ao_format, debug_id, &d))
-        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: debug_id must be 1..17");
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: debug_id must be 1..21");
     if (out_desc) *out_desc = d;
     if (!dst) return MEAO_OK;
     if (frame < 0 || frame >= ctx->last_frames)
@@ -629,7 +665,7 @@ int32_t meao_debug_view(meao_ctx *ctx, int32_t frame, int32_t debug_id, void *ou
     if (!ctx || !out) return MEAO_ERR_INVALID_ARGUMENT;
     meao_desc d{};
     if (!describe_buffer(ctx->cfg.width, ctx->cfg.height, ctx->cfg.ao_format, debug_id, &d))
-        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_view: debug_id must be 1..17");
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_view: debug_id must be 1..21");
     if (frame < 0 || frame >= ctx->last_frames)
         return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_view: frame not produced by the last execute");
     if (out_loc != MEAO_MEM_HOST && out_loc != MEAO_MEM_DEVICE) return MEAO_ERR_INVALID_ARGUMENT;

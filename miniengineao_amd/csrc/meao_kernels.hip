@@ -59,6 +59,10 @@ template <bool RTNE>
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float x)
 {
     if constexpr (RTNE) {
+        // The value is pinned in a VGPR first: without it LLVM folds "round(a * b)" into
+        // v_fma_mixlo_f16 a, b, +0, which returns +0 for a product of -0 (seen in the composite
+        // kernel, caught by tests/test_composite.py) -- the conversion must stay a plain v_cvt_f16_f32.
+        asm volatile("" : "+v"(x));
         const _Float16 h = static_cast<_Float16>(x);
         return __builtin_bit_cast(uint16_t, h);
     } else {
@@ -350,13 +354,13 @@ __device__ __forceinline__ float2v test_sample_pair2(const float *centre, int of
                    test_sample_pair(s1.y, s2.y, inv_range.y, neg_front, reject)};
 }
 
-// TestSamples (REN:77-110).  (X, Y) are slice-texel offsets; one slice texel is 4 level
-// texels (4x4 interleave), so the LDS offset of (dx, dy) is 4*dy*pitch + 4*dx.
-template <int X, int Y>
+// TestSamples (REN:77-110).  (X, Y) are sample offsets in source texels; the LDS offset of
+// (dx, dy) is dy*P + dx*Q.  Interleaved: one slice texel is 4 level texels (4x4 interleave),
+// P = 4*pitch, Q = 4.  Wide (REN:79-82, x <<= 1): P = 2*pitch, Q = 2.
+template <int X, int Y, int P, int Q>
 __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv_depth, float inv_thickness,
                                                 float front_depth, float reject)
 {
-    constexpr int P = 4 * kRenLdsW, Q = 4;
     const float2v inv_range = splat(inv_thickness) * inv_depth;
     const float neg_front = -front_depth;
     if constexpr (Y == 0) {
@@ -373,7 +377,29 @@ __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv
     }
 }
 
-template <int AOFMT, bool RTNE, int DIV>
+// ao = sum over the terms of weight * TestSamples, in the reference's accumulation order:
+// checker set REN:162-168 (slots 1,3,4,8,11,6,10), SAMPLE_EXHAUSTIVELY REN:146-157
+// (slots 0,1,2,3,4,8,11,5,6,7,9,10).  L.weight[] etc. are already in term order.
+template <bool EXH, int P, int Q>
+__device__ __forceinline__ float2v accumulate_terms(const RenderLevelArgs &L, const float *centre, float2v inv_depth)
+{
+    const float reject = L.reject_fadeoff;
+    float2v ao = splat(0.0f);
+#define MEAO_TERM(N, X, Y) \
+    ao = fma2(splat(L.weight[N]), test_samples<X, Y, P, Q>(centre, inv_depth, L.inv_thickness[N], L.front_depth[N], reject), ao)
+    if constexpr (EXH) {
+        MEAO_TERM(0, 1, 0); MEAO_TERM(1, 2, 0); MEAO_TERM(2, 3, 0); MEAO_TERM(3, 4, 0);
+        MEAO_TERM(4, 1, 1); MEAO_TERM(5, 2, 2); MEAO_TERM(6, 3, 3); MEAO_TERM(7, 1, 2);
+        MEAO_TERM(8, 1, 3); MEAO_TERM(9, 1, 4); MEAO_TERM(10, 2, 3); MEAO_TERM(11, 2, 4);
+    } else {
+        MEAO_TERM(0, 2, 0); MEAO_TERM(1, 4, 0); MEAO_TERM(2, 1, 1); MEAO_TERM(3, 2, 2);
+        MEAO_TERM(4, 3, 3); MEAO_TERM(5, 1, 3); MEAO_TERM(6, 2, 4);
+    }
+#undef MEAO_TERM
+    return fma2(splat(L.intensity), ao - splat(1.0f), splat(1.0f));   // lerp(1, ao, gIntensity) REN:176
+}
+
+template <int AOFMT, bool RTNE, int DIV, bool EXH>
 __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
 {
     __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * kRenLdsW];
@@ -427,7 +453,6 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
     const int X = X0 + 2 * txl;
     if (X >= lw) return;
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
-    const float reject = L.reject_fadeoff;
     const bool pair_store = ((lw & 1) == 0);
 
 #pragma unroll 1
@@ -437,16 +462,65 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
         const float *centre = &tile[(ly + kRenApron) * kRenLdsW + 2 * txl + kRenApron];
         const float2v c = *reinterpret_cast<const float2v *>(centre);
         const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-        // REN:162-168, accumulation order and table slots 1,3,4,8,11,6,10
-        float2v ao = splat(0.0f);
-        ao = fma2(splat(L.weight[0]), test_samples<2, 0>(centre, inv_depth, L.inv_thickness[0], L.front_depth[0], reject), ao);
-        ao = fma2(splat(L.weight[1]), test_samples<4, 0>(centre, inv_depth, L.inv_thickness[1], L.front_depth[1], reject), ao);
-        ao = fma2(splat(L.weight[2]), test_samples<1, 1>(centre, inv_depth, L.inv_thickness[2], L.front_depth[2], reject), ao);
-        ao = fma2(splat(L.weight[3]), test_samples<2, 2>(centre, inv_depth, L.inv_thickness[3], L.front_depth[3], reject), ao);
-        ao = fma2(splat(L.weight[4]), test_samples<3, 3>(centre, inv_depth, L.inv_thickness[4], L.front_depth[4], reject), ao);
-        ao = fma2(splat(L.weight[5]), test_samples<1, 3>(centre, inv_depth, L.inv_thickness[5], L.front_depth[5], reject), ao);
-        ao = fma2(splat(L.weight[6]), test_samples<2, 4>(centre, inv_depth, L.inv_thickness[6], L.front_depth[6], reject), ao);
-        const float2v out = fma2(splat(L.intensity), ao - splat(1.0f), splat(1.0f));   // lerp(1, ao, gIntensity) REN:176
+        const float2v out = accumulate_terms<EXH, 4 * kRenLdsW, 4>(L, centre, inv_depth);
+
+        typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
+        const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
+        if (pair_store) {
+            typename AO::type2 pr; pr.x = e0; pr.y = e1;
+            *reinterpret_cast<typename AO::type2 *>(p) = pr;
+        } else {
+            p[0] = e0;
+            if (X + 1 < lw) p[1] = e1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Render.main (WIDE_SAMPLING, REN:22,27-29,46-50): the same estimator on the NON-tiled f32
+// LowDepth<level>, sampling every other texel (offsets doubled, REN:79-82) out to 8 texels, one
+// output texel per source texel (REN:174).  The reference's host never dispatches it; it is
+// the "high quality" pass of the MiniEngine original and feeds Upsample.main_premin*.
+// Tile 64 x 32 outputs, LDS window (64+16) x (32+16) of raw f32 depth with clamp addressing
+// (REN:116,121 Gather on the 2D texture); no f16 round trip, no padding texels.
+template <int AOFMT, bool RTNE, int DIV, bool EXH>
+__global__ __launch_bounds__(kThreads) void render_wide_kernel(const RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kWideLdsH * kWideLdsW];
+    typedef AoTexel<AOFMT> AO;
+
+    const int frame = blockIdx.y;
+    int b = blockIdx.x, lv = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < a.num_levels && b >= a.level[k].block_begin) lv = k;
+    const RenderLevelArgs &L = a.level[lv];
+    b -= L.block_begin;
+    const int X0 = (b % L.tiles_x) * kRenTileW, Y0 = (b / L.tiles_x) * kRenTileH;
+    const int lw = L.lw, lh = L.lh;
+    const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, frame);
+
+    for (int i = threadIdx.x; i < kWideLdsW * kWideLdsH; i += kThreads) {
+        const int c = i % kWideLdsW, r = i / kWideLdsW;
+        const int x = clampi(X0 - kWideApron + c, 0, lw - 1), y = clampi(Y0 - kWideApron + r, 0, lh - 1);
+        tile[i] = src[static_cast<size_t>(y) * lw + x];
+    }
+    __syncthreads();
+
+    const int txl = threadIdx.x & 31, tyl = threadIdx.x >> 5;
+    const int X = X0 + 2 * txl;
+    if (X >= lw) return;
+    typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
+    const bool pair_store = ((lw & 1) == 0);
+
+#pragma unroll 1
+    for (int k = 0; k < kRenTileH / 8; ++k) {
+        const int ly = tyl + 8 * k, Y = Y0 + ly;
+        if (Y >= lh) break;
+        const float *centre = &tile[(ly + kWideApron) * kWideLdsW + 2 * txl + kWideApron];
+        const float2v c = *reinterpret_cast<const float2v *>(centre);
+        const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
+        const float2v out = accumulate_terms<EXH, 2 * kWideLdsW, 2>(L, centre, inv_depth);
 
         typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
         const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
@@ -556,6 +630,8 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
     const int lw = a.lw, lh = a.lh, hw = a.hw, hh = a.hh;
     const float *__restrict__ lo_depth = frame_ptr(a.lo_depth, a.frame_stride, frame);
     const ao_t *__restrict__ lo_ao = frame_ptr(static_cast<const ao_t *>(a.lo_ao), a.frame_stride, frame);
+    // main_premin*: LoResAO1 = min(LoResAO1, LoResAO2) (COMBINE_LOWER_RESOLUTIONS, UPS:58-60)
+    const ao_t *__restrict__ lo_ao2 = a.lo_ao2 ? frame_ptr(static_cast<const ao_t *>(a.lo_ao2), a.frame_stride, frame) : nullptr;
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
@@ -571,7 +647,12 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
             const float4v d4 = *reinterpret_cast<const float4v *>(lo_depth + idx);
             const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
             const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
-            const float av[4] = {AO::decode(a4.x), AO::decode(a4.y), AO::decode(a4.z), AO::decode(a4.w)};
+            float av[4] = {AO::decode(a4.x), AO::decode(a4.y), AO::decode(a4.z), AO::decode(a4.w)};
+            if (lo_ao2) {
+                const typename AO::type4 b4 = *reinterpret_cast<const typename AO::type4 *>(lo_ao2 + idx);
+                av[0] = __builtin_fminf(av[0], AO::decode(b4.x)); av[1] = __builtin_fminf(av[1], AO::decode(b4.y));
+                av[2] = __builtin_fminf(av[2], AO::decode(b4.z)); av[3] = __builtin_fminf(av[3], AO::decode(b4.w));
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * k + e - 1;
@@ -590,7 +671,9 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
             const float d = lo_depth[idx];
             s_dep[r * T::kRawPitch + c] = d;
             s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
-            s_ao[r * T::kRawPitch + c] = AO::decode(lo_ao[idx]);
+            float av = AO::decode(lo_ao[idx]);
+            if (lo_ao2) av = __builtin_fminf(av, AO::decode(lo_ao2[idx]));
+            s_ao[r * T::kRawPitch + c] = av;
         }
     }
     __syncthreads();
@@ -823,10 +906,7 @@ __global__ __launch_bounds__(kThreads) void debug_view_kernel(const DebugViewArg
 // Composite (Blit.shader:66-134): pure streaming, 17 bytes per texel (RGBA16F read + write, AO).
 // One lane = 4 texels = two 16-byte colour loads/stores + one 4-byte (R8) AO load.
 
-__device__ __forceinline__ uint16_t f32_to_f16_rtne_bits(float x)
-{
-    return __builtin_bit_cast(uint16_t, static_cast<_Float16>(x));
-}
+__device__ __forceinline__ uint16_t f32_to_f16_rtne_bits(float x) { return f32_to_f16_bits<true>(x); }
 
 template <int AOFMT>
 __global__ __launch_bounds__(kThreads) void composite_kernel(const CompositeArgs a)
@@ -944,21 +1024,46 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s)
+// WIDE selects render_wide_kernel; the (AOFMT, RTNE, DIV, EXH) choice is the same for both.
+template <bool WIDE, int AOFMT, bool RTNE, int DIV>
+static void launch_render_t(const RenderArgs &a, dim3 grid, hipStream_t s)
 {
-    const dim3 grid(a.blocks_per_frame, frames, 1), block(kThreads);
-    if (ao_format == MEAO_AO_R8) {
-        if (a.f16_rtne) render_kernel<MEAO_AO_R8, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
-        else if (a.exact_rcp_div == 2) render_kernel<MEAO_AO_R8, false, DIV_FAST><<<grid, block, 0, s>>>(a);
-        else if (a.exact_rcp_div) render_kernel<MEAO_AO_R8, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
-        else render_kernel<MEAO_AO_R8, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
+    const dim3 block(kThreads);
+    if constexpr (WIDE) {
+        if (a.exhaustive) render_wide_kernel<AOFMT, RTNE, DIV, true><<<grid, block, 0, s>>>(a);
+        else render_wide_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);
     } else {
-        if (a.f16_rtne) render_kernel<MEAO_AO_F16, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
-        else if (a.exact_rcp_div == 2) render_kernel<MEAO_AO_F16, false, DIV_FAST><<<grid, block, 0, s>>>(a);
-        else if (a.exact_rcp_div) render_kernel<MEAO_AO_F16, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
-        else render_kernel<MEAO_AO_F16, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        if (a.exhaustive) render_kernel<AOFMT, RTNE, DIV, true><<<grid, block, 0, s>>>(a);
+        else render_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);
+    }
+}
+
+template <bool WIDE>
+static hipError_t launch_render_any(const RenderArgs &a, int ao_format, int frames, hipStream_t s)
+{
+    const dim3 grid(a.blocks_per_frame, frames, 1);
+    if (ao_format == MEAO_AO_R8) {
+        if (a.f16_rtne) launch_render_t<WIDE, MEAO_AO_R8, true, DIV_IEEE>(a, grid, s);
+        else if (a.exact_rcp_div == 2) launch_render_t<WIDE, MEAO_AO_R8, false, DIV_FAST>(a, grid, s);
+        else if (a.exact_rcp_div) launch_render_t<WIDE, MEAO_AO_R8, false, DIV_EXACT_RCP>(a, grid, s);
+        else launch_render_t<WIDE, MEAO_AO_R8, false, DIV_IEEE>(a, grid, s);
+    } else {
+        if (a.f16_rtne) launch_render_t<WIDE, MEAO_AO_F16, true, DIV_IEEE>(a, grid, s);
+        else if (a.exact_rcp_div == 2) launch_render_t<WIDE, MEAO_AO_F16, false, DIV_FAST>(a, grid, s);
+        else if (a.exact_rcp_div) launch_render_t<WIDE, MEAO_AO_F16, false, DIV_EXACT_RCP>(a, grid, s);
+        else launch_render_t<WIDE, MEAO_AO_F16, false, DIV_IEEE>(a, grid, s);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s)
+{
+    return launch_render_any<false>(a, ao_format, frames, s);
+}
+
+hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s)
+{
+    return launch_render_any<true>(a, ao_format, frames, s);
 }
 
 template <int AOFMT, bool RTNE, int DIV>

@@ -38,7 +38,7 @@ struct RenderLevelArgs {
     int32_t tiles_x, tiles_y;
     int32_t block_begin;   // first linear workgroup id of this level
     float pad_value;       // value of atlas texels beyond the level
-    float inv_thickness[7], front_depth[7], weight[7];
+    float inv_thickness[12], front_depth[12], weight[12];   // per term, accumulation order
     float reject_fadeoff, intensity;
 };
 
@@ -49,7 +49,14 @@ struct RenderArgs {
     int32_t blocks_per_frame;
     int32_t f16_rtne;
     int32_t exact_rcp_div;
+    int32_t exhaustive;    // SAMPLE_EXHAUSTIVELY: 12 terms instead of 7
 };
+
+// Render.main (WIDE_SAMPLING, non-interleaved) on the non-tiled LowDepth<level>: same args; `src`
+// is sampled directly (f32, clamp addressing), sw/sh/pad_value are unused, `level[]` holds only
+// the levels that have the pass (num_levels = their count).
+constexpr int kWideApron = 8;                   // 4 samples * stride 2
+constexpr int kWideLdsW = kRenTileW + 2 * kWideApron, kWideLdsH = kRenTileH + 2 * kWideApron;
 
 // ---------------------------------------------------------------------------------------
 // Upsample (Upsample.main / main_blendout)
@@ -62,6 +69,7 @@ constexpr int ups_tile_h(bool final_pass) { return final_pass ? 64 : 32; }
 struct UpsampleArgs {
     const float *lo_depth;     // LoResDB  f32
     const void *lo_ao;         // LoResAO1
+    const void *lo_ao2;        // LoResAO2 of main_premin* (min-combined in PrefetchData), or nullptr
     const void *hi_depth;      // HiResDB  f32, or f16 in the final pass
     const void *hi_ao;         // HiResAO, nullptr in the final pass
     void *dst[MEAO_MAX_BATCH]; // per-frame destination (caller-owned in the final pass)
@@ -85,6 +93,7 @@ struct TileAtlasArgs {
 
 hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s);
 hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
+hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
 hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s);

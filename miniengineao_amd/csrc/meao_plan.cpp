@@ -8,7 +8,14 @@
 
 namespace meao {
 
-const int kRenderTermSlot[kNumRenderTerms] = {1, 3, 4, 8, 11, 6, 10};
+int render_term_slots(int sample_set, const int **slots)
+{
+    static const int checker[7] = {1, 3, 4, 8, 11, 6, 10};
+    static const int exhaustive[12] = {0, 1, 2, 3, 4, 8, 11, 5, 6, 7, 9, 10};
+    const bool all = sample_set == MEAO_SAMPLES_EXHAUSTIVE;
+    *slots = all ? exhaustive : checker;
+    return all ? 12 : 7;
+}
 
 Dims level_dims(int width, int height, int level)
 {
@@ -51,24 +58,29 @@ void sample_thickness(float out[12])
     }
 }
 
-void render_constants(int width, int height, const meao_params &p, int level,
-                      meao_render_constants *out)
+void render_constants(int width, int height, const meao_params &p, int level, bool source_tiled,
+                      int sample_set, meao_render_constants *out)
 {
-    const Dims slice = level_dims(width, height, level + 2);  // TiledDepth<level> (AO.cs:461-464)
+    // source = TiledDepth<level> (dims of mip level+2, AO.cs:461-464) or the non-tiled LowDepth<level>
+    const Dims slice = level_dims(width, height, source_tiled ? level + 2 : level);
     float thickness[12];
     sample_thickness(thickness);
 
     const float tan_half_fov_h = 1.0f / p.proj00;  // AO.cs:572
-    // AO.cs:678: 2 * TanHalfFovH * ScreenspaceDiameter / source.width (tiled: no extra *2)
+    // AO.cs:678: 2 * TanHalfFovH * ScreenspaceDiameter / source.width
     float multiplier = 2.0f * tan_half_fov_h;
     multiplier = multiplier * 10.0f;
     multiplier = multiplier / static_cast<float>(slice.w);
+    if (!source_tiled) multiplier = multiplier * 2.0f;            // AO.cs:679
+    if (p.single_pass_stereo) multiplier = multiplier * 2.0f;     // AO.cs:680
     const float inverse_range_factor = 1.0f / multiplier;  // AO.cs:683
     for (int i = 0; i < 12; ++i)
         out->inv_thickness_table[i] = inverse_range_factor / thickness[i];  // AO.cs:688
 
     // AO.cs:696-707 sample multiplicities; AO.cs:711-715 zero the exhaustive-only slots.
-    static const float multiplicity[12] = {0, 4, 0, 4, 4, 0, 8, 0, 4, 0, 8, 4};
+    static const float checker[12] = {0, 4, 0, 4, 4, 0, 8, 0, 4, 0, 8, 4};
+    static const float exhaustive[12] = {4, 4, 4, 4, 4, 8, 8, 8, 4, 8, 8, 4};
+    const float *multiplicity = sample_set == MEAO_SAMPLES_EXHAUSTIVE ? exhaustive : checker;
     float total = 0.0f;
     for (int i = 0; i < 12; ++i) {
         out->sample_weight_table[i] = multiplicity[i] == 0.0f ? 0.0f : multiplicity[i] * thickness[i];
@@ -126,7 +138,18 @@ bool params_valid(const meao_params &p)
     return true;
 }
 
-void build_plan(int width, int height, int num_levels, const meao_params &p, Plan *out)
+static void fill_terms(RenderLevelPlan &r, int sample_set)
+{
+    const int *slots;
+    r.terms = render_term_slots(sample_set, &slots);
+    for (int t = 0; t < r.terms; ++t) {
+        r.inv_thickness[t] = r.cb.inv_thickness_table[slots[t]];
+        r.front_depth[t] = r.inv_thickness[t] - 0.5f;  // Render.compute:85
+        r.weight[t] = r.cb.sample_weight_table[slots[t]];
+    }
+}
+
+void build_plan(int width, int height, int num_levels, int sample_set, const meao_params &p, Plan *out)
 {
     out->width = width;
     out->height = height;
@@ -136,13 +159,12 @@ void build_plan(int width, int height, int num_levels, const meao_params &p, Pla
     const float pad12 = linearize_out_of_range(out->zbuffer_params, p.reversed_z != 0);
     for (int level = 1; level <= 4; ++level) {
         RenderLevelPlan &r = out->render[level - 1];
-        render_constants(width, height, p, level, &r.cb);
-        for (int t = 0; t < kNumRenderTerms; ++t) {
-            const int slot = kRenderTermSlot[t];
-            r.inv_thickness[t] = r.cb.inv_thickness_table[slot];
-            r.front_depth[t] = r.inv_thickness[t] - 0.5f;  // Render.compute:85
-            r.weight[t] = r.cb.sample_weight_table[slot];
-        }
+        render_constants(width, height, p, level, true, sample_set, &r.cb);
+        fill_terms(r, sample_set);
+        RenderLevelPlan &q = out->render_hq[level - 1];
+        render_constants(width, height, p, level, false, sample_set, &q.cb);
+        fill_terms(q, sample_set);
+        q.pad_value = 0.0f;                              // unused: the 2D source clamps
         // Atlas padding: TiledDepth1/2 hold Linearize(out-of-range) (Downsample1.compute:39-46,
         // 70-78), TiledDepth3/4 hold the 0 of an out-of-range DS4x load (Downsample2.compute:35).
         r.pad_value = level <= 2 ? pad12 : 0.0f;
@@ -152,7 +174,7 @@ void build_plan(int width, int height, int num_levels, const meao_params &p, Pla
 
 bool describe_buffer(int width, int height, int ao_format, int debug_id, meao_desc *out)
 {
-    if (debug_id < 1 || debug_id > kNumDebugBuffers) return false;
+    if (debug_id < 1 || debug_id > MEAO_NUM_BUFFERS) return false;
     // AO.cs:453-475 in _debug order (AO.cs:789-808): id, mip level, format class, tiled
     int level, fmt, slices = 1;
     const int ao_fmt = ao_format == MEAO_AO_R8 ? MEAO_FMT_UNORM8 : MEAO_FMT_F16;
@@ -161,7 +183,8 @@ bool describe_buffer(int width, int height, int ao_format, int debug_id, meao_de
     else if (debug_id <= 9) { level = debug_id - 3; fmt = MEAO_FMT_F16; slices = 16; } // TiledDepth1..4 = L3..L6
     else if (debug_id <= 13) { level = debug_id - 9; fmt = ao_fmt; }                  // Occlusion1..4
     else if (debug_id <= 16) { level = debug_id - 13; fmt = ao_fmt; }                 // Combined1..3
-    else { level = 0; fmt = ao_fmt; }                                                 // AmbientOcclusion
+    else if (debug_id == 17) { level = 0; fmt = ao_fmt; }                             // AmbientOcclusion
+    else { level = debug_id - MEAO_DEBUG_OCCLUSION_HQ1 + 1; fmt = ao_fmt; }           // OcclusionHQ1..4
     const Dims d = level_dims(width, height, level);
     const uint64_t elem = fmt == MEAO_FMT_F32 ? 4 : (fmt == MEAO_FMT_F16 ? 2 : 1);
     out->debug_id = debug_id;
@@ -178,7 +201,7 @@ uint64_t depth_elem(int depth_format)
     return (depth_format == MEAO_DEPTH_F32 || depth_format == MEAO_DEPTH_UNORM24) ? 4 : 2;
 }
 
-void algorithmic_bytes(int width, int height, int num_levels, int ao_format, int depth_format,
+void algorithmic_bytes(int width, int height, int num_levels, int hq_levels, int ao_format, int depth_format,
                        uint64_t bytes[MEAO_NUM_PASSES])
 {
     uint64_t p[kNumMips];
@@ -196,6 +219,11 @@ void algorithmic_bytes(int width, int height, int num_levels, int ao_format, int
     for (int hi = num_levels - 1; hi >= 1; --hi)  // lo (f32 + AO), hi (f32 + AO), out AO
         bytes[MEAO_PASS_UPSAMPLE_0 - hi] = (4 + a) * p[hi + 1] + (4 + a) * p[hi] + a * p[hi];
     bytes[MEAO_PASS_UPSAMPLE_0] = (4 + a) * p[1] + 2 * p[0] + a * p[0];
+    for (int l = 1; l <= num_levels; ++l) {
+        if (!level_has_hq(num_levels, hq_levels, l)) continue;
+        bytes[MEAO_PASS_RENDER_HQ] += 4 * p[l] + a * p[l];   // f32 LowDepth<l> in, AO out
+        bytes[MEAO_PASS_UPSAMPLE_0 - (l - 1)] += a * p[l];   // LoResAO2 of the pass that consumes level l
+    }
 }
 
 }  // namespace meao

@@ -16,16 +16,18 @@ constexpr int kNumDebugBuffers = 17;
 
 struct Dims { int w = 0, h = 0; };
 
-// Render taps actually used by the 36-sample checker set, in accumulation order
-// (Render.compute:162-168): table slots 1,3,4,8,11,6,10.
-constexpr int kNumRenderTerms = 7;
-extern const int kRenderTermSlot[kNumRenderTerms];
+// Render terms in accumulation order: the 36-sample checker set uses table slots
+// 1,3,4,8,11,6,10 (Render.compute:162-168), SAMPLE_EXHAUSTIVELY all twelve in the order
+// 0,1,2,3,4,8,11,5,6,7,9,10 (Render.compute:146-157).
+constexpr int kMaxRenderTerms = 12;
+int render_term_slots(int sample_set, const int **slots);   // returns the number of terms
 
 struct RenderLevelPlan {
     meao_render_constants cb;                 // the reference's constant block, verbatim
-    float inv_thickness[kNumRenderTerms];     // cb.inv_thickness_table[slot]
-    float front_depth[kNumRenderTerms];       // inv_thickness - 0.5   (Render.compute:85)
-    float weight[kNumRenderTerms];            // cb.sample_weight_table[slot]
+    int terms;
+    float inv_thickness[kMaxRenderTerms];     // cb.inv_thickness_table[slot]
+    float front_depth[kMaxRenderTerms];       // inv_thickness - 0.5   (Render.compute:85)
+    float weight[kMaxRenderTerms];            // cb.sample_weight_table[slot]
     float pad_value;                          // what an out-of-level atlas texel holds
 };
 
@@ -33,25 +35,28 @@ struct Plan {
     int width = 0, height = 0, num_levels = 4;
     Dims mip[kNumMips];
     float zbuffer_params[4];
-    RenderLevelPlan render[4];                // level 1..4 -> [0..3]
+    RenderLevelPlan render[4];                // level 1..4 -> [0..3], source TiledDepth<level>
+    RenderLevelPlan render_hq[4];             // Render.main on LowDepth<level> (cfg.hq_levels)
     meao_upsample_constants upsample[4];      // low level 1..4 -> [0..3]
 };
 
 Dims level_dims(int width, int height, int level);
 void zbuffer_params(const meao_params &p, float out[4]);
 void sample_thickness(float out[12]);
-void render_constants(int width, int height, const meao_params &p, int level,
-                      meao_render_constants *out);
+void render_constants(int width, int height, const meao_params &p, int level, bool source_tiled,
+                      int sample_set, meao_render_constants *out);
 void upsample_constants(int width, int height, const meao_params &p, int low_level,
                         meao_upsample_constants *out);
 // Linearize() of an out-of-range depth load (Downsample1.compute:39-46).
 float linearize_out_of_range(const float zp[4], bool reversed_z);
 bool params_valid(const meao_params &p);
-void build_plan(int width, int height, int num_levels, const meao_params &p, Plan *out);
+void build_plan(int width, int height, int num_levels, int sample_set, const meao_params &p, Plan *out);
+// level k (1..4) has a Render.main pass iff it is one of the coarsest hq_levels rendered levels
+inline bool level_has_hq(int num_levels, int hq_levels, int k) { return k <= num_levels && k > num_levels - hq_levels; }
 
 bool describe_buffer(int width, int height, int ao_format, int debug_id, meao_desc *out);
 uint64_t depth_elem(int depth_format);   // bytes per input depth texel
-void algorithmic_bytes(int width, int height, int num_levels, int ao_format, int depth_format,
+void algorithmic_bytes(int width, int height, int num_levels, int hq_levels, int ao_format, int depth_format,
                        uint64_t bytes[MEAO_NUM_PASSES]);
 
 }  // namespace meao

@@ -34,6 +34,9 @@ for k in range(count):
                    blur_tolerance=float(rng.uniform(-8, -1)), upsample_tolerance=float(rng.uniform(-12, -1)),
                    thickness_modifier=float(rng.uniform(1, 10)), intensity=float(rng.uniform(0, 2)),
                    depth_format=depth_format)
+    if k % 2:
+        s.hq_levels, s.sample_set = int(rng.integers(0, s.num_levels + 1)), int(rng.integers(0, 2))
+        s.single_pass_stereo = bool(rng.integers(0, 2))
     raw = synth.occluder_field(w, h, seed=k, n_rects=20, n_discs=20, cam=cam)
     if k % 3 == 0:
         x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
@@ -43,12 +46,13 @@ for k in range(count):
     from miniengineao_amd import AmbientOcclusion
     ao = AmbientOcclusion(w, h, num_levels=s.num_levels, ao_format=s.ao_format, f16_rounding=s.f16_rounding,
                           depth_format=depth_format, near_clip=s.near_clip, far_clip=s.far_clip,
-                          projection00=s.proj00, reversed_z=reversed_z, max_batch=2)
+                          projection00=s.proj00, reversed_z=reversed_z, max_batch=2, hq_levels=s.hq_levels,
+                          sample_set=s.sample_set, single_pass_stereo=s.single_pass_stereo)
     ao.noiseFilterTolerance, ao.blurTolerance, ao.upsampleTolerance = s.noise_filter_tolerance, s.blur_tolerance, s.upsample_tolerance
     ao.thicknessModifier, ao.intensity = s.thickness_modifier, s.intensity
     outs = ao.render_batch([depth, depth])
     ok = np.array_equal(outs[0], want["result"]) and np.array_equal(outs[1], want["result"])
-    for i in H.valid_debug_ids(s.num_levels):
+    for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
         ok = ok and np.array_equal(ao.debug_buffer(i, frame=1), want[H.NAMES[i]])
     ao.close()
     if not ok:

@@ -9,7 +9,8 @@ from miniengineao_amd import synth
 NAMES = {1: "linear_depth", 2: "low_depth1", 3: "low_depth2", 4: "low_depth3", 5: "low_depth4",
          6: "tiled_depth1", 7: "tiled_depth2", 8: "tiled_depth3", 9: "tiled_depth4",
          10: "occlusion1", 11: "occlusion2", 12: "occlusion3", 13: "occlusion4",
-         14: "combined1", 15: "combined2", 16: "combined3", 17: "result"}
+         14: "combined1", 15: "combined2", 16: "combined3", 17: "result",
+         18: "occlusion_hq1", 19: "occlusion_hq2", 20: "occlusion_hq3", 21: "occlusion_hq4"}
 
 
 def settings(O, w, h, cam=synth.DEFAULT_CAMERA, **kw):
@@ -23,7 +24,8 @@ def component(s, max_batch=1, device=0):
     ao = AmbientOcclusion(s.width, s.height, device=device, num_levels=s.num_levels,
                           ao_format=s.ao_format, f16_rounding=s.f16_rounding, max_batch=max_batch,
                           near_clip=s.near_clip, far_clip=s.far_clip, projection00=s.proj00,
-                          reversed_z=s.reversed_z)
+                          reversed_z=s.reversed_z, hq_levels=s.hq_levels, sample_set=s.sample_set,
+                          single_pass_stereo=s.single_pass_stereo)
     ao.noiseFilterTolerance = s.noise_filter_tolerance
     ao.blurTolerance = s.blur_tolerance
     ao.upsampleTolerance = s.upsample_tolerance
@@ -32,11 +34,12 @@ def component(s, max_batch=1, device=0):
     return ao
 
 
-def valid_debug_ids(num_levels):
+def valid_debug_ids(num_levels, hq_levels=0):
     ids = list(range(1, 10))
     ids += [10 + k for k in range(num_levels)]
     ids += [14 + k for k in range(num_levels - 1)]
     ids.append(17)
+    ids += [17 + k for k in range(1, num_levels + 1) if k > num_levels - hq_levels]
     return ids
 
 

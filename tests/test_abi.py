@@ -44,7 +44,7 @@ def test_product_library_does_not_link_the_oracle():
 
 def test_struct_layouts_match_header():
     # every member is a 4-byte scalar except meao_desc.bytes (u64, naturally aligned)
-    assert C.sizeof(L.Config) == 10 * 4 and C.sizeof(L.Params) == 10 * 4
+    assert C.sizeof(L.Config) == 12 * 4 and C.sizeof(L.Params) == 11 * 4
     assert C.sizeof(L.Desc) == 32 and L.Desc.bytes.offset == 24
     assert C.sizeof(L.RenderConstants) == 28 * 4 and C.sizeof(L.UpsampleConstants) == 8 * 4
     for struct, cname in ((L.Config, "meao_config"), (L.Params, "meao_params"), (L.Desc, "meao_desc")):
@@ -75,6 +75,7 @@ def _params(meao_lib, s):
     p.noise_filter_tolerance, p.blur_tolerance = s.noise_filter_tolerance, s.blur_tolerance
     p.upsample_tolerance, p.thickness_modifier, p.intensity = s.upsample_tolerance, s.thickness_modifier, s.intensity
     p.near_clip, p.far_clip, p.proj00, p.reversed_z = s.near_clip, s.far_clip, s.proj00, int(s.reversed_z)
+    p.single_pass_stereo = int(s.single_pass_stereo)
     return p
 
 
@@ -87,14 +88,21 @@ def test_plan_constants_match_oracle_bitwise(meao_lib, oracle, seed):
                                                    fov_y_deg=float(rng.uniform(10, 100)), reversed_z=bool(seed & 1)),
                    noise_filter_tolerance=float(rng.uniform(-8, 0)), blur_tolerance=float(rng.uniform(-8, -1)),
                    upsample_tolerance=float(rng.uniform(-12, -1)), thickness_modifier=float(rng.uniform(1, 10)),
-                   intensity=float(rng.uniform(0, 2)))
+                   intensity=float(rng.uniform(0, 2)), single_pass_stereo=bool(seed & 2),
+                   sample_set=(seed >> 2) & 1)
     p = _params(meao_lib, s)
     zp = (C.c_float * 4)()
     assert meao_lib.meao_zbuffer_params(C.byref(p), C.byref(zp)) == 0
     assert list(zp) == oracle.zbuffer_params(s)
     for level in (1, 2, 3, 4):
         a, b = oracle.render_constants(s, level), L.RenderConstants()
-        assert meao_lib.meao_render_constants_for(w, h, C.byref(p), level, C.byref(b)) == 0
+        assert meao_lib.meao_render_constants_variant(w, h, C.byref(p), level, 1, s.sample_set, C.byref(b)) == 0
+        assert bytes(a) == bytes(b)
+        if s.sample_set == 0:
+            assert meao_lib.meao_render_constants_for(w, h, C.byref(p), level, C.byref(b)) == 0
+            assert bytes(a) == bytes(b)
+        a = oracle.render_constants_hq(s, level)           # Render.main on the non-tiled LowDepth<level>
+        assert meao_lib.meao_render_constants_variant(w, h, C.byref(p), level, 0, s.sample_set, C.byref(b)) == 0
         assert bytes(a) == bytes(b)
         a, b = oracle.upsample_constants(s, level), L.UpsampleConstants()
         assert meao_lib.meao_upsample_constants_for(w, h, C.byref(p), level, C.byref(b)) == 0
@@ -121,7 +129,11 @@ def test_buffer_table(meao_lib, oracle):
         total += d.bytes
     assert round(total / 1e6, 1) == 20.0            # 20.0 MB at 1080p
     assert meao_lib.meao_describe_buffer(C.byref(cfg), 0, C.byref(d)) == L.ERR_INVALID_ARGUMENT
-    assert meao_lib.meao_describe_buffer(C.byref(cfg), 18, C.byref(d)) == L.ERR_INVALID_ARGUMENT
+    for i in range(18, 22):                          # OcclusionHQ1..4: same table rows as Occlusion1..4
+        assert meao_lib.meao_describe_buffer(C.byref(cfg), i, C.byref(d)) == 0
+        a = arrs[H.NAMES[i - 8]]
+        assert (d.slices, d.height, d.width, d.bytes) == (1,) + a.shape + (a.nbytes,)
+    assert meao_lib.meao_describe_buffer(C.byref(cfg), 22, C.byref(d)) == L.ERR_INVALID_ARGUMENT
 
 
 @pytest.mark.parametrize("w,h,fmt,total_mb,ren_ups_mb", [
@@ -135,6 +147,14 @@ def test_algorithmic_bytes_match_baseline_md(meao_lib, w, h, fmt, total_mb, ren_
     assert meao_lib.meao_algorithmic_bytes(C.byref(cfg), C.byref(b)) == 0
     assert round(sum(b) / 1e6, 2) == total_mb
     assert round(sum(list(b)[1:]) / 1e6, 2) == ren_ups_mb
+    assert b[L.PASS_NAMES.index("render_hq")] == 0
+    cfg.hq_levels = 4                                 # + Render.main per level and LoResAO2 per upsample
+    base = list(b)
+    assert meao_lib.meao_algorithmic_bytes(C.byref(cfg), C.byref(b)) == 0
+    a = 1 if fmt == 0 else 2
+    px = [(-(-w // 2 ** k)) * (-(-h // 2 ** k)) for k in range(5)]
+    assert b[L.PASS_NAMES.index("render_hq")] == sum((4 + a) * px[k] for k in range(1, 5))
+    assert sum(b) - sum(base) == sum((4 + 2 * a) * px[k] for k in range(1, 5))
 
 
 def test_argument_validation(meao_lib):
@@ -148,6 +168,12 @@ def test_argument_validation(meao_lib):
     bad = L.Config.from_buffer_copy(cfg); bad.struct_size = 12
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
     bad = L.Config.from_buffer_copy(cfg); bad.max_batch = 17
+    assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
+    bad = L.Config.from_buffer_copy(cfg); bad.hq_levels = 5
+    assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
+    bad = L.Config.from_buffer_copy(cfg); bad.num_levels = 2; bad.hq_levels = 3
+    assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
+    bad = L.Config.from_buffer_copy(cfg); bad.sample_set = 2
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
     bad = L.Config.from_buffer_copy(cfg); bad.numerics = 7
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_UNSUPPORTED

@@ -48,7 +48,7 @@ def test_gpu_reproduces_small_fixtures(name):
     try:
         got = ao.render(fx["depth"])
         assert np.array_equal(got, fx["result"]), H.diff_report("result", got, fx["result"])
-        for i in H.valid_debug_ids(s.num_levels):
+        for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
             assert np.array_equal(ao.debug_buffer(i), fx[H.NAMES[i]]), H.NAMES[i]
     finally:
         ao.close()

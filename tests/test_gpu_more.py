@@ -31,6 +31,10 @@ def test_randomized_configurations(oracle, seed):
                    num_levels=int(rng.integers(1, 5)), noise_filter_tolerance=float(rng.uniform(-8, 0)),
                    blur_tolerance=float(rng.uniform(-8, -1)), upsample_tolerance=float(rng.uniform(-12, -1)),
                    thickness_modifier=float(rng.uniform(1, 10)), intensity=float(rng.uniform(0, 2)))
+    if seed % 2:                                               # the variants of SURVEY 8f #4
+        s.hq_levels = int(rng.integers(0, s.num_levels + 1))
+        s.sample_set = int(rng.integers(0, 2))
+        s.single_pass_stereo = bool(rng.integers(0, 2))
     depth = synth.occluder_field(w, h, seed=seed, n_rects=24, n_discs=24, cam=cam)
     if seed % 3 == 0:                                          # sky (1e5; overflows f16)
         x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
@@ -40,7 +44,7 @@ def test_randomized_configurations(oracle, seed):
     try:
         got = ao.render(depth)
         assert np.array_equal(got, want["result"]), (seed, w, h, H.diff_report("result", got, want["result"]))
-        for i in H.valid_debug_ids(s.num_levels):
+        for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
             g = ao.debug_buffer(i)
             assert np.array_equal(g, want[H.NAMES[i]]), (seed, w, h, H.diff_report(H.NAMES[i], g, want[H.NAMES[i]]))
     finally:

@@ -23,7 +23,7 @@ def _compare_all(O, s, depth, ao=None):
     try:
         got = ao.render(depth)
         assert np.array_equal(got, want["result"]), H.diff_report("result", got, want["result"])
-        for i in H.valid_debug_ids(s.num_levels):
+        for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
             g = ao.debug_buffer(i)
             w = want[H.NAMES[i]]
             assert g.shape == w.shape and g.dtype == w.dtype, (i, g.shape, w.shape, g.dtype, w.dtype)
@@ -47,6 +47,34 @@ def test_modes(oracle, ao_format, f16_rounding, num_levels):
     w, h = 203, 117
     s = H.settings(oracle, w, h, ao_format=ao_format, f16_rounding=f16_rounding, num_levels=num_levels)
     _compare_all(oracle, s, synth.make("S2", w, h, seed=77))
+
+
+@pytest.mark.parametrize("variant", [
+    dict(hq_levels=4), dict(hq_levels=1), dict(hq_levels=2, num_levels=3), dict(sample_set=1),
+    dict(single_pass_stereo=True), dict(hq_levels=4, sample_set=1, single_pass_stereo=True, ao_format=1),
+    dict(hq_levels=3, sample_set=1, f16_rounding=1, ao_format=1), dict(hq_levels=1, num_levels=1),
+])
+@pytest.mark.parametrize("w,h", [(203, 117), (256, 128), (61, 190)])
+def test_variants(oracle, variant, w, h):
+    """Render.main (wide) + Upsample.main_premin*, SAMPLE_EXHAUSTIVELY, single-pass stereo:
+    every buffer incl. OcclusionHQ<k> bit-exact against the oracle."""
+    s = H.settings(oracle, w, h, **variant)
+    depth = synth.make("S2", w, h, seed=31)
+    depth[h // 4: h // 4 + 20, w // 3: w // 3 + 50] = 0.0           # sky texels
+    _compare_all(oracle, s, depth)
+
+
+def test_variant_buffers_are_absent_without_the_variant(oracle):
+    s = H.settings(oracle, 96, 64, hq_levels=2)
+    ao = H.component(s)
+    try:
+        ao.render(synth.make("S1", 96, 64))
+        assert ao.debug_buffer(21).shape == (4, 6) and ao.debug_buffer(20).shape == (8, 12)
+        for i in (18, 19):                                         # levels 1, 2 have no Render.main pass
+            with pytest.raises(Exception, match="hq_levels"):
+                ao.debug_buffer(i)
+    finally:
+        ao.close()
 
 
 @pytest.mark.parametrize("params", [
