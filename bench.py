@@ -112,6 +112,11 @@ def main() -> int:
                     help="override the AO storage of the workload (R8 = reference, F16 = fp16 AO)")
     ap.add_argument("--fast-numerics", action="store_true",
                     help="MEAO_NUMERICS_FAST (raw v_rcp_f32 divides; NOT bit-exact, reported as such)")
+    ap.add_argument("--hq-levels", type=int, default=0,
+                    help="variant (not the reference's wiring): the coarsest N levels also run Render.main "
+                         "(wide) and the upsamples become main_premin*; changes config.workload")
+    ap.add_argument("--exhaustive", action="store_true",
+                    help="variant: SAMPLE_EXHAUSTIVELY (68 samples instead of 36); changes config.workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
@@ -136,6 +141,10 @@ def main() -> int:
         ao_format = _lib.AO_R8 if args.ao_format == "r8" else _lib.AO_F16
         desc = desc.replace("fp16 AO storage", "AO").replace("R8 AO", "AO") + \
             (", R8 storage" if ao_format == _lib.AO_R8 else ", fp16 storage")
+    if args.hq_levels:
+        desc += f", VARIANT hq_levels={args.hq_levels}"
+    if args.exhaustive:
+        desc += ", VARIANT 68-sample set"
     B = max(1, min(args.batch, _lib.MAX_BATCH))
     ao_dtype = torch.uint8 if ao_format == _lib.AO_R8 else torch.int16
 
@@ -149,7 +158,8 @@ def main() -> int:
     for _ in range(nfl):
         c = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=B,
                              near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
-                             reversed_z=cam.reversed_z,
+                             reversed_z=cam.reversed_z, hq_levels=args.hq_levels,
+                             sample_set=_lib.SAMPLES_EXHAUSTIVE if args.exhaustive else _lib.SAMPLES_CHECKER,
                              numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT)
         c.intensity = intensity
         ctxs.append(c)
@@ -217,7 +227,7 @@ def main() -> int:
                 "vs_copy_ceiling_frac": round(dom_gbps / HBM_COPY_CEILING_GBPS, 4), "passes": passes}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not (args.hq_levels or args.exhaustive):
         cpu = cpu_baseline(w, h, cam, intensity, ao_format, frames[0])
 
     # single-frame latency (one frame per launch sequence), for context

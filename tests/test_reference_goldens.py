@@ -113,6 +113,42 @@ def test_host_constants_from_the_reference_csharp(oracle, meao_lib, seed):
         assert (d.width, d.height, d.slices, d.format) == (aw, ah, slices, fmt_of[fmt]), name
 
 
+@needs_reference
+@pytest.mark.parametrize("seed", range(4))
+def test_variant_constants_from_the_reference_csharp(oracle, meao_lib, seed):
+    """Single-pass stereo (AO.cs:392-401,680) and the non-tiled-source branch of PushRenderCommands
+    (AO.cs:679), both executed from the reference's C#: constants equal the oracle's and the product's."""
+    import ctypes as C
+
+    from miniengineao_amd import _lib as L
+    from miniengineao_amd import synth
+    rng = np.random.default_rng(100 + seed)
+    w, h = 2 * int(rng.integers(9, 2000)), int(rng.integers(9, 2200))
+    stereo = bool(seed & 1)
+    cam = synth.Camera(near=float(rng.uniform(0.01, 1)), far=float(rng.uniform(5, 2000)),
+                       fov_y_deg=float(rng.uniform(10, 100)), reversed_z=bool(seed & 2))
+    s = H.settings(oracle, w, h, cam=cam, thickness_modifier=float(rng.uniform(1, 10)),
+                   intensity=float(rng.uniform(0, 2)), single_pass_stereo=stereo, hq_levels=4)
+    _, cmd, result_rt, it, comp = R.record_reference_commands(s, want_interp=True)
+    assert (result_rt.width, result_rt.height) == (w, h)          # pixelWidth * 2 in stereo (AO.cs:502)
+    f = lambda xs: [float(x) for x in xs]               # noqa: E731
+    p = L.Params()
+    meao_lib.meao_default_params(C.byref(p))
+    p.thickness_modifier, p.intensity, p.near_clip, p.far_clip = s.thickness_modifier, s.intensity, s.near_clip, s.far_clip
+    p.proj00, p.reversed_z, p.single_pass_stereo = s.proj00, int(s.reversed_z), int(stereo)
+    for level in (1, 2, 3, 4):
+        for tiled, c in ((1, cmd.dispatches[1 + level]["const"]), (0, R.hq_render_commands(s, it, comp, level)["const"])):
+            k = oracle.render_constants(s, level) if tiled else oracle.render_constants_hq(s, level)
+            assert f(c["gInvThicknessTable"]) == f(k.inv_thickness) and f(c["gSampleWeightTable"]) == f(k.sample_weight)
+            assert f(c["gInvSliceDimension"][:2]) == f(k.inv_slice_dim)
+            prod = L.RenderConstants()
+            assert meao_lib.meao_render_constants_variant(w, h, C.byref(p), level, tiled, 0, C.byref(prod)) == 0
+            assert bytes(prod) == bytes(k)
+    if stereo:                                          # and it differs from the mono constants by exactly x2
+        mono = oracle.render_constants(H.settings(oracle, w, h, cam=cam), 1)
+        assert f(oracle.render_constants(s, 1).inv_thickness) == [v / 2 for v in f(mono.inv_thickness)]
+
+
 def test_interpreter_semantics():
     """The pieces of HLSL the shaders lean on: C octal literals, 32-bit unsigned wrap-around,
     int/uint/float promotion, swizzles, mad contraction, D3D NaN rules."""
