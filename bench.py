@@ -251,15 +251,34 @@ def main() -> int:
                      "algorithmic_MB_per_frame": round(cbytes / 1e6, 2), "GBps": round(cg, 1),
                      "frac": round(cg / HBM_PEAK_GBPS, 4), "bound": "hbm"}
 
-    latency_ms = None
+    # single-frame use (one frame per call, the real-time case): one launch per pass (DIRECT) vs one
+    # hipGraphLaunch per call (MEAO_LAUNCH_GRAPH); back-to-back calls, and call + wait per frame
+    latency_ms, single = None, None
     if not args.skip_latency:
-        fence()
-        lat_iters = 20
-        t0 = time.perf_counter()
-        for _ in range(lat_iters):
-            ao.execute_device(dptr[:1], optr[:1], stream)
-        torch.cuda.synchronize(dev)
-        latency_ms = (time.perf_counter() - t0) / lat_iters * 1e3
+        g = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=1,
+                             near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
+                             reversed_z=cam.reversed_z, hq_levels=args.hq_levels,
+                             sample_set=_lib.SAMPLES_EXHAUSTIVE if args.exhaustive else _lib.SAMPLES_CHECKER,
+                             numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT,
+                             launch_mode=_lib.LAUNCH_GRAPH)
+        g.intensity = intensity
+        lat_iters = 50
+        single = {}
+        for name, c in (("direct", ao), ("graph", g)):
+            for sync_each in (False, True):
+                for _ in range(3):
+                    c.execute_device(dptr[:1], optr[:1], stream)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(lat_iters):
+                    c.execute_device(dptr[:1], optr[:1], stream)
+                    if sync_each:
+                        torch.cuda.synchronize(dev)
+                torch.cuda.synchronize(dev)
+                single[name + ("_call_and_wait_ms" if sync_each else "_back_to_back_ms")] = \
+                    round((time.perf_counter() - t0) / lat_iters * 1e3, 4)
+        g.close()
+        latency_ms = single["direct_back_to_back_ms"]
 
     if rank == 0:
         line = {
@@ -274,6 +293,7 @@ def main() -> int:
                        "batches_in_flight": nfl},
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
+            "single_frame": single,
             "sum_kernel_ms_per_step": round(kernel_ms, 4),
         }
         print(json.dumps(line), flush=True)

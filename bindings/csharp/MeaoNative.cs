@@ -26,6 +26,7 @@ namespace MiniEngineAO.Native
     public enum MeaoCompositeMode { Multiply = 0, AmbientOnly = 1, Debug = 2 }
     public enum MeaoFormat { F32 = 0, F16 = 1, Unorm8 = 2 }
     public enum MeaoSampleSet { Checker = 0, Exhaustive = 1 }
+    public enum MeaoLaunchMode { Direct = 0, Graph = 1 }
 
     [StructLayout(LayoutKind.Sequential)]
     public struct MeaoConfig
@@ -42,6 +43,7 @@ namespace MiniEngineAO.Native
         public int depth_format;
         public int hq_levels;
         public int sample_set;
+        public int launch_mode;
     }
 
     [StructLayout(LayoutKind.Sequential)]

@@ -67,6 +67,17 @@ typedef enum meao_numerics { MEAO_NUMERICS_STRICT = 0, MEAO_NUMERICS_FAST = 1 } 
 
 typedef enum meao_mem { MEAO_MEM_HOST = 0, MEAO_MEM_DEVICE = 1 } meao_mem;
 
+/* How meao_execute* submits the passes of one call.  DIRECT: one kernel launch per pass.  GRAPH: the
+ * launch sequence is captured once per (frame pointers, parameters) into a HIP graph and replayed
+ * with a single hipGraphLaunch.  Same kernels, same results.  The context keeps the 8 most recent
+ * graphs; meao_set_params / meao_resize drop them.  Falls back to DIRECT while profiling
+ * (meao_set_profiling) or when the caller's stream is itself being captured.
+ * Measured on MI355X / ROCm 7.2 (profiles/README.md): NOT faster than DIRECT for one frame per call
+ * (1080p 49.9 vs 45.8 us back to back) -- the 6-7 dependent kernels are separated by GPU-side
+ * barriers, not by host launch cost -- so DIRECT stays the default; the mode is kept for callers
+ * that want one submission per frame. */
+typedef enum meao_launch_mode { MEAO_LAUNCH_DIRECT = 0, MEAO_LAUNCH_GRAPH = 1 } meao_launch_mode;
+
 /* Storage of the input depth buffer.  The reference first blits _CameraDepthTexture -- whatever
  * its format -- into an RFloat copy (Blit.shader:48-64 pass 0, AO.cs:608-614) unless D3D's
  * resolved depth is available; here the downsample kernel decodes the format on load, so that
@@ -122,6 +133,7 @@ typedef struct meao_config {
                              * LoResAO1 = min(LoResAO1, that render).  Wiring as in the Microsoft
                              * MiniEngine original (its quality levels = hq_levels 0..4). */
     int32_t sample_set;     /* meao_sample_set */
+    int32_t launch_mode;    /* meao_launch_mode */
 } meao_config;
 
 /* The component's serialized properties (AO.cs:20-68; defaults there) and the camera terms

@@ -39,6 +39,7 @@ DEPTH_F32, DEPTH_UNORM16, DEPTH_UNORM24, DEPTH_F16 = 0, 1, 2, 3
 COMPOSITE_MULTIPLY, COMPOSITE_AMBIENT_ONLY, COMPOSITE_DEBUG = 0, 1, 2
 FMT_F32, FMT_F16, FMT_UNORM8 = 0, 1, 2
 SAMPLES_CHECKER, SAMPLES_EXHAUSTIVE = 0, 1
+LAUNCH_DIRECT, LAUNCH_GRAPH = 0, 1
 DEBUG_OCCLUSION_HQ1 = 18
 NUM_BUFFERS = 21
 
@@ -47,7 +48,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("width", C.c_int32),
                 ("height", C.c_int32), ("num_levels", C.c_int32), ("ao_format", C.c_int32),
                 ("f16_rounding", C.c_int32), ("numerics", C.c_int32), ("max_batch", C.c_int32),
-                ("depth_format", C.c_int32), ("hq_levels", C.c_int32), ("sample_set", C.c_int32)]
+                ("depth_format", C.c_int32), ("hq_levels", C.c_int32), ("sample_set", C.c_int32),
+                ("launch_mode", C.c_int32)]
 
 
 class Params(C.Structure):

@@ -37,7 +37,8 @@ class AmbientOcclusion:
                  max_batch: int = 1, depth_format: int = L.DEPTH_F32, numerics: int = L.NUMERICS_STRICT,
                  near_clip: float = 0.3, far_clip: float = 1000.0,
                  projection00: Optional[float] = None, reversed_z: bool = True,
-                 hq_levels: int = 0, sample_set: int = L.SAMPLES_CHECKER, single_pass_stereo: bool = False):
+                 hq_levels: int = 0, sample_set: int = L.SAMPLES_CHECKER, single_pass_stereo: bool = False,
+                 launch_mode: int = L.LAUNCH_DIRECT):
         """hq_levels / sample_set / single_pass_stereo: variants the reference's shaders and host carry
         but its command buffer never (or only in VR) uses; see include/meao.h.  ``width`` is the
         double-wide eye pair when single_pass_stereo is set (AO.cs:339)."""
@@ -50,6 +51,7 @@ class AmbientOcclusion:
         cfg.depth_format = depth_format
         cfg.numerics = numerics
         cfg.hq_levels, cfg.sample_set = hq_levels, sample_set
+        cfg.launch_mode = launch_mode      # LAUNCH_GRAPH: one hipGraphLaunch per call (real-time single frames)
         self._cfg = cfg
         prm = L.Params()
         self._lib.meao_default_params(C.byref(prm))

@@ -49,6 +49,15 @@ struct meao_ctx {
     const void *last_out[MEAO_MAX_BATCH] = {};   // device address of the last results (debug id 17)
     int last_frames = 0;
 
+    // MEAO_LAUNCH_GRAPH: captured launch sequences, most recently used last
+    struct CapturedBatch {
+        int n = 0;
+        const void *depth[MEAO_MAX_BATCH] = {};
+        void *out[MEAO_MAX_BATCH] = {};
+        hipGraphExec_t exec = nullptr;
+    };
+    std::vector<CapturedBatch> graphs;
+
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;              // kProfileRing * (MEAO_NUM_PASSES + 1)
@@ -93,6 +102,7 @@ bool config_valid(const meao_config &c, std::string *why)
     if (c.depth_format < MEAO_DEPTH_F32 || c.depth_format > MEAO_DEPTH_F16) { *why = "unknown depth_format"; return false; }
     if (c.hq_levels < 0 || c.hq_levels > c.num_levels) { *why = "hq_levels must be 0..num_levels"; return false; }
     if (c.sample_set != MEAO_SAMPLES_CHECKER && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE) { *why = "unknown sample_set"; return false; }
+    if (c.launch_mode != MEAO_LAUNCH_DIRECT && c.launch_mode != MEAO_LAUNCH_GRAPH) { *why = "unknown launch_mode"; return false; }
     return true;
 }
 
@@ -129,8 +139,19 @@ bool exact_rcp_div_applicable(const meao_config &c, const meao_params &p, const 
     return true;
 }
 
+constexpr size_t kMaxCapturedBatches = 8;
+
+void drop_graphs(meao_ctx *ctx)
+{
+    if (!ctx->graphs.empty()) (void)hipStreamSynchronize(ctx->last_stream);   // a replay may be in flight
+    for (auto &g : ctx->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    ctx->graphs.clear();
+}
+
 void update_plan(meao_ctx *ctx)
 {
+    drop_graphs(ctx);   // captured kernel arguments embed the plan's constants and the arena addresses
     build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->cfg.sample_set, ctx->prm, &ctx->plan);
     ctx->exact_rcp_div = exact_rcp_div_applicable(ctx->cfg, ctx->prm, ctx->plan) ? 1 : 0;
     // MEAO_NUMERICS_FAST: raw v_rcp_f32 (2 = DIV_FAST in the kernels); RTZ storage only, like the exact mode
@@ -309,6 +330,54 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     return MEAO_OK;
 }
 
+// MEAO_LAUNCH_GRAPH: replay the captured launch sequence of this exact batch, capturing it first
+// if it is new.  The captured nodes are the very launches run_batch() makes.
+int submit_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream)
+{
+    if (ctx->cfg.launch_mode != MEAO_LAUNCH_GRAPH || ctx->profiling)
+        return run_batch(ctx, n, depth_dev, out_dev, stream);
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &status) != hipSuccess || status != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return run_batch(ctx, n, depth_dev, out_dev, stream);   // the caller's own capture records our launches
+    }
+    for (size_t i = 0; i < ctx->graphs.size(); ++i) {
+        const meao_ctx::CapturedBatch &g = ctx->graphs[i];
+        if (g.n != n || std::memcmp(g.depth, depth_dev, sizeof(void *) * n) != 0 ||
+            std::memcmp(g.out, out_dev, sizeof(void *) * n) != 0)
+            continue;
+        const meao_ctx::CapturedBatch hit = g;
+        ctx->graphs.erase(ctx->graphs.begin() + static_cast<long>(i));
+        ctx->graphs.push_back(hit);
+        MEAO_HIP(ctx, hipGraphLaunch(hit.exec, stream));
+        for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
+        ctx->last_frames = n;
+        ctx->last_stream = stream;
+        return MEAO_OK;
+    }
+    MEAO_HIP(ctx, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    const int rc = run_batch(ctx, n, depth_dev, out_dev, stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t end = hipStreamEndCapture(stream, &graph);
+    if (rc != MEAO_OK || end != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc != MEAO_OK ? rc : fail_hip(ctx, end, "hipStreamEndCapture");
+    }
+    meao_ctx::CapturedBatch g;
+    g.n = n;
+    for (int f = 0; f < n; ++f) { g.depth[f] = depth_dev[f]; g.out[f] = out_dev[f]; }
+    const hipError_t inst = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (inst != hipSuccess) return fail_hip(ctx, inst, "hipGraphInstantiate");
+    if (ctx->graphs.size() >= kMaxCapturedBatches) {
+        (void)hipGraphExecDestroy(ctx->graphs.front().exec);
+        ctx->graphs.erase(ctx->graphs.begin());
+    }
+    ctx->graphs.push_back(g);
+    MEAO_HIP(ctx, hipGraphLaunch(g.exec, stream));
+    return MEAO_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -473,6 +542,7 @@ int32_t meao_destroy(meao_ctx *ctx)
     if (!ctx) return MEAO_OK;
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipDeviceSynchronize();
+    drop_graphs(ctx);
     release_buffers(ctx);
     if (ctx->counter) (void)hipFree(ctx->counter);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
@@ -563,7 +633,7 @@ int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth, i
         for (int f = 0; f < n; ++f) out_dev[f] = ao_out[f];
     }
 
-    rc = run_batch(ctx, n, depth_dev, out_dev, stream);
+    rc = submit_batch(ctx, n, depth_dev, out_dev, stream);
     if (rc != MEAO_OK) return rc;
 
     if (out_loc == MEAO_MEM_HOST)

@@ -18,14 +18,14 @@ def settings(O, w, h, cam=synth.DEFAULT_CAMERA, **kw):
                       reversed_z=cam.reversed_z, **kw)
 
 
-def component(s, max_batch=1, device=0):
+def component(s, max_batch=1, device=0, **kw):
     """AmbientOcclusion (C ABI) configured exactly like oracle Settings ``s``."""
     from miniengineao_amd import AmbientOcclusion
     ao = AmbientOcclusion(s.width, s.height, device=device, num_levels=s.num_levels,
                           ao_format=s.ao_format, f16_rounding=s.f16_rounding, max_batch=max_batch,
                           near_clip=s.near_clip, far_clip=s.far_clip, projection00=s.proj00,
                           reversed_z=s.reversed_z, hq_levels=s.hq_levels, sample_set=s.sample_set,
-                          single_pass_stereo=s.single_pass_stereo)
+                          single_pass_stereo=s.single_pass_stereo, **kw)
     ao.noiseFilterTolerance = s.noise_filter_tolerance
     ao.blurTolerance = s.blur_tolerance
     ao.upsampleTolerance = s.upsample_tolerance

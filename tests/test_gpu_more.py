@@ -51,6 +51,52 @@ def test_randomized_configurations(oracle, seed):
         ao.close()
 
 
+@pytest.mark.parametrize("variant", [dict(), dict(hq_levels=2, sample_set=1, ao_format=1)])
+def test_graph_launch_mode(oracle, variant):
+    """MEAO_LAUNCH_GRAPH: captured once per (pointers, parameters), replayed afterwards; a property
+    change, a resize and new pointers each force a new capture; more pointer sets than the context
+    keeps (8) evict the oldest.  Results stay bit-exact throughout."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h = 322, 182
+    s = H.settings(oracle, w, h, **variant)
+    ao = H.component(s, launch_mode=L.LAUNCH_GRAPH)
+    dt = torch.uint8 if s.ao_format == 0 else torch.int16
+    try:
+        frames = [synth.make("S2", w, h, seed=40 + k) for k in range(10)]
+        wants = [oracle.run(f, s, result_only=True)["result"] for f in frames]
+        d_in = [torch.from_numpy(f).to(dev) for f in frames]
+        d_out = [torch.zeros((h, w), dtype=dt, device=dev) for _ in frames]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for rep in range(3):                                   # 10 pointer sets > 8 cached graphs
+            for k in range(10):
+                d_out[k].zero_()
+                ao.execute_device([d_in[k].data_ptr()], [d_out[k].data_ptr()], stream)
+            torch.cuda.synchronize(dev)
+            for k in range(10):
+                got = d_out[k].cpu().numpy().view(wants[k].dtype)
+                assert np.array_equal(got, wants[k]), (rep, k)
+        for i in H.valid_debug_ids(s.num_levels, s.hq_levels):    # intermediates of the last replay (frame 9)
+            assert np.array_equal(ao.debug_buffer(i), oracle.run(frames[9], s)[H.NAMES[i]]), i
+        ao.intensity = 0.5                                     # CheckPropertiesChanged -> graphs dropped
+        s2 = H.settings(oracle, w, h, intensity=0.5, **variant)
+        for rep in range(2):
+            ao.execute_device([d_in[0].data_ptr()], [d_out[0].data_ptr()], stream)
+            torch.cuda.synchronize(dev)
+            assert np.array_equal(d_out[0].cpu().numpy().view(wants[0].dtype), oracle.run(frames[0], s2, result_only=True)["result"])
+        ao.resize(130, 70)                                     # screen-size change
+        s3 = H.settings(oracle, 130, 70, intensity=0.5, **variant)
+        ao.projection00 = s3.proj00
+        small = synth.make("S2", 130, 70, seed=3)
+        for rep in range(2):                                   # host path: staging pointers are stable -> replay
+            assert np.array_equal(ao.render(small), oracle.run(small, s3, result_only=True)["result"])
+        ao.set_profiling(True)                                 # profiling falls back to direct launches
+        assert np.array_equal(ao.render(small), oracle.run(small, s3, result_only=True)["result"])
+        assert ao.pass_times_ms()[1] == 1
+    finally:
+        ao.close()
+
+
 def test_device_pointers_and_streams_with_torch(oracle):
     """The path bench.py uses: torch owns device memory and the stream, the library gets raw
     addresses; batched, asynchronous, results identical to the host-pointer path."""
