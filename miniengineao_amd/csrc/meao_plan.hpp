@@ -12,7 +12,6 @@
 namespace meao {
 
 constexpr int kNumMips = 7;        // Original, L1..L6  (AO.cs:124)
-constexpr int kNumDebugBuffers = 17;
 
 struct Dims { int w = 0, h = 0; };
 
