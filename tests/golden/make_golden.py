@@ -35,6 +35,10 @@ LARGE = {
     "s3_1080p": (1920, 1080, "S3", 0, synth.SPONZA_CAMERA, dict(intensity=1.1)),
     "s2_1080p": (1920, 1080, "S2", 0x1234ABCD, synth.DEFAULT_CAMERA, {}),
     "s2_4k": (3840, 2160, "S2", 0x1234ABCD, synth.DEFAULT_CAMERA, {}),
+    # the SURVEY 8f#4 variants at full size: Render.main on all levels + premin, 68 samples, stereo pair
+    "s2_4k_hq4_exhaustive_stereo": (3840, 2160, "S2", 0x1234ABCD, synth.DEFAULT_CAMERA,
+                                    dict(hq_levels=4, sample_set=1, single_pass_stereo=True)),
+    "s3_1080p_hq2": (1920, 1080, "S3", 0, synth.SPONZA_CAMERA, dict(intensity=1.1, hq_levels=2)),
 }
 
 
