@@ -180,6 +180,12 @@ def main() -> int:
     def fence():
         mdist.fence(dev)     # synchronize + barrier + synchronize
 
+    # clock ramp: a fixed ~25 ms of untimed work before the W warm-up steps, so that a short run
+    # (small --steps / --warmup) is timed at the same clocks as a long one
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.025:
+        step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     for c in ctxs:
