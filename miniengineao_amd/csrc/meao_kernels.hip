@@ -586,7 +586,9 @@ __device__ __forceinline__ void blur_run(const BlurConsts &k, const float (&a)[N
         const float pa = left ? a[n] : pb;
         const float pd = (right | middle) ? a[n + 3] : pc;
         const float pe = right ? a[n + 4] : pd;
-        out[n] = ((((pa + pe) * 0.5f + pb) + pc) + pd) * 0.25f;
+        // (pa + pe) * 0.5 is exact (power of two, operands are AO values far from underflow), so
+        // fusing it into the following add rounds exactly like the reference's mul-then-add
+        out[n] = ((mad(pa + pe, 0.5f, pb) + pc) + pd) * 0.25f;
     }
 }
 
