@@ -268,7 +268,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             for (int t = 0; t < rp.terms; ++t) {
                 L.inv_thickness[t] = rp.inv_thickness[t];
                 L.front_depth[t] = rp.front_depth[t];
-                L.weight[t] = rp.weight[t];
+                L.weight[t] = rp.scaled_weight[t];
             }
             L.reject_fadeoff = rp.cb.reject_fadeoff;
             L.intensity = rp.cb.intensity;

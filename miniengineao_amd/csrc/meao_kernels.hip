@@ -80,6 +80,18 @@ __device__ __forceinline__ float f16_bits_to_f32(uint16_t b)
 template <bool RTNE>
 __device__ __forceinline__ float through_f16(float x) { return f16_bits_to_f32(f32_to_f16_bits<RTNE>(x)); }
 
+// the same for two values: RTZ converts both with one v_cvt_pkrtz_f16_f32
+template <bool RTNE>
+__device__ __forceinline__ float2v through_f16_pair(float x, float y)
+{
+    if constexpr (RTNE) {
+        return float2v{through_f16<true>(x), through_f16<true>(y)};
+    } else {
+        const auto p = __builtin_amdgcn_cvt_pkrtz(x, y);
+        return float2v{static_cast<float>(p[0]), static_cast<float>(p[1])};
+    }
+}
+
 // f32 -> UNORM8 (FixedUAV targets): NaN -> 0, clamp, *255, +0.5, truncate
 __device__ __forceinline__ uint32_t f32_to_unorm8(float x)
 {
@@ -354,8 +366,10 @@ __device__ __forceinline__ float2v test_sample_pair2(const float *centre, int of
                    test_sample_pair(s1.y, s2.y, inv_range.y, neg_front, reject)};
 }
 
-// TestSamples (REN:77-110).  (X, Y) are sample offsets in source texels; the LDS offset of
-// (dx, dy) is dy*P + dx*Q.  Interleaved: one slice texel is 4 level texels (4x4 interleave),
+// TestSamples (REN:77-110) WITHOUT its leading 0.5 / 0.25: that exact power-of-two factor is folded
+// into the term's weight on the host (RenderLevelArgs::weight), since fma(w, k*S, ao) and
+// fma(k*w, S, ao) round the same real number.  (X, Y) are sample offsets in source texels; the LDS
+// offset of (dx, dy) is dy*P + dx*Q.  Interleaved: one slice texel is 4 level texels (4x4 interleave),
 // P = 4*pitch, Q = 4.  Wide (REN:79-82, x <<= 1): P = 2*pitch, Q = 2.
 template <int X, int Y, int P, int Q>
 __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv_depth, float inv_thickness,
@@ -364,22 +378,23 @@ __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv
     const float2v inv_range = splat(inv_thickness) * inv_depth;
     const float neg_front = -front_depth;
     if constexpr (Y == 0) {
-        return splat(0.5f) * (test_sample_pair2(centre, X * Q, inv_range, neg_front, reject) +
-                              test_sample_pair2(centre, X * P, inv_range, neg_front, reject));
+        return test_sample_pair2(centre, X * Q, inv_range, neg_front, reject) +
+               test_sample_pair2(centre, X * P, inv_range, neg_front, reject);
     } else if constexpr (X == Y) {
-        return splat(0.5f) * (test_sample_pair2(centre, X * P - X * Q, inv_range, neg_front, reject) +
-                              test_sample_pair2(centre, X * P + X * Q, inv_range, neg_front, reject));
+        return test_sample_pair2(centre, X * P - X * Q, inv_range, neg_front, reject) +
+               test_sample_pair2(centre, X * P + X * Q, inv_range, neg_front, reject);
     } else {
-        return splat(0.25f) * (((test_sample_pair2(centre, Y * P + X * Q, inv_range, neg_front, reject) +
-                                 test_sample_pair2(centre, Y * P - X * Q, inv_range, neg_front, reject)) +
-                                test_sample_pair2(centre, X * P + Y * Q, inv_range, neg_front, reject)) +
-                               test_sample_pair2(centre, X * P - Y * Q, inv_range, neg_front, reject));
+        return ((test_sample_pair2(centre, Y * P + X * Q, inv_range, neg_front, reject) +
+                 test_sample_pair2(centre, Y * P - X * Q, inv_range, neg_front, reject)) +
+                test_sample_pair2(centre, X * P + Y * Q, inv_range, neg_front, reject)) +
+               test_sample_pair2(centre, X * P - Y * Q, inv_range, neg_front, reject);
     }
 }
 
 // ao = sum over the terms of weight * TestSamples, in the reference's accumulation order:
 // checker set REN:162-168 (slots 1,3,4,8,11,6,10), SAMPLE_EXHAUSTIVELY REN:146-157
-// (slots 0,1,2,3,4,8,11,5,6,7,9,10).  L.weight[] etc. are already in term order.
+// (slots 0,1,2,3,4,8,11,5,6,7,9,10).  L.weight[] etc. are already in term order; L.weight[] carries
+// the 0.5 (axial, diagonal) / 0.25 (L-shaped) factor of TestSamples.
 template <bool EXH, int P, int Q>
 __device__ __forceinline__ float2v accumulate_terms(const RenderLevelArgs &L, const float *centre, float2v inv_depth)
 {
@@ -434,8 +449,8 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
                 const float *row = src + static_cast<size_t>(py) * lw + px0;
                 if (vec_ok && px0 + 3 < lw) {
                     const float4v r = *reinterpret_cast<const float4v *>(row);
-                    t.x = through_f16<RTNE>(r.x); t.y = through_f16<RTNE>(r.y);
-                    t.z = through_f16<RTNE>(r.z); t.w = through_f16<RTNE>(r.w);
+                    const float2v lo = through_f16_pair<RTNE>(r.x, r.y), hi = through_f16_pair<RTNE>(r.z, r.w);
+                    t = float4v{lo.x, lo.y, hi.x, hi.y};
                 } else {
                     if (px0 + 0 < lw) t.x = through_f16<RTNE>(row[0]);
                     if (px0 + 1 < lw) t.y = through_f16<RTNE>(row[1]);

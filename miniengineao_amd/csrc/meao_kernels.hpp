@@ -38,7 +38,8 @@ struct RenderLevelArgs {
     int32_t tiles_x, tiles_y;
     int32_t block_begin;   // first linear workgroup id of this level
     float pad_value;       // value of atlas texels beyond the level
-    float inv_thickness[12], front_depth[12], weight[12];   // per term, accumulation order
+    float inv_thickness[12], front_depth[12];   // per term, accumulation order
+    float weight[12];                           // sample weight x the 0.5 / 0.25 factor of TestSamples
     float reject_fadeoff, intensity;
 };
 

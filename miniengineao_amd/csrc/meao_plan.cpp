@@ -26,6 +26,16 @@ Dims level_dims(int width, int height, int level)
     return d;
 }
 
+float render_term_scale(int sample_set, int term)
+{
+    // (x, y) of the terms in accumulation order; y == 0 axial, x == y diagonal, else L-shaped
+    static const int checker[7][2] = {{2, 0}, {4, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 3}, {2, 4}};
+    static const int exhaustive[12][2] = {{1, 0}, {2, 0}, {3, 0}, {4, 0}, {1, 1}, {2, 2},
+                                          {3, 3}, {1, 2}, {1, 3}, {1, 4}, {2, 3}, {2, 4}};
+    const int *xy = sample_set == MEAO_SAMPLES_EXHAUSTIVE ? exhaustive[term] : checker[term];
+    return (xy[1] == 0 || xy[0] == xy[1]) ? 0.5f : 0.25f;
+}
+
 void zbuffer_params(const meao_params &p, float out[4])
 {
     const float far_over_near = p.far_clip / p.near_clip;  // AO.cs:563
@@ -146,6 +156,7 @@ static void fill_terms(RenderLevelPlan &r, int sample_set)
         r.inv_thickness[t] = r.cb.inv_thickness_table[slots[t]];
         r.front_depth[t] = r.inv_thickness[t] - 0.5f;  // Render.compute:85
         r.weight[t] = r.cb.sample_weight_table[slots[t]];
+        r.scaled_weight[t] = r.weight[t] * render_term_scale(sample_set, t);   // power of two: exact
     }
 }
 

@@ -20,6 +20,8 @@ struct Dims { int w = 0, h = 0; };
 // 0,1,2,3,4,8,11,5,6,7,9,10 (Render.compute:146-157).
 constexpr int kMaxRenderTerms = 12;
 int render_term_slots(int sample_set, const int **slots);   // returns the number of terms
+// leading factor of TestSamples for each term (Render.compute:87-109): 0.5 axial / diagonal, 0.25 L-shaped
+float render_term_scale(int sample_set, int term);
 
 struct RenderLevelPlan {
     meao_render_constants cb;                 // the reference's constant block, verbatim
@@ -27,6 +29,7 @@ struct RenderLevelPlan {
     float inv_thickness[kMaxRenderTerms];     // cb.inv_thickness_table[slot]
     float front_depth[kMaxRenderTerms];       // inv_thickness - 0.5   (Render.compute:85)
     float weight[kMaxRenderTerms];            // cb.sample_weight_table[slot]
+    float scaled_weight[kMaxRenderTerms];     // weight * render_term_scale (exact): what the kernels multiply by
     float pad_value;                          // what an out-of-level atlas texel holds
 };
 
