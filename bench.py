@@ -89,8 +89,11 @@ def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
     try:
         table = json.load(open(path))
         row = table[workload][kernel]
-        return {"bytes": int(row["bytes_per_frame"] * frames_per_launch), "source": "profiles/pmc_traffic.json",
-                "note": row.get("note", "")}
+        out = {"bytes": int(row["bytes_per_frame"] * frames_per_launch), "source": "profiles/pmc_traffic.json",
+               "note": row.get("note", "")}
+        if "valu_wave_insts_per_frame" in row:      # SQ_INSTS_VALU of the same PMC passes
+            out["valu_wave_insts"] = int(row["valu_wave_insts_per_frame"] * frames_per_launch)
+        return out
     except (OSError, KeyError, ValueError):
         return None
 
@@ -223,6 +226,12 @@ def main() -> int:
     kernel_ms = float(sum(pass_ms))
     whole_gbps = sum(alg) * B / (kernel_ms * 1e-3) / 1e9
     ren_ups_gbps = sum(alg[1:]) * B / (sum(pass_ms[1:]) * 1e-3) / 1e9
+    if traffic and "valu_wave_insts" in traffic:
+        # what actually limits the kernel: VALU wave-instructions issued per SIMD (1024 SIMDs) over the
+        # measured launch time; tools/ubench_valu.hip: 3.0 (fma/mul/add) .. 4.4 (med3/cmp/cvt) .. 8.4 (rcp)
+        # cycles per instruction at the 2.4 GHz peak clock
+        traffic["valu_cycles_per_wave_inst_per_simd"] = round(
+            pass_ms[dominant] * 1e-3 * 2.4e9 / (traffic["valu_wave_insts"] / 1024.0), 2)
     roofline = {"bound": "hbm", "limiter": "valu" if dominant != 0 else "hbm",
                 "kernel": _lib.PASS_NAMES[dominant], "achieved": round(dom_gbps, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBPS, 4),

@@ -38,6 +38,7 @@ def mean_counter(root, group, counter):
 def main():
     root, workload, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
     fetch, write = mean_counter(root, "fetch", "FETCH_SIZE"), mean_counter(root, "write", "WRITE_SIZE")
+    valu = mean_counter(root, "sq1", "SQ_INSTS_VALU")      # VALU wave-instructions per dispatch, whole GPU
     table = {}
     for frag, (name, factor, note) in KERNELS.items():
         f = [v for k, v in fetch.items() if frag in k]
@@ -48,6 +49,9 @@ def main():
         table[name] = {"bytes_per_frame": round((fb + wb) / frames), "fetch_bytes_per_frame": round(fb / frames),
                        "write_bytes_per_frame": round(wb / frames), "fetch_size_factor": factor,
                        "frames_per_launch": frames, "note": note}
+        v = [x for k, x in valu.items() if frag in k]
+        if v:
+            table[name]["valu_wave_insts_per_frame"] = round(v[0] / frames)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     try:
         full = json.load(open(path))
