@@ -120,6 +120,9 @@ def main() -> int:
                          "(wide) and the upsamples become main_premin*; changes config.workload")
     ap.add_argument("--exhaustive", action="store_true",
                     help="variant: SAMPLE_EXHAUSTIVELY (68 samples instead of 36); changes config.workload")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not use meao_prefetch_batch: every step launches its own downsample pass instead of "
+                         "carrying the next step's inside its last upsample kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
@@ -175,9 +178,15 @@ def main() -> int:
     optr = optrs[0]
     counter = [0]
 
+    pipelined = not args.no_pipeline
+
     def step():
         k = counter[0] % nfl
         counter[0] += 1
+        if pipelined:
+            # streaming use: the frames of this context's NEXT step are announced, so this step's last
+            # kernel also runs their downsample pass (every step still does one downsample pass of work)
+            ctxs[k].prefetch_device(dptr)
         ctxs[k].execute_device(dptr, optrs[k], streams[k])
 
     def fence():
@@ -212,20 +221,28 @@ def main() -> int:
 
     # roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration
     alg = ao.algorithmic_bytes()                 # per frame, reference storage formats
+    names = list(_lib.PASS_NAMES)
+    ren_ups_bytes = sum(alg[1:])                 # render + upsample passes only (north_star's sub-path)
+    if pipelined:
+        # the downsample pass of the next step runs inside the last upsample kernel: its bytes move there
+        u0, d0 = names.index("upsample_L1_to_L0"), names.index("downsample")
+        alg[u0] += alg[d0]
+        alg[d0] = 0
+        names[u0] = "upsample_L1_to_L0+downsample_next"
     dominant = int(np.argmax(pass_ms))
     passes = []
     for k in range(_lib.NUM_PASSES):
         if pass_ms[k] <= 0:
             continue
         gbps = alg[k] * B / (pass_ms[k] * 1e-3) / 1e9
-        passes.append({"kernel": _lib.PASS_NAMES[k], "ms": round(pass_ms[k], 5),
+        passes.append({"kernel": names[k], "ms": round(pass_ms[k], 5),
                        "algorithmic_MB": round(alg[k] * B / 1e6, 3), "GBps": round(gbps, 1),
                        "frac": round(gbps / HBM_PEAK_GBPS, 4)})
     dom_gbps = alg[dominant] * B / (pass_ms[dominant] * 1e-3) / 1e9
-    traffic = pmc_traffic(args.workload, _lib.PASS_NAMES[dominant], B)
+    traffic = pmc_traffic(args.workload, names[dominant], B)
     kernel_ms = float(sum(pass_ms))
     whole_gbps = sum(alg) * B / (kernel_ms * 1e-3) / 1e9
-    ren_ups_gbps = sum(alg[1:]) * B / (sum(pass_ms[1:]) * 1e-3) / 1e9
+    ren_ups_gbps = ren_ups_bytes * B / (sum(pass_ms[1:]) * 1e-3) / 1e9   # (pipelined: the time includes the carried downsample)
     if traffic and "valu_wave_insts" in traffic:
         # what actually limits the kernel: VALU wave-instructions issued per SIMD (1024 SIMDs) over the
         # measured launch time; tools/ubench_valu.hip: 3.0 (fma/mul/add) .. 4.4 (med3/cmp/cvt) .. 8.4 (rcp)
@@ -233,7 +250,7 @@ def main() -> int:
         traffic["valu_cycles_per_wave_inst_per_simd"] = round(
             pass_ms[dominant] * 1e-3 * 2.4e9 / (traffic["valu_wave_insts"] / 1024.0), 2)
     roofline = {"bound": "hbm", "limiter": "valu" if dominant != 0 else "hbm",
-                "kernel": _lib.PASS_NAMES[dominant], "achieved": round(dom_gbps, 1),
+                "kernel": names[dominant], "achieved": round(dom_gbps, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "launch_ms": round(pass_ms[dominant], 5), "event_samples": samples,
                 "whole_frame": {"GBps": round(whole_gbps, 1), "frac": round(whole_gbps / HBM_PEAK_GBPS, 4)},
@@ -305,7 +322,9 @@ def main() -> int:
             "config": {"workload": desc, "width": w, "height": h, "frames_per_step_per_gpu": B,
                        "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
                        "numerics": "FAST (raw rcp, not bit-exact)" if args.fast_numerics else "strict (bit-exact vs CPU oracle)", "sharding": f"frames x{world}",
-                       "batches_in_flight": nfl},
+                       "batches_in_flight": nfl,
+                       "downsample": "pipelined: each step's last kernel carries the next step's downsample pass "
+                                     "(meao_prefetch_batch)" if pipelined else "own pass per step"},
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "single_frame": single,

@@ -126,6 +126,7 @@ namespace MiniEngineAO.Native
 
         [DllImport(Lib)] public static extern int meao_execute(IntPtr ctx, IntPtr depth, int depth_loc, IntPtr ao_out, int out_loc, IntPtr stream);
         [DllImport(Lib)] public static extern int meao_execute_batch(IntPtr ctx, int n, IntPtr[] depth, int depth_loc, IntPtr[] ao_out, int out_loc, IntPtr stream);
+        [DllImport(Lib)] public static extern int meao_prefetch_batch(IntPtr ctx, int n, IntPtr[] depth);
         [DllImport(Lib)] public static extern int meao_synchronize(IntPtr ctx, IntPtr stream);
 
         [DllImport(Lib)] public static extern int meao_get_intermediate(IntPtr ctx, int frame, int debug_id, IntPtr dst, ulong dst_capacity, int dst_loc, out MeaoDesc desc);

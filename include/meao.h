@@ -235,6 +235,16 @@ MEAO_API int32_t meao_execute(meao_ctx *ctx, const void *depth, int32_t depth_lo
 MEAO_API int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth,
                                     int32_t depth_loc, void *const *ao_out, int32_t out_loc,
                                     meao_stream stream);
+/* Pipelining for streams of frames.  Announces the DEVICE depth frames of the call after next: the
+ * following meao_execute* carries their downsample pass inside its last (VALU-bound) upsample
+ * kernel, where the pass's HBM traffic hides under arithmetic instead of costing ~20 % of a frame;
+ * the meao_execute* after that, if given exactly these n pointers, skips its own downsample pass.
+ * Results are identical.  Rules: the announced buffers must hold their final contents before the
+ * carrying execute is submitted and stay unchanged until the consuming one has run; consecutive
+ * pipelined executes go to the same stream; meao_set_params / meao_resize drop a pending
+ * announcement and any prefetched downsample (the next execute then runs the pass itself).  The
+ * first call re-allocates the context's intermediates with a second set of downsample buffers. */
+MEAO_API int32_t meao_prefetch_batch(meao_ctx *ctx, int32_t n, const void *const *depth);
 MEAO_API int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream);
 
 /* ---- observability (replaces the _debug 1..17 views, AO.cs:787-820) --------------------- */

@@ -101,6 +101,7 @@ SIGNATURES = {
     "meao_execute": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "meao_execute_batch": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                        C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "meao_prefetch_batch": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "meao_synchronize": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "meao_get_intermediate": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64,
                                           C.c_int32, C.POINTER(Desc)]),

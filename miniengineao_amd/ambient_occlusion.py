@@ -150,6 +150,13 @@ class AmbientOcclusion:
         L.check(self._lib.meao_execute_batch(self._ctx, n, pin, L.MEM_DEVICE, pout, L.MEM_DEVICE,
                                              C.c_void_p(stream) if stream else None), self._ctx)
 
+    def prefetch_device(self, depth_ptrs: Sequence[int]) -> None:
+        """Announce the device depth frames of the call after next (meao_prefetch_batch): the next
+        execute_device() carries their downsample pass inside its last upsample kernel."""
+        n = len(depth_ptrs)
+        pin = (C.c_void_p * n)(*depth_ptrs)
+        L.check(self._lib.meao_prefetch_batch(self._ctx, n, pin), self._ctx)
+
     def synchronize(self, stream: int = 0) -> None:
         L.check(self._lib.meao_synchronize(self._ctx, C.c_void_p(stream) if stream else None), self._ctx)
 

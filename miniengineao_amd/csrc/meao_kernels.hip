@@ -235,10 +235,9 @@ __device__ __forceinline__ float linearize(float depth, float zp0, float zp1, bo
 }
 
 template <bool RTNE, bool VEC, int DIV>
-__global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleArgs a)
+__device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int tile, int frame)
 {
-    const int frame = blockIdx.z;
-    const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+    const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const void *__restrict__ depth = a.depth[frame];
     uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
     float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
@@ -338,6 +337,12 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleAr
             }
         }
     }
+}
+
+template <bool RTNE, bool VEC, int DIV>
+__global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleArgs a)
+{
+    downsample_tile<RTNE, VEC, DIV>(a, blockIdx.x, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -627,8 +632,10 @@ __device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao,
     return div_strict<DIV>(hi_ao * sum, total);
 }
 
+// One tile of Upsample.main (FINAL) / main_blendout; every thread of the workgroup must call it
+// (barriers inside; lanes outside the image leave after the last one).
 template <int AOFMT, bool RTNE, bool FINAL, int DIV>
-__global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a)
+__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, int frame)
 {
     typedef AoTexel<AOFMT> AO;
     typedef typename AO::type ao_t;
@@ -640,8 +647,7 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
     __shared__ __attribute__((aligned(16))) float s_hb[T::kRawRows * T::kBlurPitch];   // after BlurHorizontally (AOCache2)
     float *const s_vb = s_ao;   // after BlurVertically (AOCache1): the raw taps are dead once H-blurred
 
-    const int frame = blockIdx.z;
-    const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+    const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int HX0 = tile_x * kUpsTileW, HY0 = tile_y * kTileH;
     const int LX0 = HX0 >> 1, LY0 = HY0 >> 1;
     const int lw = a.lw, lh = a.lh, hw = a.hw, hh = a.hh;
@@ -816,6 +822,32 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
             }
         }
     }
+}
+
+template <int AOFMT, bool RTNE, bool FINAL, int DIV>
+__global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a)
+{
+    upsample_tile<AOFMT, RTNE, FINAL, DIV>(a, blockIdx.x, blockIdx.z);
+}
+
+// Upsample.main of this batch carrying the downsample pass of the NEXT batch (meao_prefetch_batch):
+// the final upsample is VALU-bound (five exact divides per texel) and leaves HBM idle, the
+// downsample is pure streaming with ~2 VALU ops per byte -- inside one kernel the streaming hides
+// under the arithmetic of the other resident workgroups instead of costing a pass of its own.
+// The downsample tiles (128 x 32 texels) of `d` are spread over this kernel's grid; each workgroup
+// streams its share first and then does its upsample tile.
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(kThreads) void upsample_final_with_next_downsample_kernel(const UpsampleArgs a,
+                                                                                       const DownsampleArgs d)
+{
+    const int ds_tiles = d.tiles_x * d.tiles_y;
+    const bool vec = (d.w[0] & 3) == 0;
+    for (int f = blockIdx.z; f < d.frames; f += gridDim.z)
+        for (int t = blockIdx.x; t < ds_tiles; t += gridDim.x) {
+            if (vec) downsample_tile<RTNE, true, DIV>(d, t, f);
+            else downsample_tile<RTNE, false, DIV>(d, t, f);
+        }
+    upsample_tile<AOFMT, RTNE, true, DIV>(a, blockIdx.x, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1104,6 +1136,30 @@ hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f
         else if (a.exact_rcp_div == 2) launch_upsample_t<MEAO_AO_F16, false, DIV_FAST>(a, hi_depth_f16, grid, s);
         else if (a.exact_rcp_div) launch_upsample_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, hi_depth_f16, grid, s);
         else launch_upsample_t<MEAO_AO_F16, false, DIV_IEEE>(a, hi_depth_f16, grid, s);
+    }
+    return hipGetLastError();
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+static void launch_upsample_fused_t(const UpsampleArgs &a, const DownsampleArgs &d, dim3 grid, hipStream_t s)
+{
+    upsample_final_with_next_downsample_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a, d);
+}
+
+hipError_t launch_upsample_final_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format,
+                                                 int frames, hipStream_t s)
+{
+    const dim3 grid(a.tiles_x * a.tiles_y, 1, frames);
+    if (ao_format == MEAO_AO_R8) {
+        if (a.f16_rtne) launch_upsample_fused_t<MEAO_AO_R8, true, DIV_IEEE>(a, d, grid, s);
+        else if (a.exact_rcp_div == 2) launch_upsample_fused_t<MEAO_AO_R8, false, DIV_FAST>(a, d, grid, s);
+        else if (a.exact_rcp_div) launch_upsample_fused_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(a, d, grid, s);
+        else launch_upsample_fused_t<MEAO_AO_R8, false, DIV_IEEE>(a, d, grid, s);
+    } else {
+        if (a.f16_rtne) launch_upsample_fused_t<MEAO_AO_F16, true, DIV_IEEE>(a, d, grid, s);
+        else if (a.exact_rcp_div == 2) launch_upsample_fused_t<MEAO_AO_F16, false, DIV_FAST>(a, d, grid, s);
+        else if (a.exact_rcp_div) launch_upsample_fused_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, d, grid, s);
+        else launch_upsample_fused_t<MEAO_AO_F16, false, DIV_IEEE>(a, d, grid, s);
     }
     return hipGetLastError();
 }

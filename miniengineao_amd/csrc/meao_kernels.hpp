@@ -22,6 +22,7 @@ struct DownsampleArgs {
     int32_t f16_rtne;
     int32_t exact_rcp_div;
     int32_t tiles_x, tiles_y;
+    int32_t frames;                      // used by the fused kernel only (the plain launch has grid.z = frames)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -97,6 +98,9 @@ hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStre
 hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
+// Upsample.main of this batch + the downsample pass of the next one in a single kernel.
+hipError_t launch_upsample_final_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format,
+                                                 int frames, hipStream_t s);
 hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s);
 // Debug view (PushDebugBlitCommands): src in `src_format` (meao_format), [slices][sh][sw] -> dst AO W x H.
 struct DebugViewArgs {

@@ -223,3 +223,51 @@ def test_fast_numerics_stays_within_one_storage_step(oracle, ao_format):
         assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
     else:
         assert diff.max() <= 8 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
+
+
+@pytest.mark.parametrize("variant", [dict(), dict(ao_format=1, f16_rounding=1), dict(hq_levels=1, num_levels=3)])
+@pytest.mark.parametrize("w,h,batch", [(322, 182, 1), (256, 128, 3), (131, 77, 2)])
+def test_pipelined_downsample(oracle, variant, w, h, batch):
+    """meao_prefetch_batch: the downsample pass of the next call runs inside the last upsample kernel
+    of the current one.  A stream of different frames, a mispredicted announcement, a property change
+    and a resize in between: every result and every intermediate stays bit-exact."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = H.settings(oracle, w, h, **variant)
+    ao = H.component(s, max_batch=batch)
+    dt = torch.uint8 if s.ao_format == 0 else torch.int16
+    try:
+        sets = [[synth.make("S2", w, h, seed=100 * k + f) for f in range(batch)] for k in range(5)]
+        d_in = [[torch.from_numpy(f).to(dev) for f in fs] for fs in sets]
+        d_out = [torch.zeros((h, w), dtype=dt, device=dev) for _ in range(batch)]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ptrs = lambda k: [t.data_ptr() for t in d_in[k]]                      # noqa: E731
+        optr = [t.data_ptr() for t in d_out]
+
+        def run(k, announce=None, settings=s):
+            if announce is not None:
+                ao.prefetch_device(ptrs(announce))
+            ao.execute_device(ptrs(k), optr, stream)
+            torch.cuda.synchronize(dev)
+            for f in range(batch):
+                want = oracle.run(sets[k][f], settings, result_only=True)["result"]
+                got = d_out[f].cpu().numpy().view(want.dtype)
+                assert np.array_equal(got, want), (k, f, H.diff_report("result", got, want))
+
+        run(0, announce=1)                 # downsample of set 1 rides in this call
+        run(1, announce=2)                 # consumes it, carries set 2
+        want = oracle.run(sets[1][batch - 1], s)
+        for i in H.valid_debug_ids(s.num_levels, s.hq_levels):               # intermediates come from the prefetched set
+            assert np.array_equal(ao.debug_buffer(i, frame=batch - 1), want[H.NAMES[i]]), i
+        run(2, announce=4)                 # consumes set 2, carries set 4 ...
+        run(3)                             # ... but set 3 arrives: mispredicted, runs its own downsample
+        run(4)                             # the stale prefetch was dropped by the previous call
+        run(0, announce=0)                 # steady state of bench.py: the same frames announced again
+        run(0, announce=0)
+        ao.intensity = 0.7                 # property change between announce-carrying call and consumer
+        s2 = H.settings(oracle, w, h, intensity=0.7, **variant)
+        run(0, settings=s2)
+        run(1, announce=2, settings=s2)
+        run(2, settings=s2)
+    finally:
+        ao.close()
