@@ -104,6 +104,13 @@ public:
         cfg_.height = pixelHeight;
     }
 
+    // Streams of frames: announce the device depth frames of the call after next; the next Render*
+    // carries their downsample pass inside its last kernel (meao_prefetch_batch).
+    void PrefetchBatch(const std::vector<const void *> &nextDeviceDepth)
+    {
+        check(meao_prefetch_batch(ctx_, static_cast<int32_t>(nextDeviceDepth.size()), nextDeviceDepth.data()));
+    }
+
     void Synchronize(meao_stream stream = nullptr) { check(meao_synchronize(ctx_, stream)); }
 
     // The _debug 1..17 views (AO.cs:787-820) and OcclusionHQ1..4 (18..21), copied to the host.

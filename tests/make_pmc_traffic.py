@@ -23,7 +23,13 @@ KERNELS = {
     "render_kernel": ("render", 2.0, "window fill is 16 B/lane: FETCH_SIZE x2"),
     "upsample_kernel<0, false, true": ("upsample_L1_to_L0", 1.0, "8 B/lane (f16 depth) + 16 B/lane + 4 B/lane reads: FETCH_SIZE left raw (uncalibrated width); raw value equals compulsory + apron bytes"),
     "upsample_kernel<0, false, false": ("upsample_blend_passes", 1.0, "mean of the three main_blendout launches; FETCH_SIZE raw"),
+    # the last upsample kernel carrying the next batch's downsample pass (meao_prefetch_batch): the carried
+    # 16 B/lane depth stream (4*W*H bytes per frame, known exactly) is tallied at half size like in
+    # downsample_kernel, the upsample reads are raw -> add the missing half of the depth stream
+    "upsample_final_with_next_downsample_kernel<0, false": ("upsample_L1_to_L0+downsample_next", 1.0,
+                                                           "FETCH_SIZE raw + 2*W*H bytes per frame (the half of the carried 16 B/lane depth stream that the counter misses)"),
 }
+DEPTH_STREAM_HALF = {"4k": 2 * 3840 * 2160, "1080p": 2 * 1920 * 1080, "8k": 2 * 7680 * 4320}
 
 
 def mean_counter(root, group, counter):
@@ -46,6 +52,8 @@ def main():
         if not f or not w:
             continue
         fb, wb = f[0] * 1024 * factor, w[0] * 1024
+        if "downsample_next" in name:
+            fb += DEPTH_STREAM_HALF[workload] * frames
         table[name] = {"bytes_per_frame": round((fb + wb) / frames), "fetch_bytes_per_frame": round(fb / frames),
                        "write_bytes_per_frame": round(wb / frames), "fetch_size_factor": factor,
                        "frames_per_launch": frames, "note": note}
