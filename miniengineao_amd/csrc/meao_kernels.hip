@@ -226,12 +226,13 @@ __device__ __forceinline__ float div_strict(float a, float b)
 constexpr int kDsTileW = 128, kDsTileH = 32, kDsRowsPerPass = 8;
 
 template <int DIV>
-__device__ __forceinline__ float linearize(float depth, float zp0, float zp1, bool reversed)
+__device__ __forceinline__ float linearize(float depth, float zp0, float zp1, float sky_depth)
 {
     // ZBufferParams.x * d + ZBufferParams.y lies in [1, far/near] for every depth in [0, 1]
-    float dist = rcp_strict<DIV>(mad(zp0, depth, zp1));              // DS1:40
-    if (reversed ? (depth == 0.0f) : (depth == 1.0f)) dist = 1e5f;  // DS1:41-45
-    return dist;
+    const float dist = rcp_strict<DIV>(mad(zp0, depth, zp1));       // DS1:40
+    // DS1:41-45: depth == 0 (reversed Z) / == 1 marks the far plane; sky_depth is that constant, so the
+    // test is one v_cmp + v_cndmask per texel instead of a uniform branch on the Z convention
+    return depth == sky_depth ? 1e5f : dist;
 }
 
 template <bool RTNE, bool VEC, int DIV>
@@ -245,7 +246,7 @@ __device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int til
     float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
     float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
     const int W = a.w[0], H = a.h[0];
-    const bool reversed = a.reversed_z != 0;
+    const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
 
     const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
     const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
@@ -306,7 +307,7 @@ __device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int til
         if (y >= H) continue;
         float lin[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], a.zp0, a.zp1, reversed);
+        for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], a.zp0, a.zp1, sky_depth);
 
         uint16_t *lrow = linear + static_cast<size_t>(y) * W + x0;    // LinearZ[st] = dist (DS1:46)
         if constexpr (VEC) {
