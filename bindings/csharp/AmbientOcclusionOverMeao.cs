@@ -95,6 +95,13 @@ namespace MiniEngineAO
             }
         }
 
+        // Streams of frames: announce the device depth buffer of the frame AFTER the next Render call;
+        // that Render then carries its downsample pass inside its last kernel (meao_prefetch_batch).
+        public void PrefetchNext(IntPtr nextDeviceDepth)
+        {
+            Check(Meao.meao_prefetch_batch(_ctx, 1, new IntPtr[] { nextDeviceDepth }));
+        }
+
         // Device-resident depth in -> AO texture out (the recorded "SSAO" command buffer,
         // AO.cs:496-531).  Asynchronous on `stream`.
         public void Render(IntPtr deviceDepth, IntPtr deviceAo, int pixelWidth, int pixelHeight, IntPtr stream)
