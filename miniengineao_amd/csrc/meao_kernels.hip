@@ -642,11 +642,29 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
     typedef typename AO::type ao_t;
     constexpr int kTileH = ups_tile_h(FINAL);
     typedef UpsTile<kTileH> T;
-    __shared__ __attribute__((aligned(16))) float s_ao[T::kRawRows * T::kRawPitch];    // LoResAO1 taps (AOCache1 before blur)
-    __shared__ __attribute__((aligned(16))) float s_inv[T::kRawRows * T::kRawPitch];   // 1 / LoResDB   (DepthCache)
-    __shared__ __attribute__((aligned(16))) float s_dep[T::kRawH * T::kRawPitch];      // LoResDB       (LoDepths gather)
-    __shared__ __attribute__((aligned(16))) float s_hb[T::kRawRows * T::kBlurPitch];   // after BlurHorizontally (AOCache2)
-    float *const s_vb = s_ao;   // after BlurVertically (AOCache1): the raw taps are dead once H-blurred
+    // One allocation, carved so that the scratch rows the last V-blur run reads past the raw window
+    // (rows kRawH .. kRawRows-1 of s_inv and s_hb; their products are never used) fall into the next
+    // array instead of being allocated.  In the full-resolution pass the LoResDB window is also cut to
+    // what the bilateral phase gathers (rows / columns 2 .. kLow+5): 22.3 KB per workgroup instead of
+    // 24.1 KB, which lets a seventh workgroup share the CU's 160 KB (with __launch_bounds__(.., 7):
+    // A/B on one box, 357 -> 343 us for the kernel that also carries the next downsample pass).
+    constexpr int kDep0 = FINAL ? 2 : 0;                                   // first row / column kept
+    constexpr int kDepH = FINAL ? T::kLowH + 4 : T::kRawH, kDepW = FINAL ? T::kLowW + 4 : T::kRawW;
+    constexpr int kDepPitch = FINAL ? 36 : T::kRawPitch;
+    constexpr int kInvN = T::kRawH * T::kRawPitch, kHbN = T::kRawH * T::kBlurPitch, kDepN = kDepH * kDepPitch;
+    constexpr int kAoN = T::kRawH * T::kRawPitch;
+    static_assert(kDepW <= kDepPitch && (T::kRawRows - T::kRawH) * T::kRawPitch <= kHbN &&
+                  (T::kRawRows - T::kRawH) * T::kBlurPitch <= kDepN + kAoN, "scratch rows stay inside the allocation");
+    static_assert(T::kVRows * T::kBlurPitch <= kAoN, "s_vb fits in s_ao");
+    static_assert(kInvN % 4 == 0 && kHbN % 4 == 0 && kDepN % 4 == 0, "16-byte alignment of the carved arrays");
+    __shared__ __attribute__((aligned(16))) float smem[kInvN + kHbN + kDepN + kAoN];
+    float *const s_inv = smem;                       // 1 / LoResDB   (DepthCache)
+    float *const s_hb = s_inv + kInvN;               // after BlurHorizontally (AOCache2)
+    float *const s_dep = s_hb + kHbN;                // LoResDB       (LoDepths gather), window from (kDep0, kDep0)
+    float *const s_ao = s_dep + kDepN;               // LoResAO1 taps (AOCache1 before blur)
+    float *const s_vb = s_ao;                        // after BlurVertically (AOCache1): the raw taps are dead once H-blurred
+    auto dep_at = [&](int r, int c) -> float & { return s_dep[(r - kDep0) * kDepPitch + (c - kDep0)]; };
+    auto dep_kept = [&](int r, int c) { return !FINAL || (r >= kDep0 && r < kDep0 + kDepH && c >= kDep0 && c < kDep0 + kDepW); };
 
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int HX0 = tile_x * kUpsTileW, HY0 = tile_y * kTileH;
@@ -681,7 +699,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * k + e - 1;
                 if (c >= 0 && c < T::kRawW) {
-                    s_dep[r * T::kRawPitch + c] = dv[e];
+                    if (dep_kept(r, c)) dep_at(r, c) = dv[e];
                     s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
                     s_ao[r * T::kRawPitch + c] = av[e];
                 }
@@ -693,7 +711,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
             const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
             const size_t idx = static_cast<size_t>(cy) * lw + cx;
             const float d = lo_depth[idx];
-            s_dep[r * T::kRawPitch + c] = d;
+            if (dep_kept(r, c)) dep_at(r, c) = d;
             s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
             float av = AO::decode(lo_ao[idx]);
             if (lo_ao2) av = __builtin_fminf(av, AO::decode(lo_ao2[idx]));
@@ -756,8 +774,8 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
         for (int rr = 0; rr < 3; ++rr) {
             const float2v v0 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx]);
             const float2v v1 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx + 2]);
-            const float2v d0 = *reinterpret_cast<const float2v *>(&s_dep[(ty + rr + 2) * T::kRawPitch + 2 * tx + 2]);
-            const float2v d1 = *reinterpret_cast<const float2v *>(&s_dep[(ty + rr + 2) * T::kRawPitch + 2 * tx + 4]);
+            const float2v d0 = *reinterpret_cast<const float2v *>(&dep_at(ty + rr + 2, 2 * tx + 2));
+            const float2v d1 = *reinterpret_cast<const float2v *>(&dep_at(ty + rr + 2, 2 * tx + 4));
             vb[rr][0] = v0.x; vb[rr][1] = v0.y; vb[rr][2] = v1.x; vb[rr][3] = v1.y;
             dl[rr][0] = d0.x; dl[rr][1] = d0.y; dl[rr][2] = d1.x; dl[rr][3] = d1.y;
         }
@@ -826,7 +844,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
 }
 
 template <int AOFMT, bool RTNE, bool FINAL, int DIV>
-__global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a)
+__global__ __launch_bounds__(kThreads, FINAL ? 7 : 1) void upsample_kernel(const UpsampleArgs a)
 {
     upsample_tile<AOFMT, RTNE, FINAL, DIV>(a, blockIdx.x, blockIdx.z);
 }
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(kThreads) void upsample_kernel(const UpsampleArgs a
 // The downsample tiles (128 x 32 texels) of `d` are spread over this kernel's grid; each workgroup
 // streams its share first and then does its upsample tile.
 template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(kThreads) void upsample_final_with_next_downsample_kernel(const UpsampleArgs a,
+__global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsample_kernel(const UpsampleArgs a,
                                                                                        const DownsampleArgs d)
 {
     const int ds_tiles = d.tiles_x * d.tiles_y;
