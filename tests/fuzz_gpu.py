@@ -54,6 +54,22 @@ for k in range(count):
     ok = np.array_equal(outs[0], want["result"]) and np.array_equal(outs[1], want["result"])
     for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
         ok = ok and np.array_equal(ao.debug_buffer(i, frame=1), want[H.NAMES[i]])
+    if k % 3 == 1:
+        # the pipelined path: announce the same frames, run twice; the second call consumes the downsample
+        # that rode inside the first call's last kernel
+        import torch
+        raw_bytes = np.ascontiguousarray(depth).view(np.uint8)
+        d_in = [torch.from_numpy(raw_bytes.copy()).cuda() for _ in range(2)]
+        d_out = [torch.zeros((h, w), dtype=torch.uint8 if s.ao_format == 0 else torch.int16, device="cuda") for _ in range(2)]
+        pin, pout = [t.data_ptr() for t in d_in], [t.data_ptr() for t in d_out]
+        ao.prefetch_device(pin)
+        ao.execute_device(pin, pout)
+        ao.execute_device(pin, pout)
+        ao.synchronize()
+        for t in d_out:
+            ok = ok and np.array_equal(t.cpu().numpy().view(want["result"].dtype), want["result"])
+        for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+            ok = ok and np.array_equal(ao.debug_buffer(i, frame=1), want[H.NAMES[i]])
     ao.close()
     if not ok:
         bad += 1
