@@ -179,11 +179,12 @@ def main() -> int:
     counter = [0]
 
     pipelined = not args.no_pipeline
+    use_prefetch = [pipelined]
 
     def step():
         k = counter[0] % nfl
         counter[0] += 1
-        if pipelined:
+        if use_prefetch[0]:
             # streaming use: the frames of this context's NEXT step are announced, so this step's last
             # kernel also runs their downsample pass (every step still does one downsample pass of work)
             ctxs[k].prefetch_device(dptr)
@@ -215,6 +216,22 @@ def main() -> int:
         c.set_profiling(False)
 
     elapsed = mdist.max_over_ranks(elapsed, dev)
+
+    # for reference, the same K steps as the plain launch sequence (every step runs its own downsample pass)
+    plain = None
+    if pipelined:
+        use_prefetch[0] = False
+        for _ in range(3):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        plain_elapsed = mdist.max_over_ranks(time.perf_counter() - t1, dev)
+        plain = {"value": round(float(w) * h * B * args.steps * world / plain_elapsed / 1e6, 1),
+                 "ms_per_step": round(plain_elapsed / args.steps * 1e3, 4)}
+        use_prefetch[0] = True
 
     total_pixels = float(w) * h * B * args.steps * world
     value = total_pixels / elapsed / 1e6
@@ -329,6 +346,7 @@ def main() -> int:
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "single_frame": single,
+            "plain_launch_sequence": plain,
             "sum_kernel_ms_per_step": round(kernel_ms, 4),
         }
         print(json.dumps(line), flush=True)
