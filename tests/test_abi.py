@@ -181,6 +181,7 @@ def test_argument_validation(meao_lib):
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_UNSUPPORTED
     assert meao_lib.meao_destroy(None) == 0
     assert meao_lib.meao_execute(None, None, 0, None, 0, None) == L.ERR_INVALID_ARGUMENT
+    assert meao_lib.meao_prefetch_batch(None, 1, None) == L.ERR_INVALID_ARGUMENT
     assert meao_lib.meao_status_string(L.ERR_NO_DEVICE).startswith(b"no gfx950 device")
     p = L.Params()
     meao_lib.meao_default_params(C.byref(p))
