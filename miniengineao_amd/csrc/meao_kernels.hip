@@ -792,7 +792,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
             if constexpr (FINAL) {
                 const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
                 if (vec_ok) {
-                    const ushort4v q = *reinterpret_cast<const ushort4v *>(p);
+                    const ushort4v q = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(p));   // read once
                     hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
                     hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
                 } else {
@@ -836,7 +836,9 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
             ao_t *o = dst + hrow;
             if (vec_ok) {
                 typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
-                *reinterpret_cast<typename AO::type4 *>(o) = r4;
+                // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
+                if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
+                else *reinterpret_cast<typename AO::type4 *>(o) = r4;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
