@@ -98,7 +98,7 @@ namespace MiniEngineAO.Native
     {
         const string Lib = "meao_hip";   // libmeao_hip.so
         public const int AbiVersion = 3;
-        public const int MaxBatch = 16;
+        public const int MaxBatch = 64;
         public const int NumPasses = 7;
         public const int DebugOcclusionHq1 = 18;
         public const int NumBuffers = 21;

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define MEAO_ABI_VERSION 3
-#define MEAO_MAX_BATCH 16      /* frames per batched launch */
+#define MEAO_MAX_BATCH 64      /* frames per batched launch */
 #define MEAO_NUM_PASSES 7      /* downsample, render, upsample x4, render_hq (see meao_pass) */
 
 typedef struct meao_ctx meao_ctx;

@@ -22,7 +22,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmeao_hip.so")
 
 ABI_VERSION = 3
-MAX_BATCH = 16
+MAX_BATCH = 64
 NUM_PASSES = 7
 PASS_NAMES = ("downsample", "render", "upsample_L4_to_L3", "upsample_L3_to_L2",
               "upsample_L2_to_L1", "upsample_L1_to_L0", "render_hq")

@@ -167,7 +167,7 @@ def test_argument_validation(meao_lib):
     assert b"num_levels" in meao_lib.meao_last_error(None)
     bad = L.Config.from_buffer_copy(cfg); bad.struct_size = 12
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
-    bad = L.Config.from_buffer_copy(cfg); bad.max_batch = 17
+    bad = L.Config.from_buffer_copy(cfg); bad.max_batch = 65
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
     bad = L.Config.from_buffer_copy(cfg); bad.hq_levels = 5
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT

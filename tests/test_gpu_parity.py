@@ -146,6 +146,31 @@ def test_batch_matches_per_frame(oracle):
         ao.close()
 
 
+def test_largest_batch(oracle):
+    """MEAO_MAX_BATCH = 64 frames through one launch per pass, incl. the pipelined path."""
+    import torch
+    from miniengineao_amd import _lib as L
+    w, h, n = 136, 72, L.MAX_BATCH
+    s = H.settings(oracle, w, h)
+    depths = [synth.make("S2", w, h, seed=300 + f) for f in range(n)]
+    wants = [oracle.run(d, s, result_only=True)["result"] for d in depths]
+    ao = H.component(s, max_batch=n)
+    try:
+        outs = ao.render_batch(depths)
+        assert all(np.array_equal(outs[f], wants[f]) for f in range(n))
+        d_in = [torch.from_numpy(d).cuda() for d in depths]
+        d_out = [torch.zeros((h, w), dtype=torch.uint8, device="cuda") for _ in range(n)]
+        pin, pout = [t.data_ptr() for t in d_in], [t.data_ptr() for t in d_out]
+        for _ in range(2):
+            ao.prefetch_device(pin)
+            ao.execute_device(pin, pout)
+        ao.synchronize()
+        assert all(np.array_equal(d_out[f].cpu().numpy(), wants[f]) for f in range(n))
+        assert np.array_equal(ao.debug_buffer(2, frame=n - 1), oracle.run(depths[n - 1], s)["low_depth1"])
+    finally:
+        ao.close()
+
+
 @pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6])
 def test_hardware_conversions_exhaustive(oracle, which):
     """All 2^32 f32 -> f16 inputs (both rounding modes), all 256 UNORM8 and all 65536 f16
