@@ -269,5 +269,17 @@ def test_pipelined_downsample(oracle, variant, w, h, batch):
         run(0, settings=s2)
         run(1, announce=2, settings=s2)
         run(2, settings=s2)
+        # a resize between the announcing call and the consumer drops the prefetched set as well
+        ao.prefetch_device(ptrs(3))
+        ao.execute_device(ptrs(2), optr, stream)
+        torch.cuda.synchronize(dev)
+        w2, h2 = w - 6, h - 3
+        ao.resize(w2, h2)
+        s3 = H.settings(oracle, w2, h2, intensity=0.7, **variant)
+        ao.projection00 = s3.proj00
+        small = [synth.make("S2", w2, h2, seed=900 + f) for f in range(batch)]
+        outs = ao.render_batch(small)
+        for f in range(batch):
+            assert np.array_equal(outs[f], oracle.run(small[f], s3, result_only=True)["result"]), f
     finally:
         ao.close()
