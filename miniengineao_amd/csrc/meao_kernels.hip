@@ -3,7 +3,10 @@
 // One workgroup = 256 threads = 4 wave64.  Kernels (stream order, one launch each per batch):
 //   downsample_kernel  Downsample1.main + Downsample2.main   (DS1:52-81, DS2:32-51)
 //   render_kernel      Render.main_interleaved, all levels   (REN:112-177)
-//   upsample_kernel    Upsample.main / main_blendout         (UPS:185-233)
+//   render_wide_kernel Render.main on LowDepth<k> (opt-in hq_levels variant)
+//   upsample_kernel    Upsample.main / main_blendout [/ main_premin*]   (UPS:185-233)
+//   upsample_final_with_next_downsample_kernel   Upsample.main of this batch + the downsample pass
+//                      of the next one (meao_prefetch_batch): streaming hidden under VALU-bound work
 // (DS1/DS2/REN/UPS = Assets/MiniEngineAO/Shaders/{Downsample1,Downsample2,Render,Upsample}.compute)
 //
 // Numerics contract: binary32, RNE, correctly rounded '/' (exact v_rcp_f32-based
@@ -22,9 +25,10 @@
 //  * Each lane renders horizontally adjacent texel pairs so every LDS sample is one
 //    conflict-free ds_read_b64; saturate() folds into the clamp modifier of v_mul/v_fma and
 //    clamp(d, p, 1) is one v_med3_f32, so a sample pair costs exactly 8 VALU ops per texel.
-//  * Upsample uses 64x32 hi-res tiles (32x16 low-res + aprons): 1.5x apron amplification
-//    instead of the reference's 2.6x, all 256 lanes busy in both blur phases, 16-byte loads
-//    of the hi-res depth and 4-byte stores of four AO texels.
+//  * Upsample uses 64x64 hi-res tiles in the full-resolution pass (64x32 in the blend passes):
+//    1.4x apron amplification instead of the reference's 2.6x, >= 89 % of the lanes busy in both
+//    blur phases, 16-byte loads of the hi-res depth and 4-byte stores of four AO texels, LDS
+//    carved so that seven workgroups share a CU.
 #include "meao_kernels.hpp"
 
 #include <algorithm>
