@@ -427,6 +427,15 @@ __device__ __forceinline__ float2v accumulate_terms(const RenderLevelArgs &L, co
     return fma2(splat(L.intensity), ao - splat(1.0f), splat(1.0f));   // lerp(1, ao, gIntensity) REN:176
 }
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (id mod 8), each with its own L2.  This maps the
+// ids one XCD receives to a contiguous range of tiles, so that neighbouring tiles -- which share their
+// aprons -- share an L2.  Bijection of [0, n).
+__device__ __forceinline__ int xcd_contiguous(int id, int n)
+{
+    const int q = n >> 3, r = n & 7, xcd = id & 7;
+    return xcd * q + min(xcd, r) + (id >> 3);
+}
+
 template <int AOFMT, bool RTNE, int DIV, bool EXH>
 __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
 {
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
     typedef AoTexel<AOFMT> AO;
 
     const int frame = blockIdx.y;
-    int b = blockIdx.x, lv = 0;
+    int b = xcd_contiguous(blockIdx.x, gridDim.x), lv = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k)
         if (k < a.num_levels && b >= a.level[k].block_begin) lv = k;
@@ -855,7 +864,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
 template <int AOFMT, bool RTNE, bool FINAL, int DIV>
 __global__ __launch_bounds__(kThreads, FINAL ? 7 : 1) void upsample_kernel(const UpsampleArgs a)
 {
-    upsample_tile<AOFMT, RTNE, FINAL, DIV>(a, blockIdx.x, blockIdx.z);
+        upsample_tile<AOFMT, RTNE, FINAL, DIV>(a, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
 
 // Upsample.main of this batch carrying the downsample pass of the NEXT batch (meao_prefetch_batch):
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsamp
             if (vec) downsample_tile<RTNE, true, DIV>(d, t, f);
             else downsample_tile<RTNE, false, DIV>(d, t, f);
         }
-    upsample_tile<AOFMT, RTNE, true, DIV>(a, blockIdx.x, blockIdx.z);
+        upsample_tile<AOFMT, RTNE, true, DIV>(a, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------
