@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kThreads) void render_wide_kernel(const RenderArgs 
     typedef AoTexel<AOFMT> AO;
 
     const int frame = blockIdx.y;
-    int b = blockIdx.x, lv = 0;
+    int b = xcd_contiguous(blockIdx.x, gridDim.x), lv = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k)
         if (k < a.num_levels && b >= a.level[k].block_begin) lv = k;
