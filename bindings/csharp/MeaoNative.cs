@@ -44,6 +44,7 @@ namespace MiniEngineAO.Native
         public int hq_levels;
         public int sample_set;
         public int launch_mode;
+        public int pipelined;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -97,7 +98,7 @@ namespace MiniEngineAO.Native
     public static class Meao
     {
         const string Lib = "meao_hip";   // libmeao_hip.so
-        public const int AbiVersion = 3;
+        public const int AbiVersion = 4;
         public const int MaxBatch = 64;
         public const int NumPasses = 7;
         public const int DebugOcclusionHq1 = 18;
@@ -133,6 +134,7 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_set_profiling(IntPtr ctx, int enable);
         [DllImport(Lib)] public static extern int meao_get_pass_times(IntPtr ctx, [Out] float[] ms7, out int samples);
         [DllImport(Lib)] public static extern int meao_selftest(IntPtr ctx, int which, out ulong mismatches);
+        [DllImport(Lib)] public static extern int meao_set_tracing(IntPtr ctx, int enable);
         [DllImport(Lib)] public static extern int meao_debug_view(IntPtr ctx, int frame, int debug_id, IntPtr dst, int out_loc, IntPtr stream);
         [DllImport(Lib)] public static extern int meao_composite(IntPtr ctx, int mode, IntPtr ao, IntPtr color_rgba16f, IntPtr gbuffer0_rgba8, int loc, IntPtr stream);
     }

@@ -32,7 +32,7 @@ extern "C" {
 #define MEAO_API
 #endif
 
-#define MEAO_ABI_VERSION 3
+#define MEAO_ABI_VERSION 4
 #define MEAO_MAX_BATCH 64      /* frames per batched launch */
 #define MEAO_NUM_PASSES 7      /* downsample, render, upsample x4, render_hq (see meao_pass) */
 
@@ -134,6 +134,9 @@ typedef struct meao_config {
                              * MiniEngine original (its quality levels = hq_levels 0..4). */
     int32_t sample_set;     /* meao_sample_set */
     int32_t launch_mode;    /* meao_launch_mode */
+    int32_t pipelined;      /* 1: allocate the second set of downsample buffers at meao_create, so that
+                             * meao_prefetch_batch never allocates or synchronises (streams of frames);
+                             * 0 (default): the first meao_prefetch_batch call does it, once */
 } meao_config;
 
 /* The component's serialized properties (AO.cs:20-68; defaults there) and the camera terms
@@ -227,6 +230,14 @@ MEAO_API const char *meao_last_error(const meao_ctx *ctx);
  *        tightly packed
  *        (_CameraDepthTexture / ResolvedDepth, AO.cs:608-641).
  * ao_out: width*height AO texels in cfg.ao_format (the "AmbientOcclusion" RT, AO.cs:475).
+ * Alignment of DEVICE pointers: none required.  When width % 4 == 0 and every depth pointer is
+ *        aligned to 4 texels (16 bytes for F32 / UNORM24, 8 for the 16-bit formats) the downsample
+ *        pass uses 4-texel vector loads, and when every ao_out pointer is aligned to 4 texels (4 bytes
+ *        R8, 8 bytes F16) the last pass uses 4-texel stores; otherwise the scalar variants run
+ *        (same results, slower).  hipMalloc / torch allocations are always aligned.
+ * Any depth value is accepted: NaN, +-inf, negative, > 1 or denormal raw depths are processed with
+ *        IEEE division exactly like the reference's Linearize (Downsample1.compute:37-48) -- a frame
+ *        containing such texels takes slower kernel bodies, results stay bit-exact vs the oracle.
  * *_loc: meao_mem; HOST pointers are staged through context-owned device buffers.
  * Asynchronous on `stream` for DEVICE/DEVICE; returns after completion if either is HOST. */
 MEAO_API int32_t meao_execute(meao_ctx *ctx, const void *depth, int32_t depth_loc,
@@ -240,10 +251,13 @@ MEAO_API int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const 
  * kernel, where the pass's HBM traffic hides under arithmetic instead of costing ~20 % of a frame;
  * the meao_execute* after that, if given exactly these n pointers, skips its own downsample pass.
  * Results are identical.  Rules: the announced buffers must hold their final contents before the
- * carrying execute is submitted and stay unchanged until the consuming one has run; consecutive
- * pipelined executes go to the same stream; meao_set_params / meao_resize drop a pending
- * announcement and any prefetched downsample (the next execute then runs the pass itself).  The
- * first call re-allocates the context's intermediates with a second set of downsample buffers. */
+ * carrying execute is submitted and stay unchanged until the consuming one has run.  Enforced, not
+ * only documented: the prefetched downsample is used only by an execute on the SAME stream as the
+ * one that carried it (stream order is what orders the two) and given exactly the announced
+ * pointers; any other execute, meao_set_params and meao_resize simply run / re-run the pass.
+ * With cfg.pipelined = 1 this call never allocates or synchronises; otherwise the first call
+ * re-allocates the context's intermediates with a second set of downsample buffers (one device
+ * synchronisation; on allocation failure the context is left unchanged and usable). */
 MEAO_API int32_t meao_prefetch_batch(meao_ctx *ctx, int32_t n, const void *const *depth);
 MEAO_API int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream);
 
@@ -283,10 +297,16 @@ MEAO_API int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, voi
                                 void *gbuffer0_rgba8, int32_t loc, meao_stream stream);
 
 /* Per-pass device timing: when enabled, meao_execute* brackets every pass with HIP events on
- * the launch stream; meao_get_pass_times averages them over the executes since the last reset
- * (synchronises the stream).  ms[MEAO_NUM_PASSES]; passes not run report 0. */
+ * the launch stream; meao_get_pass_times averages each pass over the executes that ran it since
+ * the last reset (synchronises the stream); *out_samples = executes measured.
+ * ms[MEAO_NUM_PASSES]; passes not run report 0. */
 MEAO_API int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable);
 MEAO_API int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *out_samples);
+
+/* roctx ranges ("meao:downsample", "meao:render", "meao:upsample_L1_to_L0", ...) around the launches
+ * of every pass, so that rocprofv3 --marker-trace output is self-describing even where passes are
+ * fused.  Off by default; libroctx64.so is loaded on first use (MEAO_ERR_UNSUPPORTED if absent). */
+MEAO_API int32_t meao_set_tracing(meao_ctx *ctx, int32_t enable);
 
 /* Exhaustive device self-tests of what bit-exactness rests on; *out_mismatches = number of
  * inputs whose hardware result differs from the IEEE / bit-level model.

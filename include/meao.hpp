@@ -108,6 +108,7 @@ public:
     // carries their downsample pass inside its last kernel (meao_prefetch_batch).
     void PrefetchBatch(const std::vector<const void *> &nextDeviceDepth)
     {
+        sync();   // pending property changes first: meao_set_params would drop the announcement
         check(meao_prefetch_batch(ctx_, static_cast<int32_t>(nextDeviceDepth.size()), nextDeviceDepth.data()));
     }
 

@@ -21,7 +21,7 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmeao_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_BATCH = 64
 NUM_PASSES = 7
 PASS_NAMES = ("downsample", "render", "upsample_L4_to_L3", "upsample_L3_to_L2",
@@ -49,7 +49,7 @@ class Config(C.Structure):
                 ("height", C.c_int32), ("num_levels", C.c_int32), ("ao_format", C.c_int32),
                 ("f16_rounding", C.c_int32), ("numerics", C.c_int32), ("max_batch", C.c_int32),
                 ("depth_format", C.c_int32), ("hq_levels", C.c_int32), ("sample_set", C.c_int32),
-                ("launch_mode", C.c_int32)]
+                ("launch_mode", C.c_int32), ("pipelined", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -108,6 +108,7 @@ SIGNATURES = {
     "meao_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
     "meao_get_pass_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float * NUM_PASSES), C.POINTER(C.c_int32)]),
     "meao_selftest": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+    "meao_set_tracing": (C.c_int32, [C.c_void_p, C.c_int32]),
     "meao_debug_view": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "meao_composite": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }

@@ -38,7 +38,7 @@ class AmbientOcclusion:
                  near_clip: float = 0.3, far_clip: float = 1000.0,
                  projection00: Optional[float] = None, reversed_z: bool = True,
                  hq_levels: int = 0, sample_set: int = L.SAMPLES_CHECKER, single_pass_stereo: bool = False,
-                 launch_mode: int = L.LAUNCH_DIRECT):
+                 launch_mode: int = L.LAUNCH_DIRECT, pipelined: bool = False):
         """hq_levels / sample_set / single_pass_stereo: variants the reference's shaders and host carry
         but its command buffer never (or only in VR) uses; see include/meao.h.  ``width`` is the
         double-wide eye pair when single_pass_stereo is set (AO.cs:339)."""
@@ -52,6 +52,7 @@ class AmbientOcclusion:
         cfg.numerics = numerics
         cfg.hq_levels, cfg.sample_set = hq_levels, sample_set
         cfg.launch_mode = launch_mode      # LAUNCH_GRAPH: one hipGraphLaunch per call (real-time single frames)
+        cfg.pipelined = 1 if pipelined else 0   # second downsample set from the start (prefetch_device never allocates)
         self._cfg = cfg
         prm = L.Params()
         self._lib.meao_default_params(C.byref(prm))
@@ -154,6 +155,7 @@ class AmbientOcclusion:
         """Announce the device depth frames of the call after next (meao_prefetch_batch): the next
         execute_device() carries their downsample pass inside its last upsample kernel."""
         n = len(depth_ptrs)
+        self._sync_params()     # pending property changes first: meao_set_params would drop the announcement
         pin = (C.c_void_p * n)(*depth_ptrs)
         L.check(self._lib.meao_prefetch_batch(self._ctx, n, pin), self._ctx)
 
@@ -200,6 +202,10 @@ class AmbientOcclusion:
 
     def set_profiling(self, enable: bool) -> None:
         L.check(self._lib.meao_set_profiling(self._ctx, 1 if enable else 0), self._ctx)
+
+    def set_tracing(self, enable: bool) -> None:
+        """roctx ranges around every pass (rocprofv3 --marker-trace)."""
+        L.check(self._lib.meao_set_tracing(self._ctx, 1 if enable else 0), self._ctx)
 
     def pass_times_ms(self):
         ms = (C.c_float * L.NUM_PASSES)()

@@ -2,6 +2,7 @@
 // per-frame launch sequence, intermediates, profiling.  No CPU fallback exists anywhere in
 // this library: without a gfx950 device meao_create fails with MEAO_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstring>
@@ -19,7 +20,7 @@ namespace {
 thread_local std::string g_last_error;   // for failures that have no context (meao_create)
 
 constexpr uint64_t kAlign = 256;
-constexpr int kProfileRing = 64;          // executes buffered before timings are folded
+constexpr int kProfileRing = 256;         // executes buffered before timings are folded
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 }  // namespace
@@ -47,6 +48,12 @@ struct meao_ctx {
     const void *next_depth[MEAO_MAX_BATCH] = {};
     int ready_n = 0, ready_set = 0;               // a set already downsampled from exactly these frames
     const void *ready_depth[MEAO_MAX_BATCH] = {};
+    hipStream_t ready_stream = nullptr;           // the stream the carrying execute ran on
+    // Hostile-depth flags (meao_kernels.hip nice_denominator): [set][frame] words the downsample pass
+    // stamps with its generation when a frame holds texels outside the exact-division range.
+    uint32_t *hostile = nullptr;
+    uint32_t gen_counter = 0, set_gen[2] = {0, 0};
+    uint32_t *hostile_of(int set) const { return hostile + set * MEAO_MAX_BATCH; }
     uint64_t off_hq[4] = {};                  // OcclusionHQ<k>: only the levels cfg.hq_levels enables
 
     // lazily allocated: staging for HOST in/out, atlas scratch, selftest counter
@@ -67,16 +74,24 @@ struct meao_ctx {
         const void *depth[MEAO_MAX_BATCH] = {};
         void *out[MEAO_MAX_BATCH] = {};
         hipGraphExec_t exec = nullptr;
+        uint32_t generation = 0;
     };
     std::vector<CapturedBatch> graphs;
 
-    // profiling
+    // profiling: a ring of per-execute event sets; each entry remembers which passes it ran
     bool profiling = false;
     std::vector<hipEvent_t> events;              // kProfileRing * (MEAO_NUM_PASSES + 1)
     int ring_fill = 0;
-    bool ran[MEAO_NUM_PASSES] = {};
+    uint32_t ran_mask[kProfileRing] = {};        // bit k: pass k ran in that execute
     double pass_ms_sum[MEAO_NUM_PASSES] = {};
-    int pass_samples = 0;
+    int pass_samples[MEAO_NUM_PASSES] = {};      // executes that ran pass k
+    int executes_profiled = 0;
+
+    // roctx ranges around every pass (meao_set_tracing); libroctx64.so is loaded on first use
+    bool tracing = false;
+    void *roctx_lib = nullptr;
+    int (*roctx_push)(const char *) = nullptr;
+    int (*roctx_pop)() = nullptr;
 
     std::string err;
 };
@@ -115,6 +130,7 @@ bool config_valid(const meao_config &c, std::string *why)
     if (c.hq_levels < 0 || c.hq_levels > c.num_levels) { *why = "hq_levels must be 0..num_levels"; return false; }
     if (c.sample_set != MEAO_SAMPLES_CHECKER && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE) { *why = "unknown sample_set"; return false; }
     if (c.launch_mode != MEAO_LAUNCH_DIRECT && c.launch_mode != MEAO_LAUNCH_GRAPH) { *why = "unknown launch_mode"; return false; }
+    if (c.pipelined != 0 && c.pipelined != 1) { *why = "pipelined must be 0 or 1"; return false; }
     return true;
 }
 
@@ -138,13 +154,14 @@ void layout_slot(meao_ctx *ctx)
 }
 
 // Divides on the path: 1/LoResDB, 1/centre depth, {9,3,1,3}/(|dHi-dLo| + tol), (HiAO*sum)/total.
-// Depths are Linear01 in [near/far, 1] or the sky value (1e5 in f32; 65504 after an RTZ f16
-// store, +inf after an RTNE one); weights are <= 9/tol; total and sum are >= noise strength.
+// The exact v_rcp_f32 sequences need their operands inside verified ranges.  The DATA side of that
+// (every linear depth in [2^-24, 2^20] or the sky value, finite, not NaN) is checked per frame on the
+// device by the downsample pass (nice_denominator; hostile frames take the IEEE bodies).  The
+// PARAMETER side is checked here: weights are <= 9/tol, total and sum are >= noise strength.
 bool exact_rcp_div_applicable(const meao_config &c, const meao_params &p, const Plan &plan)
 {
     if (c.f16_rounding != MEAO_F16_RTZ_CLAMP) return false;               // RTNE stores inf for sky
-    const float near_over_far = p.near_clip / p.far_clip;
-    if (!(near_over_far >= 0x1p-40f)) return false;                       // smallest Linear01 depth
+    (void)p;
     for (int k = 0; k < 4; ++k) {
         const meao_upsample_constants &u = plan.upsample[k];
         if (!(u.upsample_tolerance >= 0x1p-44f && u.upsample_tolerance <= 0x1p20f)) return false;  // weights <= 9 * 2^44
@@ -155,7 +172,7 @@ bool exact_rcp_div_applicable(const meao_config &c, const meao_params &p, const 
 
 constexpr size_t kMaxCapturedBatches = 8;
 
-void drop_prefetch(meao_ctx *ctx) { ctx->next_n = 0; ctx->ready_n = 0; }
+void drop_prefetch(meao_ctx *ctx) { ctx->next_n = 0; ctx->ready_n = 0; ctx->ready_stream = nullptr; }
 
 void drop_graphs(meao_ctx *ctx)
 {
@@ -175,23 +192,45 @@ void update_plan(meao_ctx *ctx)
     if (ctx->cfg.numerics == MEAO_NUMERICS_FAST && ctx->cfg.f16_rounding == MEAO_F16_RTZ_CLAMP) ctx->exact_rcp_div = 2;
 }
 
-void release_buffers(meao_ctx *ctx)
+void release_staging(meao_ctx *ctx)
 {
-    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->stage_depth) (void)hipFree(ctx->stage_depth);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->stage_view) (void)hipFree(ctx->stage_view);
     if (ctx->atlas_scratch) (void)hipFree(ctx->atlas_scratch);
-    ctx->arena = ctx->stage_depth = ctx->stage_out = ctx->stage_view = ctx->atlas_scratch = nullptr;
+    ctx->stage_depth = ctx->stage_out = ctx->stage_view = ctx->atlas_scratch = nullptr;
     ctx->atlas_scratch_bytes = 0;
+}
+
+void release_buffers(meao_ctx *ctx)
+{
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    ctx->arena = nullptr;
+    release_staging(ctx);
     ctx->last_frames = 0;
 }
 
-int allocate_buffers(meao_ctx *ctx)
+// (Re)plans for cfg/two_ds_sets and replaces the arena.  The new arena is allocated BEFORE the old one
+// is released: on failure the context keeps its previous geometry and buffers and stays usable.
+int reallocate(meao_ctx *ctx, const meao_config &cfg, bool two_ds_sets)
 {
+    const meao_config old_cfg = ctx->cfg;
+    const bool old_two = ctx->two_ds_sets;
+    ctx->cfg = cfg;
+    ctx->two_ds_sets = two_ds_sets;
     update_plan(ctx);
     layout_slot(ctx);
-    MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->arena), ctx->slot_bytes * ctx->cfg.max_batch));
+    char *fresh = nullptr;
+    const hipError_t e = hipMalloc(reinterpret_cast<void **>(&fresh), ctx->slot_bytes * ctx->cfg.max_batch);
+    if (e != hipSuccess) {
+        ctx->cfg = old_cfg;
+        ctx->two_ds_sets = old_two;
+        update_plan(ctx);
+        layout_slot(ctx);
+        return fail_hip(ctx, e, "hipMalloc (intermediates)");
+    }
+    release_buffers(ctx);
+    ctx->arena = fresh;
     return MEAO_OK;
 }
 
@@ -218,15 +257,25 @@ void fold_profile(meao_ctx *ctx)
     for (int r = 0; r < ctx->ring_fill; ++r) {
         for (int i = 0; i < MEAO_NUM_PASSES; ++i) {
             const int k = kStreamOrder[i];
-            if (!ctx->ran[k]) continue;
+            if (!(ctx->ran_mask[r] >> k & 1u)) continue;
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ctx->events[r * per + i], ctx->events[r * per + i + 1]) == hipSuccess)
+            if (hipEventElapsedTime(&ms, ctx->events[r * per + i], ctx->events[r * per + i + 1]) == hipSuccess) {
                 ctx->pass_ms_sum[k] += ms;
+                ++ctx->pass_samples[k];
+            }
         }
-        ++ctx->pass_samples;
+        ++ctx->executes_profiled;
     }
     ctx->ring_fill = 0;
 }
+
+struct TraceRange {   // roctx range around one pass (no-op unless meao_set_tracing enabled it)
+    meao_ctx *ctx;
+    TraceRange(meao_ctx *c, const char *name) : ctx(c) { if (ctx->tracing && ctx->roctx_push) ctx->roctx_push(name); }
+    ~TraceRange() { if (ctx->tracing && ctx->roctx_pop) ctx->roctx_pop(); }
+};
+
+bool aligned_to(const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // The launch sequence of one batch: what RebuildCommandBuffers records (AO.cs:511-531).
 int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream)
@@ -236,18 +285,28 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     const int rtne = c.f16_rounding == MEAO_F16_RTNE;
     const int per = MEAO_NUM_PASSES + 1;
     hipEvent_t *ev = nullptr;
+    uint32_t ran = 0;
     if (ctx->profiling) {
         if (ctx->ring_fill == kProfileRing) fold_profile(ctx);
         ev = &ctx->events[ctx->ring_fill * per];
-        std::memset(ctx->ran, 0, sizeof ctx->ran);
     }
     int slot_index = 0;   // position in kStreamOrder
     auto mark = [&]() -> hipError_t { return ev ? hipEventRecord(ev[slot_index++], stream) : hipSuccess; };
 
+    // 4-texel vector loads / stores need 16-byte (f32, UNORM24), 8-byte (16-bit) aligned depth rows and
+    // 4- (R8) / 8-byte (F16) aligned AO rows: width % 4 == 0 and aligned base pointers (include/meao.h);
+    // anything else takes the scalar variants.
+    const uintptr_t depth_align = 4 * depth_elem(c.depth_format), out_align = 4 * ao_elem(c);
+
     // ---- PushDownsampleCommands (AO.cs:604-658)
-    auto downsample_args = [&](int frames, const void *const *depth, int set) {
+    auto downsample_args = [&](int frames, const void *const *depth, int set, uint32_t generation) {
         DownsampleArgs ds{};
-        for (int f = 0; f < frames; ++f) ds.depth[f] = depth[f];
+        bool aligned = (p.mip[0].w & 3) == 0;
+        for (int f = 0; f < frames; ++f) {
+            ds.depth[f] = depth[f];
+            aligned = aligned && aligned_to(depth[f], depth_align);
+        }
+        ds.vec_ok = aligned;
         ds.frames = frames;
         ds.depth_format = c.depth_format;
         ds.linear = slot_ptr<uint16_t>(ctx, ctx->off_linear_of(set));
@@ -261,18 +320,29 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         ds.exact_rcp_div = ctx->exact_rcp_div;
         ds.tiles_x = (p.mip[0].w + 127) / 128;
         ds.tiles_y = (p.mip[0].h + 31) / 32;
+        ds.hostile = ctx->hostile_of(set);
+        ds.generation = generation;
         return ds;
     };
-    // A previous call may already have downsampled exactly these frames (meao_prefetch_batch).
-    const bool prefetched = ctx->ready_n == n && std::memcmp(ctx->ready_depth, depth_dev, sizeof(void *) * n) == 0;
+    auto next_generation = [&]() { if (++ctx->gen_counter == 0) ++ctx->gen_counter; return ctx->gen_counter; };   // never 0
+
+    // A previous call may already have downsampled exactly these frames (meao_prefetch_batch).  The
+    // prefetched set is only valid on the stream of the execute that carried it: stream order is what
+    // orders that kernel before this call's readers.
+    const bool prefetched = ctx->ready_n == n && ctx->ready_stream == stream &&
+                            std::memcmp(ctx->ready_depth, depth_dev, sizeof(void *) * n) == 0;
     ctx->ds_cur = prefetched ? ctx->ready_set : 0;
     ctx->ready_n = 0;
     MEAO_HIP(ctx, mark());
     if (!prefetched) {
-        MEAO_HIP(ctx, launch_downsample(downsample_args(n, depth_dev, ctx->ds_cur), n, stream));
-        if (ev) ctx->ran[MEAO_PASS_DOWNSAMPLE] = true;
+        TraceRange tr(ctx, "meao:downsample");
+        ctx->set_gen[ctx->ds_cur] = next_generation();
+        MEAO_HIP(ctx, launch_downsample(downsample_args(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur]), n, stream));
+        ran |= 1u << MEAO_PASS_DOWNSAMPLE;
     }
     MEAO_HIP(ctx, mark());
+    const uint32_t *hostile = ctx->hostile_of(ctx->ds_cur);
+    const uint32_t generation = ctx->set_gen[ctx->ds_cur];
 
     // ---- PushRenderCommands x num_levels (AO.cs:519-522) as one grid; then Render.main (wide)
     // on LowDepth<k> for the levels cfg.hq_levels enables, also one grid
@@ -306,14 +376,19 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         rn.f16_rtne = rtne;
         rn.exact_rcp_div = ctx->exact_rcp_div;
         rn.exhaustive = c.sample_set == MEAO_SAMPLES_EXHAUSTIVE;
+        rn.hostile = hostile;
+        rn.generation = generation;
         if (count > 0) {
+            TraceRange tr(ctx, wide ? "meao:render_hq" : "meao:render");
             MEAO_HIP(ctx, wide ? launch_render_wide(rn, c.ao_format, n, stream) : launch_render(rn, c.ao_format, n, stream));
-            if (ev) ctx->ran[wide ? MEAO_PASS_RENDER_HQ : MEAO_PASS_RENDER] = true;
+            ran |= 1u << (wide ? MEAO_PASS_RENDER_HQ : MEAO_PASS_RENDER);
         }
         MEAO_HIP(ctx, mark());
     }
 
     // ---- PushUpsampleCommands chain (AO.cs:528-531), generalised to num_levels
+    static const char *const kUpsRange[4] = {"meao:upsample_L1_to_L0", "meao:upsample_L2_to_L1", "meao:upsample_L3_to_L2",
+                                             "meao:upsample_L4_to_L3"};
     const void *lo_ao = slot_ptr<void>(ctx, ctx->off_occ[c.num_levels - 1]);
     for (int hi = 3; hi >= 0; --hi) {
         const int pass = MEAO_PASS_UPSAMPLE_0 - hi;
@@ -335,6 +410,9 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             up.upsample_tolerance = k.upsample_tolerance;
             up.f16_rtne = rtne;
             up.exact_rcp_div = ctx->exact_rcp_div;
+            up.hostile = hostile;
+            up.generation = generation;
+            bool vec_ok = (up.hw & 3) == 0;
             if (hi > 0) {   // main_blendout: blend with Occlusion<hi>, write Combined<hi>
                 up.hi_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi - 1));
                 up.hi_ao = slot_ptr<void>(ctx, ctx->off_occ[hi - 1]);
@@ -343,25 +421,32 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             } else {        // main: LinearDepth f16 as HiResDB, no HiResAO, write the result
                 up.hi_depth = slot_ptr<uint16_t>(ctx, ctx->off_linear_of(ctx->ds_cur));
                 up.hi_ao = nullptr;
-                for (int f = 0; f < n; ++f) up.dst[f] = out_dev[f];
+                for (int f = 0; f < n; ++f) {
+                    up.dst[f] = out_dev[f];
+                    vec_ok = vec_ok && aligned_to(out_dev[f], out_align);
+                }
             }
+            up.vec_ok = vec_ok;
+            TraceRange tr(ctx, kUpsRange[hi]);
             if (hi == 0 && ctx->next_n > 0) {
                 // carry the downsample of the announced next batch in this (VALU-bound) kernel
                 const int other = 1 - ctx->ds_cur;
+                ctx->set_gen[other] = next_generation();
                 MEAO_HIP(ctx, launch_upsample_final_with_downsample(
-                                  up, downsample_args(ctx->next_n, ctx->next_depth, other), c.ao_format, n, stream));
+                                  up, downsample_args(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other]), c.ao_format, n, stream));
                 ctx->ready_n = ctx->next_n;
                 ctx->ready_set = other;
+                ctx->ready_stream = stream;
                 std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
                 ctx->next_n = 0;
             } else {
                 MEAO_HIP(ctx, launch_upsample(up, c.ao_format, hi == 0, n, stream));
             }
-            if (ev) ctx->ran[pass] = true;
+            ran |= 1u << pass;
         }
         MEAO_HIP(ctx, mark());
     }
-    if (ev) ++ctx->ring_fill;
+    if (ev) ctx->ran_mask[ctx->ring_fill++] = ran;
     for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
     ctx->last_frames = n;
     ctx->last_stream = stream;
@@ -388,6 +473,8 @@ int submit_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const
         ctx->graphs.erase(ctx->graphs.begin() + static_cast<long>(i));
         ctx->graphs.push_back(hit);
         MEAO_HIP(ctx, hipGraphLaunch(hit.exec, stream));
+        ctx->ds_cur = 0;                       // captured sequences always write and read downsample set 0
+        ctx->set_gen[0] = hit.generation;      // ... with the hostile-flag generation baked into their arguments
         for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
         ctx->last_frames = n;
         ctx->last_stream = stream;
@@ -403,6 +490,7 @@ int submit_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const
     }
     meao_ctx::CapturedBatch g;
     g.n = n;
+    g.generation = ctx->set_gen[0];
     for (int f = 0; f < n; ++f) { g.depth[f] = depth_dev[f]; g.out[f] = out_dev[f]; }
     const hipError_t inst = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -451,6 +539,7 @@ void meao_default_config(meao_config *cfg)
     cfg->numerics = MEAO_NUMERICS_STRICT;
     cfg->max_batch = 1;
     cfg->depth_format = MEAO_DEPTH_F32;
+    cfg->pipelined = 0;
 }
 
 void meao_default_params(meao_params *p)
@@ -564,7 +653,15 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
         e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
         if (e != hipSuccess) rc = fail_hip(ctx, e, "hipStreamCreateWithFlags");
     }
-    if (rc == MEAO_OK) rc = allocate_buffers(ctx);
+    if (rc == MEAO_OK) {
+        // hostile-depth flags: 2 downsample sets x MEAO_MAX_BATCH frames, zero = never hostile (generations start at 1)
+        const size_t bytes = 2 * MEAO_MAX_BATCH * sizeof(uint32_t);
+        e = hipMalloc(reinterpret_cast<void **>(&ctx->hostile), bytes);
+        if (e == hipSuccess) e = hipMemset(ctx->hostile, 0, bytes);
+        if (e != hipSuccess) rc = fail_hip(ctx, e, "hipMalloc (hostile flags)");
+    }
+    // cfg.pipelined: the second downsample set exists from the start, so meao_prefetch_batch never re-allocates
+    if (rc == MEAO_OK) rc = reallocate(ctx, *cfg, cfg->pipelined != 0);
     if (rc != MEAO_OK) {
         g_last_error = ctx->err;
         meao_destroy(ctx);
@@ -583,6 +680,8 @@ int32_t meao_destroy(meao_ctx *ctx)
     drop_graphs(ctx);
     release_buffers(ctx);
     if (ctx->counter) (void)hipFree(ctx->counter);
+    if (ctx->hostile) (void)hipFree(ctx->hostile);
+    if (ctx->roctx_lib) (void)dlclose(ctx->roctx_lib);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -600,9 +699,8 @@ int32_t meao_resize(meao_ctx *ctx, int32_t width, int32_t height)
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     MEAO_HIP(ctx, hipDeviceSynchronize());
-    release_buffers(ctx);
-    ctx->cfg = c;
-    return allocate_buffers(ctx);
+    // on failure (e.g. out of memory) the context keeps its previous size and buffers
+    return reallocate(ctx, c, ctx->two_ds_sets);
 }
 
 int32_t meao_set_params(meao_ctx *ctx, const meao_params *p)
@@ -640,6 +738,7 @@ int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth, i
         return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_execute_batch: bad memory location");
     for (int f = 0; f < n; ++f)
         if (!depth[f] || !ao_out[f]) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_execute_batch: null frame pointer");
+    if (!ctx->arena) return fail(ctx, MEAO_ERR_OUT_OF_MEMORY, "meao_execute_batch: the context has no intermediates");
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->own_stream;
@@ -689,11 +788,11 @@ int32_t meao_prefetch_batch(meao_ctx *ctx, int32_t n, const void *const *depth)
         if (!depth[f]) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_prefetch_batch: null frame pointer");
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
-    if (!ctx->two_ds_sets) {   // first use: re-lay the slots out with a second downsample set
+    if (!ctx->two_ds_sets) {
+        // Created without cfg.pipelined: the first announcement re-lays the slots out with a second
+        // downsample set (device-wide synchronisation + allocation, once).  On failure the context is unchanged.
         MEAO_HIP(ctx, hipDeviceSynchronize());
-        release_buffers(ctx);
-        ctx->two_ds_sets = true;
-        rc = allocate_buffers(ctx);
+        rc = reallocate(ctx, ctx->cfg, true);
         if (rc != MEAO_OK) return rc;
     }
     ctx->next_n = n;
@@ -772,6 +871,7 @@ int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id, vo
         return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: debug_id must be 1..21");
     if (out_desc) *out_desc = d;
     if (!dst) return MEAO_OK;
+    if (!ctx->arena) return fail(ctx, MEAO_ERR_OUT_OF_MEMORY, "meao_get_intermediate: the context has no intermediates");
     if (frame < 0 || frame >= ctx->last_frames)
         return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_get_intermediate: frame not produced by the last execute");
     if (dst_capacity < d.bytes) return fail(ctx, MEAO_ERR_BUFFER_TOO_SMALL, "meao_get_intermediate: dst_capacity < desc.bytes");
@@ -794,6 +894,7 @@ int32_t meao_debug_view(meao_ctx *ctx, int32_t frame, int32_t debug_id, void *ou
     meao_desc d{};
     if (!describe_buffer(ctx->cfg.width, ctx->cfg.height, ctx->cfg.ao_format, debug_id, &d))
         return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_view: debug_id must be 1..21");
+    if (!ctx->arena) return fail(ctx, MEAO_ERR_OUT_OF_MEMORY, "meao_debug_view: the context has no intermediates");
     if (frame < 0 || frame >= ctx->last_frames)
         return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_view: frame not produced by the last execute");
     if (out_loc != MEAO_MEM_HOST && out_loc != MEAO_MEM_DEVICE) return MEAO_ERR_INVALID_ARGUMENT;
@@ -839,7 +940,8 @@ int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable)
     if (enable) {   // (re)start a measurement window
         if (ctx->ring_fill) fold_profile(ctx);
         std::memset(ctx->pass_ms_sum, 0, sizeof ctx->pass_ms_sum);
-        ctx->pass_samples = 0;
+        std::memset(ctx->pass_samples, 0, sizeof ctx->pass_samples);
+        ctx->executes_profiled = 0;
     }
     ctx->profiling = enable != 0;
     return MEAO_OK;
@@ -851,9 +953,30 @@ int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *o
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     fold_profile(ctx);
+    // mean over the executes that actually ran the pass (a prefetched downsample does not dilute it)
     for (int k = 0; k < MEAO_NUM_PASSES; ++k)
-        ms[k] = ctx->pass_samples ? static_cast<float>(ctx->pass_ms_sum[k] / ctx->pass_samples) : 0.0f;
-    if (out_samples) *out_samples = ctx->pass_samples;
+        ms[k] = ctx->pass_samples[k] ? static_cast<float>(ctx->pass_ms_sum[k] / ctx->pass_samples[k]) : 0.0f;
+    if (out_samples) *out_samples = ctx->executes_profiled;
+    return MEAO_OK;
+}
+
+int32_t meao_set_tracing(meao_ctx *ctx, int32_t enable)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    if (enable && !ctx->roctx_lib) {
+        void *lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return fail(ctx, MEAO_ERR_UNSUPPORTED, "meao_set_tracing: libroctx64.so not found");
+        ctx->roctx_push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+        ctx->roctx_pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!ctx->roctx_push || !ctx->roctx_pop) {
+            (void)dlclose(lib);
+            ctx->roctx_push = nullptr; ctx->roctx_pop = nullptr;
+            return fail(ctx, MEAO_ERR_UNSUPPORTED, "meao_set_tracing: roctxRangePushA / roctxRangePop missing");
+        }
+        ctx->roctx_lib = lib;
+    }
+    ctx->tracing = enable != 0;
     return MEAO_OK;
 }
 

@@ -242,6 +242,18 @@ __device__ __forceinline__ float linearize(float depth, float zp0, float zp1, fl
     return depth == sky_depth ? 1e5f : dist;
 }
 
+// "Nice" depth: the denominator of Linearize lies in [2^-20, 2^24], i.e. the linear depth is a
+// normal number in [2^-24, 2^20] (non-zero after the f16 store, finite, not NaN).  Every exact
+// v_rcp_f32 sequence downstream (centre depth, 1 / LoResDB, the bilateral weights, the final
+// quotient) has its operands inside its verified range when all texels of a frame are nice.  A frame
+// with any other texel -- NaN, +-inf, negative, > 1 with a conventional Z buffer, depths below
+// 2^-24 -- is marked hostile by the downsample pass and takes the IEEE-division bodies of the later
+// kernels (the reference divides with IEEE '/', Downsample1.compute:37-48; inputs are never sanitised).
+__device__ __forceinline__ bool nice_denominator(float den)
+{
+    return __builtin_amdgcn_fmed3f(den, 0x1p-20f, 0x1p24f) == den;   // false for NaN
+}
+
 template <bool RTNE, bool VEC, int DIV>
 __device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int tile, int frame)
 {
@@ -313,8 +325,24 @@ __device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int til
         const int y = yb + k * kDsRowsPerPass;
         if (y >= H) continue;
         float lin[4];
+        if constexpr (DIV == DIV_EXACT_RCP) {
+            // the exact reciprocal sequence is only valid for a "nice" denominator; anything else
+            // (hostile input) is divided with IEEE '/' and marks the frame for the later kernels
+            bool nice = true;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], a.zp0, a.zp1, sky_depth);
+            for (int e = 0; e < 4; ++e) {
+                nice = nice && nice_denominator(mad(a.zp0, v[k][e], a.zp1));
+                lin[e] = linearize<DIV_EXACT_RCP>(v[k][e], a.zp0, a.zp1, sky_depth);
+            }
+            if (__builtin_expect(!nice, 0)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[k][e], a.zp0, a.zp1, sky_depth);
+                a.hostile[frame] = a.generation;     // racing stores of the same value
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], a.zp0, a.zp1, sky_depth);
+        }
 
         uint16_t *lrow = linear + static_cast<size_t>(y) * W + x0;    // LinearZ[st] = dist (DS1:46)
         if constexpr (VEC) {
@@ -436,14 +464,19 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n)
     return xcd * q + min(xcd, r) + (id >> 3);
 }
 
-template <int AOFMT, bool RTNE, int DIV, bool EXH>
-__global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
+// True when the downsample pass that produced this frame's depth mips saw a texel outside the
+// verified operand range of the exact v_rcp_f32 sequences (see nice_denominator).
+__device__ __forceinline__ bool frame_is_hostile(const uint32_t *hostile, uint32_t generation, int frame)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * kRenLdsW];
+    return __builtin_nontemporal_load(hostile + frame) == generation;
+}
+
+template <int AOFMT, bool RTNE, int DIV, bool EXH>
+__device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, int frame, int block)
+{
     typedef AoTexel<AOFMT> AO;
 
-    const int frame = blockIdx.y;
-    int b = xcd_contiguous(blockIdx.x, gridDim.x), lv = 0;
+    int b = block, lv = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k)
         if (k < a.num_levels && b >= a.level[k].block_begin) lv = k;
@@ -513,6 +546,20 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
     }
 }
 
+template <int AOFMT, bool RTNE, int DIV, bool EXH>
+__global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * kRenLdsW];
+    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
+            render_tile<AOFMT, RTNE, DIV_IEEE, EXH>(a, tile, frame, block);
+            return;
+        }
+    }
+    render_tile<AOFMT, RTNE, DIV, EXH>(a, tile, frame, block);
+}
+
 // ------------------------------------------------------------------------------------------
 // Render.main (WIDE_SAMPLING, REN:22,27-29,46-50): the same estimator on the NON-tiled f32
 // LowDepth<level>, sampling every other texel (offsets doubled, REN:79-82) out to 8 texels, one
@@ -521,13 +568,11 @@ __global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
 // Tile 64 x 32 outputs, LDS window (64+16) x (32+16) of raw f32 depth with clamp addressing
 // (REN:116,121 Gather on the 2D texture); no f16 round trip, no padding texels.
 template <int AOFMT, bool RTNE, int DIV, bool EXH>
-__global__ __launch_bounds__(kThreads) void render_wide_kernel(const RenderArgs a)
+__device__ __forceinline__ void render_wide_tile(const RenderArgs &a, float *tile, int frame, int block)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kWideLdsH * kWideLdsW];
     typedef AoTexel<AOFMT> AO;
 
-    const int frame = blockIdx.y;
-    int b = xcd_contiguous(blockIdx.x, gridDim.x), lv = 0;
+    int b = block, lv = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k)
         if (k < a.num_levels && b >= a.level[k].block_begin) lv = k;
@@ -569,6 +614,20 @@ __global__ __launch_bounds__(kThreads) void render_wide_kernel(const RenderArgs 
             if (X + 1 < lw) p[1] = e1;
         }
     }
+}
+
+template <int AOFMT, bool RTNE, int DIV, bool EXH>
+__global__ __launch_bounds__(kThreads) void render_wide_kernel(const RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kWideLdsH * kWideLdsW];
+    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(a.hostile, a.generation, frame)) {
+            render_wide_tile<AOFMT, RTNE, DIV_IEEE, EXH>(a, tile, frame, block);
+            return;
+        }
+    }
+    render_wide_tile<AOFMT, RTNE, DIV, EXH>(a, tile, frame, block);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -651,8 +710,19 @@ __device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao,
 
 // One tile of Upsample.main (FINAL) / main_blendout; every thread of the workgroup must call it
 // (barriers inside; lanes outside the image leave after the last one).
+template <bool FINAL>
+struct UpsLds {
+    typedef UpsTile<ups_tile_h(FINAL)> T;
+    static constexpr int kDep0 = FINAL ? 2 : 0;                                   // first row / column kept
+    static constexpr int kDepH = FINAL ? T::kLowH + 4 : T::kRawH, kDepW = FINAL ? T::kLowW + 4 : T::kRawW;
+    static constexpr int kDepPitch = FINAL ? 36 : T::kRawPitch;
+    static constexpr int kInvN = T::kRawH * T::kRawPitch, kHbN = T::kRawH * T::kBlurPitch, kDepN = kDepH * kDepPitch;
+    static constexpr int kAoN = T::kRawH * T::kRawPitch;
+    static constexpr int kFloats = kInvN + kHbN + kDepN + kAoN;
+};
+
 template <int AOFMT, bool RTNE, bool FINAL, int DIV>
-__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, int frame)
+__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame)
 {
     typedef AoTexel<AOFMT> AO;
     typedef typename AO::type ao_t;
@@ -664,16 +734,13 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
     // what the bilateral phase gathers (rows / columns 2 .. kLow+5): 22.3 KB per workgroup instead of
     // 24.1 KB, which lets a seventh workgroup share the CU's 160 KB (with __launch_bounds__(.., 7):
     // A/B on one box, 357 -> 343 us for the kernel that also carries the next downsample pass).
-    constexpr int kDep0 = FINAL ? 2 : 0;                                   // first row / column kept
-    constexpr int kDepH = FINAL ? T::kLowH + 4 : T::kRawH, kDepW = FINAL ? T::kLowW + 4 : T::kRawW;
-    constexpr int kDepPitch = FINAL ? 36 : T::kRawPitch;
-    constexpr int kInvN = T::kRawH * T::kRawPitch, kHbN = T::kRawH * T::kBlurPitch, kDepN = kDepH * kDepPitch;
-    constexpr int kAoN = T::kRawH * T::kRawPitch;
+    typedef UpsLds<FINAL> Lds;
+    constexpr int kDep0 = Lds::kDep0, kDepH = Lds::kDepH, kDepW = Lds::kDepW, kDepPitch = Lds::kDepPitch;
+    constexpr int kInvN = Lds::kInvN, kHbN = Lds::kHbN, kDepN = Lds::kDepN, kAoN = Lds::kAoN;
     static_assert(kDepW <= kDepPitch && (T::kRawRows - T::kRawH) * T::kRawPitch <= kHbN &&
                   (T::kRawRows - T::kRawH) * T::kBlurPitch <= kDepN + kAoN, "scratch rows stay inside the allocation");
     static_assert(T::kVRows * T::kBlurPitch <= kAoN, "s_vb fits in s_ao");
     static_assert(kInvN % 4 == 0 && kHbN % 4 == 0 && kDepN % 4 == 0, "16-byte alignment of the carved arrays");
-    __shared__ __attribute__((aligned(16))) float smem[kInvN + kHbN + kDepN + kAoN];
     float *const s_inv = smem;                       // 1 / LoResDB   (DepthCache)
     float *const s_hb = s_inv + kInvN;               // after BlurHorizontally (AOCache2)
     float *const s_dep = s_hb + kHbN;                // LoResDB       (LoDepths gather), window from (kDep0, kDep0)
@@ -773,7 +840,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
     // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
                                    : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
-    const bool vec_ok = (hw & 3) == 0;
+    const bool vec_ok = a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
     // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
     constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
     const int tx = threadIdx.x & 15;
@@ -861,10 +928,24 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, int tile, i
     }
 }
 
+// The (rare) hostile-frame variant of a tile: the same code with IEEE division.
+template <int AOFMT, bool RTNE, bool FINAL, int DIV>
+__device__ __forceinline__ void upsample_tile_checked(const UpsampleArgs &a, float *smem, int tile, int frame)
+{
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
+            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE>(a, smem, tile, frame);
+            return;
+        }
+    }
+    upsample_tile<AOFMT, RTNE, FINAL, DIV>(a, smem, tile, frame);
+}
+
 template <int AOFMT, bool RTNE, bool FINAL, int DIV>
 __global__ __launch_bounds__(kThreads, FINAL ? 7 : 1) void upsample_kernel(const UpsampleArgs a)
 {
-        upsample_tile<AOFMT, RTNE, FINAL, DIV>(a, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<FINAL>::kFloats];
+    upsample_tile_checked<AOFMT, RTNE, FINAL, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
 
 // Upsample.main of this batch carrying the downsample pass of the NEXT batch (meao_prefetch_batch):
@@ -877,14 +958,15 @@ template <int AOFMT, bool RTNE, int DIV>
 __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsample_kernel(const UpsampleArgs a,
                                                                                        const DownsampleArgs d)
 {
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<true>::kFloats];
     const int ds_tiles = d.tiles_x * d.tiles_y;
-    const bool vec = (d.w[0] & 3) == 0;
+    const bool vec = d.vec_ok != 0;
     for (int f = blockIdx.z; f < d.frames; f += gridDim.z)
         for (int t = blockIdx.x; t < ds_tiles; t += gridDim.x) {
             if (vec) downsample_tile<RTNE, true, DIV>(d, t, f);
             else downsample_tile<RTNE, false, DIV>(d, t, f);
         }
-        upsample_tile<AOFMT, RTNE, true, DIV>(a, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
+    upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1093,7 +1175,7 @@ __global__ __launch_bounds__(kThreads) void selftest_div_kernel(unsigned long lo
 hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
 {
     const dim3 grid(a.tiles_x * a.tiles_y, 1, frames), block(kThreads);
-    const bool vec = (a.w[0] & 3) == 0;
+    const bool vec = a.vec_ok != 0;
     if (a.f16_rtne) {
         if (vec) downsample_kernel<true, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
         else downsample_kernel<true, false, DIV_IEEE><<<grid, block, 0, s>>>(a);

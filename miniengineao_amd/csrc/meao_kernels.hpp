@@ -23,6 +23,11 @@ struct DownsampleArgs {
     int32_t exact_rcp_div;
     int32_t tiles_x, tiles_y;
     int32_t frames;                      // used by the fused kernel only (the plain launch has grid.z = frames)
+    int32_t vec_ok;                      // width % 4 == 0 and every depth pointer aligned for 4-texel loads
+    // hostile[frame] = generation when a texel of the frame is outside the range the exact
+    // v_rcp_f32 sequences are verified for (NaN, inf, negative, tiny); read by the later kernels
+    uint32_t *hostile;
+    uint32_t generation;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -52,6 +57,8 @@ struct RenderArgs {
     int32_t f16_rtne;
     int32_t exact_rcp_div;
     int32_t exhaustive;    // SAMPLE_EXHAUSTIVELY: 12 terms instead of 7
+    const uint32_t *hostile;   // per frame, written by the downsample pass that produced `src`
+    uint32_t generation;       // hostile[frame] == generation -> IEEE-division body for that frame
 };
 
 // Render.main (WIDE_SAMPLING, non-interleaved) on the non-tiled LowDepth<level>: same args; `src`
@@ -81,6 +88,9 @@ struct UpsampleArgs {
     float noise_filter_strength, step_size, blur_tolerance, upsample_tolerance;
     int32_t f16_rtne;
     int32_t exact_rcp_div;     // operands proven inside the exact range of the v_rcp_f32 sequences
+    int32_t vec_ok;            // hw % 4 == 0 and, in the final pass, every dst pointer aligned for 4-texel stores
+    const uint32_t *hostile;   // as in RenderArgs
+    uint32_t generation;
 };
 
 // ---------------------------------------------------------------------------------------

@@ -54,6 +54,21 @@ def max_over_ranks(value: float, device: "torch.device | None" = None) -> float:
     return float(t.item())
 
 
+def world_size() -> int:
+    """World size as the process group reports it (1 without a group)."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def gather_floats(value: float, device: "torch.device | None" = None) -> List[float]:
+    """One float per rank, indexed by rank (e.g. each rank's own ms per step)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=_tensor_device(device))
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def gather_checksums(local: List[int], device: "torch.device | None" = None) -> List[List[int]]:
     """All ranks' per-frame 63-bit checksums, indexed [rank][local frame]."""
     if not dist.is_initialized():

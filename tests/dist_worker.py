@@ -34,9 +34,11 @@ def main():
     local = time.perf_counter() - t0 + 0.001 * rank
     slowest = mdist.max_over_ranks(local)
     gathered = mdist.gather_checksums(sums)
+    per_rank = mdist.gather_floats(local)
     if rank == 0:
         print(json.dumps({"world": world, "frames": [frames_for_rank(num_frames, r, world) for r in range(world)],
-                          "checksums": gathered, "slowest": slowest, "local0": local}))
+                          "checksums": gathered, "slowest": slowest, "local0": local, "per_rank": per_rank,
+                          "world_seen": mdist.world_size()}))
     mdist.shutdown()
 
 

@@ -9,7 +9,7 @@ import sys
 import pytest
 
 from miniengineao_amd import synth
-from miniengineao_amd.sharding import frame_seed, frames_for_rank
+from miniengineao_amd.sharding import frame_checksum, frame_seed, frames_for_rank, owner_of_frame
 from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,6 +25,17 @@ def test_partition_is_a_disjoint_cover():
     assert frames_for_rank(8, 3, 8) == [3]           # BASELINE config 4: one 4K frame per GPU
     with pytest.raises(ValueError):
         frames_for_rank(4, 2, 2)
+    for world in (1, 2, 8):
+        for f in range(20):
+            assert f in frames_for_rank(20, owner_of_frame(f, world), world)
+
+
+def test_frame_checksum_is_order_sensitive_and_63_bit():
+    import numpy as np
+    a = np.arange(4096, dtype=np.uint8).reshape(64, 64)
+    b = a.copy(); b[3, 5], b[3, 6] = a[3, 6], a[3, 5]
+    assert frame_checksum(a) != frame_checksum(b) and 0 <= frame_checksum(a) < 2 ** 63
+    assert frame_checksum(a) == H.checksum(a) & 0x7FFFFFFFFFFFFFFF
 
 
 @pytest.mark.parametrize("world,port", [(2, 29611), (3, 29612)])
@@ -41,6 +52,8 @@ def test_sharded_batch_over_gloo(oracle, world, port):
     assert res["world"] == world
     assert res["frames"] == [frames_for_rank(num_frames, r, world) for r in range(world)]
     assert res["slowest"] >= res["local0"]           # max over ranks
+    assert res["world_seen"] == world and len(res["per_rank"]) == world
+    assert abs(max(res["per_rank"]) - res["slowest"]) < 1e-9 and abs(res["per_rank"][0] - res["local0"]) < 1e-9
     s = H.settings(oracle, 96, 54)
     for r in range(world):
         for k, f in enumerate(res["frames"][r]):
