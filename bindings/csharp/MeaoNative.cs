@@ -45,6 +45,7 @@ namespace MiniEngineAO.Native
         public int sample_set;
         public int launch_mode;
         public int pipelined;
+        public int concurrent_levels;
     }
 
     [StructLayout(LayoutKind.Sequential)]

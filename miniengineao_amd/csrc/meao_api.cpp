@@ -21,6 +21,10 @@ thread_local std::string g_last_error;   // for failures that have no context (m
 
 constexpr uint64_t kAlign = 256;
 constexpr int kProfileRing = 256;         // executes buffered before timings are folded
+// launch slots of one execute: the MEAO_NUM_PASSES passes + the coarse-level render launch of the
+// concurrent mode (its time is reported as part of MEAO_PASS_RENDER)
+constexpr int kSlotRenderCoarse = MEAO_NUM_PASSES;
+constexpr int kProfSlots = MEAO_NUM_PASSES + 1;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 }  // namespace
@@ -78,11 +82,17 @@ struct meao_ctx {
     };
     std::vector<CapturedBatch> graphs;
 
-    // profiling: a ring of per-execute event sets; each entry remembers which passes it ran
+    // Concurrent coarse chain (cfg.concurrent_levels): render L2..L4 and the two smallest upsample
+    // passes run on aux_stream next to render L1 on the caller's stream (fork / join with events).
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
+    // profiling: a ring of per-execute event sets (one start/end pair per launch slot); each entry
+    // remembers which slots it used
     bool profiling = false;
-    std::vector<hipEvent_t> events;              // kProfileRing * (MEAO_NUM_PASSES + 1)
+    std::vector<hipEvent_t> events;              // kProfileRing * kProfSlots * 2
     int ring_fill = 0;
-    uint32_t ran_mask[kProfileRing] = {};        // bit k: pass k ran in that execute
+    uint32_t ran_mask[kProfileRing] = {};        // bit k: launch slot k ran in that execute
     double pass_ms_sum[MEAO_NUM_PASSES] = {};
     int pass_samples[MEAO_NUM_PASSES] = {};      // executes that ran pass k
     int executes_profiled = 0;
@@ -131,6 +141,7 @@ bool config_valid(const meao_config &c, std::string *why)
     if (c.sample_set != MEAO_SAMPLES_CHECKER && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE) { *why = "unknown sample_set"; return false; }
     if (c.launch_mode != MEAO_LAUNCH_DIRECT && c.launch_mode != MEAO_LAUNCH_GRAPH) { *why = "unknown launch_mode"; return false; }
     if (c.pipelined != 0 && c.pipelined != 1) { *why = "pipelined must be 0 or 1"; return false; }
+    if (c.concurrent_levels != 0 && c.concurrent_levels != 1) { *why = "concurrent_levels must be 0 or 1"; return false; }
     return true;
 }
 
@@ -243,26 +254,19 @@ int use_device(meao_ctx *ctx)
 template <typename T>
 T *slot_ptr(meao_ctx *ctx, uint64_t off) { return reinterpret_cast<T *>(ctx->arena + off); }
 
-// Launch order on the stream; event i / i+1 of an execute bracket kStreamOrder[i].
-constexpr int kStreamOrder[MEAO_NUM_PASSES] = {MEAO_PASS_DOWNSAMPLE, MEAO_PASS_RENDER, MEAO_PASS_RENDER_HQ,
-                                               MEAO_PASS_UPSAMPLE_3, MEAO_PASS_UPSAMPLE_2, MEAO_PASS_UPSAMPLE_1,
-                                               MEAO_PASS_UPSAMPLE_0};
-
 void fold_profile(meao_ctx *ctx)
 {
-    // events of the buffered executes are complete once the last one is
-    const int per = MEAO_NUM_PASSES + 1;
     if (ctx->ring_fill == 0) return;
-    (void)hipEventSynchronize(ctx->events[(ctx->ring_fill - 1) * per + MEAO_NUM_PASSES]);
     for (int r = 0; r < ctx->ring_fill; ++r) {
-        for (int i = 0; i < MEAO_NUM_PASSES; ++i) {
-            const int k = kStreamOrder[i];
+        for (int k = 0; k < kProfSlots; ++k) {
             if (!(ctx->ran_mask[r] >> k & 1u)) continue;
+            hipEvent_t a = ctx->events[(r * kProfSlots + k) * 2], b = ctx->events[(r * kProfSlots + k) * 2 + 1];
+            (void)hipEventSynchronize(b);
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ctx->events[r * per + i], ctx->events[r * per + i + 1]) == hipSuccess) {
-                ctx->pass_ms_sum[k] += ms;
-                ++ctx->pass_samples[k];
-            }
+            if (hipEventElapsedTime(&ms, a, b) != hipSuccess) continue;
+            const int pass = k == kSlotRenderCoarse ? MEAO_PASS_RENDER : k;
+            ctx->pass_ms_sum[pass] += ms;
+            if (k != kSlotRenderCoarse) ++ctx->pass_samples[pass];
         }
         ++ctx->executes_profiled;
     }
@@ -283,15 +287,18 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     const Plan &p = ctx->plan;
     const meao_config &c = ctx->cfg;
     const int rtne = c.f16_rounding == MEAO_F16_RTNE;
-    const int per = MEAO_NUM_PASSES + 1;
     hipEvent_t *ev = nullptr;
     uint32_t ran = 0;
     if (ctx->profiling) {
         if (ctx->ring_fill == kProfileRing) fold_profile(ctx);
-        ev = &ctx->events[ctx->ring_fill * per];
+        ev = &ctx->events[ctx->ring_fill * kProfSlots * 2];
     }
-    int slot_index = 0;   // position in kStreamOrder
-    auto mark = [&]() -> hipError_t { return ev ? hipEventRecord(ev[slot_index++], stream) : hipSuccess; };
+    // one launch = one profiling slot: events right before and after it on ITS stream
+    auto begin = [&](int slot, hipStream_t s) -> hipError_t { return ev ? hipEventRecord(ev[slot * 2], s) : hipSuccess; };
+    auto end = [&](int slot, hipStream_t s) -> hipError_t {
+        ran |= 1u << slot;
+        return ev ? hipEventRecord(ev[slot * 2 + 1], s) : hipSuccess;
+    };
 
     // 4-texel vector loads / stores need 16-byte (f32, UNORM24), 8-byte (16-bit) aligned depth rows and
     // 4- (R8) / 8-byte (F16) aligned AO rows: width % 4 == 0 and aligned base pointers (include/meao.h);
@@ -333,23 +340,21 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
                             std::memcmp(ctx->ready_depth, depth_dev, sizeof(void *) * n) == 0;
     ctx->ds_cur = prefetched ? ctx->ready_set : 0;
     ctx->ready_n = 0;
-    MEAO_HIP(ctx, mark());
     if (!prefetched) {
         TraceRange tr(ctx, "meao:downsample");
         ctx->set_gen[ctx->ds_cur] = next_generation();
+        MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, stream));
         MEAO_HIP(ctx, launch_downsample(downsample_args(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur]), n, stream));
-        ran |= 1u << MEAO_PASS_DOWNSAMPLE;
+        MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, stream));
     }
-    MEAO_HIP(ctx, mark());
     const uint32_t *hostile = ctx->hostile_of(ctx->ds_cur);
     const uint32_t generation = ctx->set_gen[ctx->ds_cur];
 
-    // ---- PushRenderCommands x num_levels (AO.cs:519-522) as one grid; then Render.main (wide)
-    // on LowDepth<k> for the levels cfg.hq_levels enables, also one grid
-    for (int wide = 0; wide < 2; ++wide) {
+    // ---- PushRenderCommands x num_levels (AO.cs:519-522): the levels [first, last] as one grid
+    auto render_args = [&](int first, int last, bool wide) {
         RenderArgs rn{};
         int blocks = 0, count = 0;
-        for (int l = 1; l <= c.num_levels; ++l) {
+        for (int l = first; l <= last; ++l) {
             if (wide && !level_has_hq(c.num_levels, c.hq_levels, l)) continue;
             RenderLevelArgs &L = rn.level[count++];
             const RenderLevelPlan &rp = wide ? p.render_hq[l - 1] : p.render[l - 1];
@@ -378,73 +383,124 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         rn.exhaustive = c.sample_set == MEAO_SAMPLES_EXHAUSTIVE;
         rn.hostile = hostile;
         rn.generation = generation;
-        if (count > 0) {
-            TraceRange tr(ctx, wide ? "meao:render_hq" : "meao:render");
-            MEAO_HIP(ctx, wide ? launch_render_wide(rn, c.ao_format, n, stream) : launch_render(rn, c.ao_format, n, stream));
-            ran |= 1u << (wide ? MEAO_PASS_RENDER_HQ : MEAO_PASS_RENDER);
-        }
-        MEAO_HIP(ctx, mark());
-    }
+        return rn;
+    };
 
-    // ---- PushUpsampleCommands chain (AO.cs:528-531), generalised to num_levels
+    // ---- PushUpsampleCommands (AO.cs:750-785): the pass that writes level `hi`
     static const char *const kUpsRange[4] = {"meao:upsample_L1_to_L0", "meao:upsample_L2_to_L1", "meao:upsample_L3_to_L2",
                                              "meao:upsample_L4_to_L3"};
-    const void *lo_ao = slot_ptr<void>(ctx, ctx->off_occ[c.num_levels - 1]);
-    for (int hi = 3; hi >= 0; --hi) {
-        const int pass = MEAO_PASS_UPSAMPLE_0 - hi;
-        if (hi <= c.num_levels - 1) {
-            UpsampleArgs up{};
-            const meao_upsample_constants &k = p.upsample[hi];   // low level = hi + 1
-            up.lo_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi));
-            up.lo_ao = lo_ao;
-            // main_premin*: the Render.main output of the low level is min-combined in PrefetchData
-            up.lo_ao2 = level_has_hq(c.num_levels, c.hq_levels, hi + 1) ? slot_ptr<void>(ctx, ctx->off_hq[hi]) : nullptr;
-            up.frame_stride = ctx->slot_bytes;
-            up.lw = p.mip[hi + 1].w; up.lh = p.mip[hi + 1].h;
-            up.hw = p.mip[hi].w; up.hh = p.mip[hi].h;
-            up.tiles_x = (up.hw + kUpsTileW - 1) / kUpsTileW;
-            up.tiles_y = (up.hh + ups_tile_h(hi == 0) - 1) / ups_tile_h(hi == 0);
-            up.noise_filter_strength = k.noise_filter_strength;
-            up.step_size = k.step_size;
-            up.blur_tolerance = k.blur_tolerance;
-            up.upsample_tolerance = k.upsample_tolerance;
-            up.f16_rtne = rtne;
-            up.exact_rcp_div = ctx->exact_rcp_div;
-            up.hostile = hostile;
-            up.generation = generation;
-            bool vec_ok = (up.hw & 3) == 0;
-            if (hi > 0) {   // main_blendout: blend with Occlusion<hi>, write Combined<hi>
-                up.hi_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi - 1));
-                up.hi_ao = slot_ptr<void>(ctx, ctx->off_occ[hi - 1]);
-                up.dst[0] = slot_ptr<void>(ctx, ctx->off_comb[hi - 1]);
-                lo_ao = up.dst[0];
-            } else {        // main: LinearDepth f16 as HiResDB, no HiResAO, write the result
-                up.hi_depth = slot_ptr<uint16_t>(ctx, ctx->off_linear_of(ctx->ds_cur));
-                up.hi_ao = nullptr;
-                for (int f = 0; f < n; ++f) {
-                    up.dst[f] = out_dev[f];
-                    vec_ok = vec_ok && aligned_to(out_dev[f], out_align);
-                }
+    auto upsample_args = [&](int hi) {
+        UpsampleArgs up{};
+        const meao_upsample_constants &k = p.upsample[hi];   // low level = hi + 1
+        up.lo_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi));
+        // LoResAO1: the coarsest level's Occlusion, else the Combined buffer of the previous pass
+        up.lo_ao = slot_ptr<void>(ctx, hi == c.num_levels - 1 ? ctx->off_occ[hi] : ctx->off_comb[hi]);
+        // main_premin*: the Render.main output of the low level is min-combined in PrefetchData
+        up.lo_ao2 = level_has_hq(c.num_levels, c.hq_levels, hi + 1) ? slot_ptr<void>(ctx, ctx->off_hq[hi]) : nullptr;
+        up.frame_stride = ctx->slot_bytes;
+        up.lw = p.mip[hi + 1].w; up.lh = p.mip[hi + 1].h;
+        up.hw = p.mip[hi].w; up.hh = p.mip[hi].h;
+        up.tiles_x = (up.hw + kUpsTileW - 1) / kUpsTileW;
+        up.tiles_y = (up.hh + ups_tile_h(hi == 0) - 1) / ups_tile_h(hi == 0);
+        up.noise_filter_strength = k.noise_filter_strength;
+        up.step_size = k.step_size;
+        up.blur_tolerance = k.blur_tolerance;
+        up.upsample_tolerance = k.upsample_tolerance;
+        up.f16_rtne = rtne;
+        up.exact_rcp_div = ctx->exact_rcp_div;
+        up.hostile = hostile;
+        up.generation = generation;
+        bool vec_ok = (up.hw & 3) == 0;
+        if (hi > 0) {   // main_blendout: blend with Occlusion<hi>, write Combined<hi>
+            up.hi_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi - 1));
+            up.hi_ao = slot_ptr<void>(ctx, ctx->off_occ[hi - 1]);
+            up.dst[0] = slot_ptr<void>(ctx, ctx->off_comb[hi - 1]);
+        } else {        // main: LinearDepth f16 as HiResDB, no HiResAO, write the result
+            up.hi_depth = slot_ptr<uint16_t>(ctx, ctx->off_linear_of(ctx->ds_cur));
+            up.hi_ao = nullptr;
+            for (int f = 0; f < n; ++f) {
+                up.dst[f] = out_dev[f];
+                vec_ok = vec_ok && aligned_to(out_dev[f], out_align);
             }
-            up.vec_ok = vec_ok;
-            TraceRange tr(ctx, kUpsRange[hi]);
-            if (hi == 0 && ctx->next_n > 0) {
-                // carry the downsample of the announced next batch in this (VALU-bound) kernel
-                const int other = 1 - ctx->ds_cur;
-                ctx->set_gen[other] = next_generation();
-                MEAO_HIP(ctx, launch_upsample_final_with_downsample(
-                                  up, downsample_args(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other]), c.ao_format, n, stream));
-                ctx->ready_n = ctx->next_n;
-                ctx->ready_set = other;
-                ctx->ready_stream = stream;
-                std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
-                ctx->next_n = 0;
-            } else {
-                MEAO_HIP(ctx, launch_upsample(up, c.ao_format, hi == 0, n, stream));
-            }
-            ran |= 1u << pass;
         }
-        MEAO_HIP(ctx, mark());
+        up.vec_ok = vec_ok;
+        return up;
+    };
+    auto launch_blend = [&](int hi, hipStream_t s) -> int {   // hi = 3, 2, 1
+        const int pass = MEAO_PASS_UPSAMPLE_0 - hi;
+        TraceRange tr(ctx, kUpsRange[hi]);
+        MEAO_HIP(ctx, begin(pass, s));
+        MEAO_HIP(ctx, launch_upsample(upsample_args(hi), c.ao_format, false, n, s));
+        MEAO_HIP(ctx, end(pass, s));
+        return MEAO_OK;
+    };
+
+    // Concurrent coarse chain: render L2..L4 -> upsample L4->L3 -> L3->L2 only depend on each other and
+    // are latency-bound (few workgroups, three barriers each); on a second stream they run next to
+    // render L1, which has 3/4 of the render work, instead of serialising five launches.
+    const bool concurrent = c.concurrent_levels != 0 && c.num_levels == 4 && c.hq_levels == 0 && ctx->aux_stream != nullptr;
+    if (concurrent) {
+        hipStream_t aux = ctx->aux_stream;
+        MEAO_HIP(ctx, hipEventRecord(ctx->ev_fork, stream));
+        MEAO_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+        {
+            TraceRange tr(ctx, "meao:render_L2_L3_L4");
+            MEAO_HIP(ctx, begin(kSlotRenderCoarse, aux));
+            MEAO_HIP(ctx, launch_render(render_args(2, 4, false), c.ao_format, n, aux));
+            MEAO_HIP(ctx, end(kSlotRenderCoarse, aux));
+        }
+        {
+            TraceRange tr(ctx, "meao:render_L1");
+            MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
+            MEAO_HIP(ctx, launch_render(render_args(1, 1, false), c.ao_format, n, stream));
+            MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
+        }
+        int rc = launch_blend(3, aux);
+        if (rc == MEAO_OK) rc = launch_blend(2, aux);
+        if (rc != MEAO_OK) return rc;
+        MEAO_HIP(ctx, hipEventRecord(ctx->ev_join, aux));
+        MEAO_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
+    } else {
+        {
+            TraceRange tr(ctx, "meao:render");
+            MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
+            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false), c.ao_format, n, stream));
+            MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
+        }
+        if (c.hq_levels > 0) {   // Render.main (wide) on LowDepth<k> for the levels cfg.hq_levels enables, one grid
+            TraceRange tr(ctx, "meao:render_hq");
+            MEAO_HIP(ctx, begin(MEAO_PASS_RENDER_HQ, stream));
+            MEAO_HIP(ctx, launch_render_wide(render_args(1, c.num_levels, true), c.ao_format, n, stream));
+            MEAO_HIP(ctx, end(MEAO_PASS_RENDER_HQ, stream));
+        }
+        for (int hi = c.num_levels - 1; hi >= 2; --hi) {
+            const int rc = launch_blend(hi, stream);
+            if (rc != MEAO_OK) return rc;
+        }
+    }
+    if (c.num_levels >= 2) {
+        const int rc = launch_blend(1, stream);
+        if (rc != MEAO_OK) return rc;
+    }
+    {   // Upsample.main: the result
+        TraceRange tr(ctx, kUpsRange[0]);
+        const UpsampleArgs up = upsample_args(0);
+        MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_0, stream));
+        if (ctx->next_n > 0) {
+            // carry the downsample of the announced next batch in this (VALU-bound) kernel
+            const int other = 1 - ctx->ds_cur;
+            ctx->set_gen[other] = next_generation();
+            MEAO_HIP(ctx, launch_upsample_final_with_downsample(
+                              up, downsample_args(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other]), c.ao_format, n, stream));
+            ctx->ready_n = ctx->next_n;
+            ctx->ready_set = other;
+            ctx->ready_stream = stream;
+            std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
+            ctx->next_n = 0;
+        } else {
+            MEAO_HIP(ctx, launch_upsample(up, c.ao_format, true, n, stream));
+        }
+        MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_0, stream));
     }
     if (ev) ctx->ran_mask[ctx->ring_fill++] = ran;
     for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
@@ -540,6 +596,7 @@ void meao_default_config(meao_config *cfg)
     cfg->max_batch = 1;
     cfg->depth_format = MEAO_DEPTH_F32;
     cfg->pipelined = 0;
+    cfg->concurrent_levels = 1;
 }
 
 void meao_default_params(meao_params *p)
@@ -653,6 +710,12 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
         e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
         if (e != hipSuccess) rc = fail_hip(ctx, e, "hipStreamCreateWithFlags");
     }
+    if (rc == MEAO_OK && cfg->concurrent_levels) {
+        e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail_hip(ctx, e, "aux stream / events");
+    }
     if (rc == MEAO_OK) {
         // hostile-depth flags: 2 downsample sets x MEAO_MAX_BATCH frames, zero = never hostile (generations start at 1)
         const size_t bytes = 2 * MEAO_MAX_BATCH * sizeof(uint32_t);
@@ -683,6 +746,9 @@ int32_t meao_destroy(meao_ctx *ctx)
     if (ctx->hostile) (void)hipFree(ctx->hostile);
     if (ctx->roctx_lib) (void)dlclose(ctx->roctx_lib);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MEAO_OK;
@@ -929,7 +995,7 @@ int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable)
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     if (enable && ctx->events.empty()) {
-        const int count = kProfileRing * (MEAO_NUM_PASSES + 1);
+        const int count = kProfileRing * kProfSlots * 2;
         ctx->events.reserve(count);
         for (int i = 0; i < count; ++i) {
             hipEvent_t ev;

@@ -1,18 +1,18 @@
-# A/B on ONE box: bench with the in-tree lib, then rebuild with the given hipcc defines and bench again, twice each
-# usage: bash tests/run_gpu_ab.sh "-DMEAO_UPS_TILE_H=32" [bench args]
+# A/B on one box: bench.py with two flag sets, alternating, 3 runs each.   bash tests/run_gpu_ab.sh TAG "flagsA" "flagsB"
+TAG=$1; A=$2; B=$3
 mkdir -p gpurun_out
-DEF="$1"; shift
-show() { python - "$1" <<'PY'
-import json, sys
-d = json.load(open(sys.argv[1]))
-print(sys.argv[1], 'value', d['value'], ' '.join('%s=%.1f' % (p['kernel'].replace('upsample_', 'u'), p['ms'] * 1e3) for p in d['roofline']['passes']))
+for i in 1 2 3; do
+  timeout 300 python bench.py --no-cpu-baseline --skip-latency --validate-frames 1 $A 2>/dev/null | grep '^{' > gpurun_out/ab_${TAG}_A$i.json
+  timeout 300 python bench.py --no-cpu-baseline --skip-latency --validate-frames 1 $B 2>/dev/null | grep '^{' > gpurun_out/ab_${TAG}_B$i.json
+done
+python - <<PY
+import json,glob
+for arm in "AB":
+    for f in sorted(glob.glob("gpurun_out/ab_${TAG}_%s?.json" % arm)):
+        try:
+            j=json.loads(open(f).read())
+            ps={p["kernel"]:p["ms"] for p in j["roofline"]["passes"]}
+            print(arm, f.split("_")[-1], j["value"], j["ms_per_step"], j["validation"]["mismatching_frames"], {k:round(v*1e3,1) for k,v in ps.items()}, "plain", j["plain_launch_sequence"] and j["plain_launch_sequence"]["value"])
+        except Exception as e:
+            print(arm, f, "ERR", e)
 PY
-}
-run() { timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --skip-latency "${@:2}" 2>&1 | grep '^{' > gpurun_out/ab_$1.json; show gpurun_out/ab_$1.json; }
-run A1 "$@"
-python -c "from miniengineao_amd import build; build.build_lib(force=True, extra_flags=tuple('$DEF'.split()))"
-run B1 "$@"
-python -c "from miniengineao_amd import build; build.build_lib(force=True)"
-run A2 "$@"
-python -c "from miniengineao_amd import build; build.build_lib(force=True, extra_flags=tuple('$DEF'.split()))"
-run B2 "$@"
