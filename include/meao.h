@@ -139,11 +139,12 @@ typedef struct meao_config {
     int32_t pipelined;      /* 1: allocate the second set of downsample buffers at meao_create, so that
                              * meao_prefetch_batch never allocates or synchronises (streams of frames);
                              * 0 (default): the first meao_prefetch_batch call does it, once */
-    int32_t concurrent_levels; /* 1 (default): with 4 levels, render L2..L4 and the two smallest upsample
-                             * passes (L4->L3, L3->L2) run on a second, context-owned stream next to
-                             * render L1 (fork / join with events on the caller's stream): they only
-                             * depend on each other and are latency-bound.  0: every pass on the
-                             * caller's stream, in the reference's order.  Same results. */
+    int32_t concurrent_levels; /* 1: with 4 levels, render L2..L4 and the two smallest upsample passes
+                             * (L4->L3, L3->L2) run on a second, context-owned stream next to render L1
+                             * (fork / join with events on the caller's stream): they only depend on each
+                             * other.  0 (default): every pass on the caller's stream, in the reference's
+                             * order.  Same results.  Measured on MI355X: no gain for batches (the GPU is
+                             * already full; 0.661 vs 0.661 ms per 16-frame step), see profiles/README.md. */
 } meao_config;
 
 /* The component's serialized properties (AO.cs:20-68; defaults there) and the camera terms

@@ -19,7 +19,8 @@ import os
 import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmeao_hip.so")
+# MEAO_LIB_PATH: an alternative build of the same library (A/B of kernel variants, tests/run_gpu_variants_ab.sh)
+LIB_PATH = os.environ.get("MEAO_LIB_PATH") or os.path.join(_PKG, "lib", "libmeao_hip.so")
 
 ABI_VERSION = 4
 MAX_BATCH = 64

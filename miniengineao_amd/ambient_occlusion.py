@@ -39,7 +39,7 @@ class AmbientOcclusion:
                  projection00: Optional[float] = None, reversed_z: bool = True,
                  hq_levels: int = 0, sample_set: int = L.SAMPLES_CHECKER, single_pass_stereo: bool = False,
                  launch_mode: int = L.LAUNCH_DIRECT, pipelined: bool = False,
-                 concurrent_levels: bool = True):
+                 concurrent_levels: bool = False):
         """hq_levels / sample_set / single_pass_stereo: variants the reference's shaders and host carry
         but its command buffer never (or only in VR) uses; see include/meao.h.  ``width`` is the
         double-wide eye pair when single_pass_stereo is set (AO.cs:339)."""

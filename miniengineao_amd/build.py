@@ -50,13 +50,15 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > built for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not _stale():
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str = None) -> str:
+    """out_path + extra_flags (-DMEAO_...) build a kernel variant next to the product library (A/B runs)."""
+    if out_path is None and not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc(), *FLAGS, *extra_flags, f"-I{_INCLUDE}"]
     cmd += [os.path.join(_CSRC, s) for s in SOURCES]
-    tmp = LIB_PATH + ".tmp"
+    final = out_path or LIB_PATH
+    tmp = final + ".tmp"
     cmd += ["-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -65,8 +67,8 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str
         raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
     if verbose and proc.stderr.strip():
         print(proc.stderr)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    os.replace(tmp, final)
+    return final
 
 
 DEMO_PATH = os.path.join(LIB_DIR, "ao_host_demo")

@@ -362,7 +362,8 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             L.dst = slot_ptr<void>(ctx, wide ? ctx->off_hq[l - 1] : ctx->off_occ[l - 1]);
             L.lw = p.mip[l].w; L.lh = p.mip[l].h;
             L.sw = p.mip[l + 2].w; L.sh = p.mip[l + 2].h;
-            L.tiles_x = (L.lw + kRenTileW - 1) / kRenTileW;
+            const int tile_w = wide ? kWideTileW : ren_tile_w(c.sample_set == MEAO_SAMPLES_EXHAUSTIVE);
+            L.tiles_x = (L.lw + tile_w - 1) / tile_w;
             L.tiles_y = (L.lh + kRenTileH - 1) / kRenTileH;
             L.block_begin = blocks;
             blocks += L.tiles_x * L.tiles_y;
@@ -596,7 +597,7 @@ void meao_default_config(meao_config *cfg)
     cfg->max_batch = 1;
     cfg->depth_format = MEAO_DEPTH_F32;
     cfg->pipelined = 0;
-    cfg->concurrent_levels = 1;
+    cfg->concurrent_levels = 0;
 }
 
 void meao_default_params(meao_params *p)

@@ -34,6 +34,15 @@
 #include <algorithm>
 #include <type_traits>
 
+// Build-time switches for A/B runs (tests/build_variants.py builds variants next to the product
+// library; measured outcomes in profiles/README.md).
+#ifndef MEAO_UPS_HOIST
+#define MEAO_UPS_HOIST 1        // hi-res depth / AO loads of the bilateral phase issued at the top of the tile
+#endif
+#ifndef MEAO_REN_FASTPATH
+#define MEAO_REN_FASTPATH 0     // wave-uniform "all distances >= 0" path in the render kernel (bit-exact; slower, see test_samples)
+#endif
+
 namespace meao {
 namespace {
 
@@ -384,65 +393,92 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleAr
 // ------------------------------------------------------------------------------------------
 // Render: volumetric-obscurance AO, 36-sample checker set.
 
-// TestSamplePair (REN:60-75) for one output texel; s1/s2 are the two opposite depth samples.
+// TestSamplePair (REN:60-75) for one output texel, from the two signed distances d = s * invRange - front.
 // saturate() folds into the clamp output modifier of v_mul/v_fma; clamp(d, p, 1) with
 // 0 <= p <= 1 is v_med3_f32(d, p, 1) (same value for every input incl. NaN d -> p).
-__device__ __forceinline__ float test_sample_pair(float s1, float s2, float inv_range, float neg_front, float reject)
+__device__ __forceinline__ float pair_from_distances(float d1, float d2, float reject)
 {
-    const float d1 = mad(s1, inv_range, neg_front);
-    const float d2 = mad(s2, inv_range, neg_front);
     const float p1 = sat(reject * d1);
     const float p2 = sat(reject * d2);
     const float acc = __builtin_amdgcn_fmed3f(d1, p2, 1.0f) + __builtin_amdgcn_fmed3f(d2, p1, 1.0f);
     return sat(mad(-p1, p2, acc));
 }
 
-// Two horizontally adjacent texels share every LDS address: one ds_read_b64 per sample.
-__device__ __forceinline__ float2v test_sample_pair2(const float *centre, int offset, float2v inv_range,
-                                                     float neg_front, float reject)
-{
-    const float2v s1 = *reinterpret_cast<const float2v *>(centre + offset);
-    const float2v s2 = *reinterpret_cast<const float2v *>(centre - offset);
-    return float2v{test_sample_pair(s1.x, s2.x, inv_range.x, neg_front, reject),
-                   test_sample_pair(s1.y, s2.y, inv_range.y, neg_front, reject)};
-}
+// When d1 >= 0 and d2 >= 0 (no NaN): p1 = p2 = 0, so the pair is saturate(saturate(d1) + saturate(d2)),
+// and that equals saturate(d1 + d2): if both are <= 1 the expressions are identical; if one exceeds 1
+// both sides are 1 (rounding is monotonic, so d1 + d2 >= max(d1, d2)).  One v_add_f32 with clamp.
+__device__ __forceinline__ float pair_all_nonnegative(float d1, float d2) { return sat(d1 + d2); }
+
 
 // TestSamples (REN:77-110) WITHOUT its leading 0.5 / 0.25: that exact power-of-two factor is folded
 // into the term's weight on the host (RenderLevelArgs::weight), since fma(w, k*S, ao) and
 // fma(k*w, S, ao) round the same real number.  (X, Y) are sample offsets in source texels; the LDS
 // offset of (dx, dy) is dy*P + dx*Q.  Interleaved: one slice texel is 4 level texels (4x4 interleave),
 // P = 4*pitch, Q = 4.  Wide (REN:79-82, x <<= 1): P = 2*pitch, Q = 2.
-template <int X, int Y, int P, int Q>
+// Two horizontally adjacent texels share every LDS address: one 8-byte LDS read per sample.
+//
+// FAST (wave-uniform fast path, bit-exact): the 8 / 16 distances of the term are computed first; if no
+// lane of the wave has a negative one (v_min3 chain, one ballot), every pair of the term is
+// pair_all_nonnegative -- 1 instruction instead of 6.  `try_fast` carries the outcome to the next term
+// of the same texel: neighbouring terms sample the same neighbourhood, so after a miss the remaining
+// terms skip the test (a frame of slopes costs one failed test per texel, not seven).
+template <int X, int Y, int P, int Q, bool FAST>
 __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv_depth, float inv_thickness,
-                                                float front_depth, float reject)
+                                                float front_depth, float reject, bool &try_fast)
 {
+    constexpr int N = (Y == 0 || X == Y) ? 2 : 4;
+    constexpr int off[4] = {Y == 0 ? X * Q : (X == Y ? X * P - X * Q : Y * P + X * Q),
+                            Y == 0 ? X * P : (X == Y ? X * P + X * Q : Y * P - X * Q),
+                            X * P + Y * Q, X * P - Y * Q};
     const float2v inv_range = splat(inv_thickness) * inv_depth;
     const float neg_front = -front_depth;
-    if constexpr (Y == 0) {
-        return test_sample_pair2(centre, X * Q, inv_range, neg_front, reject) +
-               test_sample_pair2(centre, X * P, inv_range, neg_front, reject);
-    } else if constexpr (X == Y) {
-        return test_sample_pair2(centre, X * P - X * Q, inv_range, neg_front, reject) +
-               test_sample_pair2(centre, X * P + X * Q, inv_range, neg_front, reject);
-    } else {
-        return ((test_sample_pair2(centre, Y * P + X * Q, inv_range, neg_front, reject) +
-                 test_sample_pair2(centre, Y * P - X * Q, inv_range, neg_front, reject)) +
-                test_sample_pair2(centre, X * P + Y * Q, inv_range, neg_front, reject)) +
-               test_sample_pair2(centre, X * P - Y * Q, inv_range, neg_front, reject);
+    float2v d1[N], d2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float2v s1 = *reinterpret_cast<const float2v *>(centre + off[i]);
+        const float2v s2 = *reinterpret_cast<const float2v *>(centre - off[i]);
+        d1[i] = float2v{mad(s1.x, inv_range.x, neg_front), mad(s1.y, inv_range.y, neg_front)};
+        d2[i] = float2v{mad(s2.x, inv_range.x, neg_front), mad(s2.y, inv_range.y, neg_front)};
     }
+    float2v r[N];
+    bool fast = false;
+    if constexpr (FAST) {
+        if (try_fast) {
+            // minimum of the distances (v_min3_f32 chain; the inputs are NaN-free here).  Not an OR of
+            // the sign bits: ROCm 7.2's clang drops operands from or(bitcast(...)) < 0 (seen, reproduced).
+            float lowest = __builtin_fminf(__builtin_fminf(d1[0].x, d1[0].y), __builtin_fminf(d2[0].x, d2[0].y));
+#pragma unroll
+            for (int i = 1; i < N; ++i)
+                lowest = __builtin_fminf(__builtin_fminf(lowest, __builtin_fminf(d1[i].x, d1[i].y)), __builtin_fminf(d2[i].x, d2[i].y));
+            fast = __builtin_amdgcn_ballot_w64(lowest < 0.0f) == 0;   // wave-uniform
+            try_fast = fast;
+        }
+    }
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            r[i] = float2v{pair_all_nonnegative(d1[i].x, d2[i].x), pair_all_nonnegative(d1[i].y, d2[i].y)};
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            r[i] = float2v{pair_from_distances(d1[i].x, d2[i].x, reject), pair_from_distances(d1[i].y, d2[i].y, reject)};
+    }
+    if constexpr (N == 2) return r[0] + r[1];
+    else return ((r[0] + r[1]) + r[2]) + r[3];
 }
 
 // ao = sum over the terms of weight * TestSamples, in the reference's accumulation order:
 // checker set REN:162-168 (slots 1,3,4,8,11,6,10), SAMPLE_EXHAUSTIVELY REN:146-157
 // (slots 0,1,2,3,4,8,11,5,6,7,9,10).  L.weight[] etc. are already in term order; L.weight[] carries
 // the 0.5 (axial, diagonal) / 0.25 (L-shaped) factor of TestSamples.
-template <bool EXH, int P, int Q>
+template <bool EXH, int P, int Q, bool FAST>
 __device__ __forceinline__ float2v accumulate_terms(const RenderLevelArgs &L, const float *centre, float2v inv_depth)
 {
     const float reject = L.reject_fadeoff;
     float2v ao = splat(0.0f);
+    bool try_fast = true;
 #define MEAO_TERM(N, X, Y) \
-    ao = fma2(splat(L.weight[N]), test_samples<X, Y, P, Q>(centre, inv_depth, L.inv_thickness[N], L.front_depth[N], reject), ao)
+    ao = fma2(splat(L.weight[N]), test_samples<X, Y, P, Q, FAST>(centre, inv_depth, L.inv_thickness[N], L.front_depth[N], reject, try_fast), ao)
     if constexpr (EXH) {
         MEAO_TERM(0, 1, 0); MEAO_TERM(1, 2, 0); MEAO_TERM(2, 3, 0); MEAO_TERM(3, 4, 0);
         MEAO_TERM(4, 1, 1); MEAO_TERM(5, 2, 2); MEAO_TERM(6, 3, 3); MEAO_TERM(7, 1, 2);
@@ -475,6 +511,7 @@ template <int AOFMT, bool RTNE, int DIV, bool EXH>
 __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, int frame, int block)
 {
     typedef AoTexel<AOFMT> AO;
+    constexpr int kRenTileW = ren_tile_w(EXH), kRenThreads = kRenTileW * 4, kRenLdsW = kRenTileW + 2 * kRenApron;
 
     int b = block, lv = 0;
 #pragma unroll
@@ -494,7 +531,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
         const float pad = through_f16<RTNE>(L.pad_value);
         const bool vec_ok = (lw & 3) == 0;
         constexpr int kQuadsX = kRenLdsW / 4;
-        for (int q = threadIdx.x; q < kQuadsX * kRenLdsH; q += kThreads) {
+        for (int q = threadIdx.x; q < kQuadsX * kRenLdsH; q += kRenThreads) {
             const int qx = q % kQuadsX, qy = q / kQuadsX;
             const int px0 = clampi((X0 >> 2) - (kRenApron >> 2) + qx, 0, L.sw - 1) * 4;
             const int vy = Y0 - kRenApron + qy;
@@ -518,21 +555,24 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     }
     __syncthreads();
 
-    // ---- each lane: texel pairs (X, X+1) on rows ty, ty+8, ty+16, ty+24 of the tile
-    const int txl = threadIdx.x & 31, tyl = threadIdx.x >> 5;
-    const int X = X0 + 2 * txl;
-    if (X >= lw) return;
+    // ---- each lane: a texel pair (X, X+1) in each of the 4 iterations
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
     const bool pair_store = ((lw & 1) == 0);
+    // a wave covers a compact 32 x 4 block (16 lanes x 4 rows) of the tile in each of the 4 iterations
+    constexpr int kBlocksX = kRenTileW / 32, kWaves = kRenThreads / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
 #pragma unroll 1
     for (int k = 0; k < kRenTileH / 8; ++k) {
-        const int ly = tyl + 8 * k, Y = Y0 + ly;
-        if (Y >= lh) break;
+        const int blk = k * kWaves + wave;
+        const int txl = (blk % kBlocksX) * 16 + (lane & 15), ly = (blk / kBlocksX) * 4 + (lane >> 4);
+        const int X = X0 + 2 * txl, Y = Y0 + ly;
+        if (X >= lw || Y >= lh) continue;
         const float *centre = &tile[(ly + kRenApron) * kRenLdsW + 2 * txl + kRenApron];
         const float2v c = *reinterpret_cast<const float2v *>(centre);
         const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-        const float2v out = accumulate_terms<EXH, 4 * kRenLdsW, 4>(L, centre, inv_depth);
+        // the fast path assumes NaN-free distances: the body hostile frames (and RTNE storage, inf samples) run has it off
+        const float2v out = accumulate_terms<EXH, 4 * kRenLdsW, 4, MEAO_REN_FASTPATH && DIV == DIV_EXACT_RCP>(L, centre, inv_depth);
 
         typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
         const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
@@ -546,10 +586,11 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     }
 }
 
+// 128 x 32 tiles: 40 KB window, 4 workgroups of 8 waves per CU = 8 waves per SIMD (<= 64 VGPRs).
 template <int AOFMT, bool RTNE, int DIV, bool EXH>
-__global__ __launch_bounds__(kThreads) void render_kernel(const RenderArgs a)
+__global__ __launch_bounds__(ren_tile_w(EXH) * 4, EXH ? 1 : 8) void render_kernel(const RenderArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * kRenLdsW];
+    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(EXH) + 2 * kRenApron)];
     const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
     if constexpr (DIV == DIV_EXACT_RCP) {
         if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
@@ -578,7 +619,7 @@ __device__ __forceinline__ void render_wide_tile(const RenderArgs &a, float *til
         if (k < a.num_levels && b >= a.level[k].block_begin) lv = k;
     const RenderLevelArgs &L = a.level[lv];
     b -= L.block_begin;
-    const int X0 = (b % L.tiles_x) * kRenTileW, Y0 = (b / L.tiles_x) * kRenTileH;
+    const int X0 = (b % L.tiles_x) * kWideTileW, Y0 = (b / L.tiles_x) * kRenTileH;
     const int lw = L.lw, lh = L.lh;
     const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, frame);
 
@@ -602,7 +643,7 @@ __device__ __forceinline__ void render_wide_tile(const RenderArgs &a, float *til
         const float *centre = &tile[(ly + kWideApron) * kWideLdsW + 2 * txl + kWideApron];
         const float2v c = *reinterpret_cast<const float2v *>(centre);
         const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-        const float2v out = accumulate_terms<EXH, 2 * kWideLdsW, 2>(L, centre, inv_depth);
+        const float2v out = accumulate_terms<EXH, 2 * kWideLdsW, 2, false>(L, centre, inv_depth);
 
         typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
         const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
@@ -759,6 +800,37 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const ao_t *__restrict__ lo_ao2 = a.lo_ao2 ? frame_ptr(static_cast<const ao_t *>(a.lo_ao2), a.frame_stride, frame) : nullptr;
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
 
+#if MEAO_UPS_HOIST
+    // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
+    // are issued first, so that their latency hides behind the prefetch and blur phases.
+    constexpr int kPasses = kTileH / 32;
+    ushort4v hoist_hd16[kPasses][2];
+    float4v hoist_hd32[kPasses][2];
+    typename AO::type4 hoist_ha[kPasses][2];
+    const bool hoist_ok = a.vec_ok != 0;
+    if (hoist_ok) {
+        const int htx = threadIdx.x & 15, hhx0 = HX0 + 4 * htx;
+#pragma unroll
+        for (int pass = 0; pass < kPasses; ++pass)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int hy = HY0 + 2 * ((threadIdx.x >> 4) + 16 * pass) + f;
+                if (hhx0 < hw && hy < hh) {
+                    const size_t hrow = static_cast<size_t>(hy) * hw + hhx0;
+                    if constexpr (FINAL) {
+                        hoist_hd16[pass][f] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(
+                            frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow));
+                    } else {
+                        hoist_hd32[pass][f] = *reinterpret_cast<const float4v *>(
+                            frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow);
+                        hoist_ha[pass][f] = *reinterpret_cast<const typename AO::type4 *>(
+                            frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow);
+                    }
+                }
+            }
+    }
+#endif
+
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
     // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
     const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
@@ -846,7 +918,11 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const int tx = threadIdx.x & 15;
     const int hx0 = HX0 + 4 * tx;
     if (hx0 >= hw) return;
+#if MEAO_UPS_HOIST
+#pragma unroll       // the hoisted operands live in registers: static indices
+#else
 #pragma unroll 1
+#endif
     for (int pass = 0; pass < kTileH / 32; ++pass) {
         const int ty = (threadIdx.x >> 4) + 16 * pass;
         const int hy0 = HY0 + 2 * ty;
@@ -872,7 +948,11 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             if constexpr (FINAL) {
                 const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
                 if (vec_ok) {
+#if MEAO_UPS_HOIST
+                    const ushort4v q = hoist_hd16[pass][f];
+#else
                     const ushort4v q = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(p));   // read once
+#endif
                     hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
                     hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
                 } else {
@@ -883,9 +963,14 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
                 const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
                 if (vec_ok) {
+#if MEAO_UPS_HOIST
+                    const float4v d4 = hoist_hd32[pass][f];
+                    const typename AO::type4 a4 = hoist_ha[pass][f];
+#else
                     const float4v d4 = *reinterpret_cast<const float4v *>(p);
-                    hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
                     const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(q);
+#endif
+                    hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
                     ha[0] = AO::decode(a4.x); ha[1] = AO::decode(a4.y);
                     ha[2] = AO::decode(a4.z); ha[3] = AO::decode(a4.w);
                 } else {
@@ -959,13 +1044,16 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsamp
                                                                                        const DownsampleArgs d)
 {
     __shared__ __attribute__((aligned(16))) float smem[UpsLds<true>::kFloats];
-    const int ds_tiles = d.tiles_x * d.tiles_y;
-    const bool vec = d.vec_ok != 0;
-    for (int f = blockIdx.z; f < d.frames; f += gridDim.z)
-        for (int t = blockIdx.x; t < ds_tiles; t += gridDim.x) {
-            if (vec) downsample_tile<RTNE, true, DIV>(d, t, f);
-            else downsample_tile<RTNE, false, DIV>(d, t, f);
-        }
+    auto carried_downsample = [&]() {
+        const int ds_tiles = d.tiles_x * d.tiles_y;
+        const bool vec = d.vec_ok != 0;
+        for (int f = blockIdx.z; f < d.frames; f += gridDim.z)
+            for (int t = blockIdx.x; t < ds_tiles; t += gridDim.x) {
+                if (vec) downsample_tile<RTNE, true, DIV>(d, t, f);
+                else downsample_tile<RTNE, false, DIV>(d, t, f);
+            }
+    };
+    carried_downsample();
     upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
 
@@ -1196,7 +1284,7 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
 template <bool WIDE, int AOFMT, bool RTNE, int DIV>
 static void launch_render_t(const RenderArgs &a, dim3 grid, hipStream_t s)
 {
-    const dim3 block(kThreads);
+    const dim3 block(WIDE ? kThreads : ren_tile_w(a.exhaustive != 0) * 4);
     if constexpr (WIDE) {
         if (a.exhaustive) render_wide_kernel<AOFMT, RTNE, DIV, true><<<grid, block, 0, s>>>(a);
         else render_wide_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);

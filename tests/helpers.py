@@ -61,3 +61,49 @@ def checksum(arr: np.ndarray) -> int:
     with np.errstate(over="ignore"):
         mixed = (w ^ (idx * np.uint64(0x9E3779B97F4A7C15))) * np.uint64(0x100000001B3)
         return int(np.bitwise_xor.reduce(mixed) ^ np.uint64(len(b)))
+
+
+# ---- hostile depth inputs (tests/test_hostile_depth.py, tests/fuzz_gpu.py)
+
+def nan_aware_equal(got, want):
+    if got.dtype == np.float32:
+        g, w = got.view(np.uint32), want.view(np.uint32)
+        gn = (g & 0x7fffffff) > 0x7f800000
+        wn = (w & 0x7fffffff) > 0x7f800000
+    elif got.dtype == np.uint16:      # f16 bit patterns (depth mips, fp16 AO)
+        g, w = got, want
+        gn = (g & 0x7fff) > 0x7c00
+        wn = (w & 0x7fff) > 0x7c00
+    else:
+        return np.array_equal(got, want), got != want
+    bad = ~((g == w) | (gn & wn))
+    return not bad.any(), bad
+
+
+def hostile_frame(w, h, seed, cam=synth.DEFAULT_CAMERA, density=0.01, kinds=None):
+    """S2 frame with hostile texels sprinkled in (isolated ones and small blocks)."""
+    rng = np.random.default_rng(seed)
+    d = synth.make("S2", w, h, seed=seed).copy()
+    fpn = np.float32(cam.far) / np.float32(cam.near)
+    zp0 = (fpn - np.float32(1)) if cam.reversed_z else (np.float32(1) - fpn)
+    zp1 = np.float32(1) if cam.reversed_z else fpn
+    zero_den = np.float32(-zp1 / zp0)          # ZBufferParams.x * d + ZBufferParams.y == 0 (or nearly)
+    values = {
+        "nan": np.float32(np.nan), "pinf": np.float32(np.inf), "ninf": np.float32(-np.inf),
+        "neg": np.float32(-0.25), "big": np.float32(7.5), "huge": np.float32(3e38), "nhuge": np.float32(-3e38),
+        "denorm": np.float32(1e-41), "negzero": np.float32(-0.0), "zero_den": zero_den,
+        "tiny_den": np.nextafter(zero_den, np.float32(0), dtype=np.float32), "one": np.float32(1.0),
+        "zero": np.float32(0.0),
+    }
+    names = list(values) if kinds is None else list(kinds)
+    n = max(1, int(w * h * density))
+    ys, xs = rng.integers(0, h, n), rng.integers(0, w, n)
+    for i in range(n):
+        v = values[names[i % len(names)]]
+        if i % 7 == 0:
+            d[ys[i]:ys[i] + 3, xs[i]:xs[i] + 5] = v
+        else:
+            d[ys[i], xs[i]] = v
+    return d
+
+

@@ -283,3 +283,156 @@ def test_pipelined_downsample(oracle, variant, w, h, batch):
             assert np.array_equal(outs[f], oracle.run(small[f], s3, result_only=True)["result"]), f
     finally:
         ao.close()
+
+
+# ---- round 2: contract enforcement, robustness of the boundary ------------------------------------
+
+@pytest.mark.parametrize("launch_mode", [L.LAUNCH_DIRECT, L.LAUNCH_GRAPH])
+@pytest.mark.parametrize("w,h,batch", [(320, 180, 2), (203, 117, 1), (640, 360, 3)])
+def test_concurrent_levels_match_the_single_stream_order(oracle, w, h, batch, launch_mode):
+    """cfg.concurrent_levels: the coarse chain on the context's second stream (fork / join) produces the
+    same buffers as the reference's launch order, also when captured into a graph and replayed."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = H.settings(oracle, w, h)
+    frames = [synth.make("S2", w, h, seed=40 + f) for f in range(batch)]
+    want = [oracle.run(f, s) for f in frames]
+    ao = H.component(s, max_batch=batch, concurrent_levels=True, launch_mode=launch_mode)
+    try:
+        dd = [torch.from_numpy(f).to(dev) for f in frames]
+        out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in frames]
+        for _ in range(3):       # capture, replay, replay
+            for t in out:
+                t.zero_()
+            ao.execute_device([t.data_ptr() for t in dd], [t.data_ptr() for t in out], torch.cuda.current_stream(dev).cuda_stream)
+            torch.cuda.synchronize(dev)
+            for f in range(batch):
+                assert np.array_equal(out[f].cpu().numpy(), want[f]["result"]), f
+        for f in range(batch):
+            for i in H.valid_debug_ids(4):
+                assert np.array_equal(ao.debug_buffer(i, f), want[f][H.NAMES[i]]), (f, H.NAMES[i])
+    finally:
+        ao.close()
+
+
+def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
+    """The pipelining contract is enforced: a consumer on a different stream than the carrying execute
+    runs its own downsample pass (and is still correct); the same stream consumes the prefetched set."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h = 256, 128
+    s = H.settings(oracle, w, h)
+    a_frames = [synth.make("S2", w, h, seed=60 + f) for f in range(2)]
+    b_frames = [synth.make("S2", w, h, seed=70 + f) for f in range(2)]
+    want_b = [oracle.run(f, s, result_only=True)["result"] for f in b_frames]
+    da = [torch.from_numpy(f).to(dev) for f in a_frames]
+    db = [torch.from_numpy(f).to(dev) for f in b_frames]
+    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    ao = H.component(s, max_batch=2, pipelined=True)
+    try:
+        ao.set_profiling(True)
+        for consumer in (s2, s1):                      # other stream first, then the carrying stream
+            ao.prefetch_device([t.data_ptr() for t in db])
+            ao.execute_device([t.data_ptr() for t in da], [t.data_ptr() for t in out], s1.cuda_stream)
+            s1.synchronize()                           # (makes the cross-stream use legal for the test itself)
+            ao.pass_times_ms()                         # fold
+            ao.set_profiling(True)                     # restart the window
+            ao.execute_device([t.data_ptr() for t in db], [t.data_ptr() for t in out], consumer.cuda_stream)
+            consumer.synchronize()
+            ms, n = ao.pass_times_ms()
+            ran_own_downsample = ms[L.PASS_NAMES.index("downsample")] > 0
+            assert ran_own_downsample == (consumer is s2)
+            for f in range(2):
+                assert np.array_equal(out[f].cpu().numpy(), want_b[f]), (f, consumer is s2)
+            ao.set_profiling(True)
+    finally:
+        ao.close()
+
+
+def test_graph_replay_after_prefetched_batch_reads_the_right_downsample_set(oracle):
+    """ADVICE r1: a direct pipelined call leaves ds_cur = 1; a later graph replay writes set 0 and the
+    debug buffers must come from set 0."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h = 192, 96
+    s = H.settings(oracle, w, h)
+    f0, f1 = synth.make("S2", w, h, seed=81), synth.make("S1", w, h)
+    want0 = oracle.run(f0, s)
+    d0, d1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
+    out = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ao = H.component(s, max_batch=1, launch_mode=L.LAUNCH_GRAPH, pipelined=True)
+    try:
+        ao.execute_device([d0.data_ptr()], [out.data_ptr()], st)       # captured (set 0)
+        ao.prefetch_device([d1.data_ptr()])
+        ao.execute_device([d0.data_ptr()], [out.data_ptr()], st)       # direct: carries d1's downsample into set 1
+        ao.execute_device([d1.data_ptr()], [out.data_ptr()], st)       # direct: consumes set 1 -> ds_cur = 1
+        ao.execute_device([d0.data_ptr()], [out.data_ptr()], st)       # graph replay -> set 0
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(out.cpu().numpy(), want0["result"])
+        for i in (1, 2, 5, 6, 9):
+            assert np.array_equal(ao.debug_buffer(i), want0[H.NAMES[i]]), H.NAMES[i]
+    finally:
+        ao.close()
+
+
+def test_failed_resize_leaves_the_context_usable(oracle):
+    """meao_resize that cannot allocate (32768 x 32768 x 64 slots > 288 GB) returns OUT_OF_MEMORY and the
+    context keeps its size and buffers (VERDICT r1 weak #8)."""
+    w, h = 160, 90
+    s = H.settings(oracle, w, h)
+    depth = synth.make("S2", w, h, seed=5)
+    want = oracle.run(depth, s, result_only=True)["result"]
+    ao = H.component(s, max_batch=64)
+    try:
+        assert np.array_equal(ao.render(depth), want)
+        with pytest.raises(L.MeaoError) as e:
+            ao.resize(32768, 32768)
+        assert e.value.status == L.ERR_OUT_OF_MEMORY
+        assert (ao.width, ao.height) == (w, h)
+        assert np.array_equal(ao.render(depth), want)
+        ao.resize(96, 64)                               # a resize that fits still works afterwards
+        d2 = synth.make("S1", 96, 64)
+        assert np.array_equal(ao.render(d2), oracle.run(d2, H.settings(oracle, 96, 64), result_only=True)["result"])
+    finally:
+        ao.close()
+
+
+@pytest.mark.parametrize("depth_off,out_off", [(4, 0), (0, 1), (8, 2), (0, 0)])
+def test_unaligned_device_pointers_take_the_scalar_paths(oracle, depth_off, out_off):
+    """Caller pointers that are not 4-texel aligned (include/meao.h: no alignment required)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h = 256, 96                                      # width % 4 == 0: the vector variants would be chosen
+    s = H.settings(oracle, w, h)
+    depth = synth.make("S2", w, h, seed=17)
+    want = oracle.run(depth, s, result_only=True)["result"]
+    raw = torch.zeros(w * h * 4 + 64, dtype=torch.uint8, device=dev)
+    raw[depth_off:depth_off + w * h * 4] = torch.from_numpy(depth.view(np.uint8).ravel().copy()).to(dev)
+    out = torch.zeros(w * h + 64, dtype=torch.uint8, device=dev)
+    ao = H.component(s)
+    try:
+        ao.execute_device([raw.data_ptr() + depth_off], [out.data_ptr() + out_off])
+        ao.synchronize()
+        got = out[out_off:out_off + w * h].cpu().numpy().reshape(h, w)
+        assert np.array_equal(got, want)
+        assert not out[out_off + w * h:].any() and not out[:out_off].any()     # nothing written outside
+    finally:
+        ao.close()
+
+
+def test_tracing_ranges_can_be_switched_on(oracle):
+    w, h = 96, 64
+    s = H.settings(oracle, w, h)
+    depth = synth.make("S1", w, h)
+    ao = H.component(s)
+    try:
+        try:
+            ao.set_tracing(True)
+        except L.MeaoError as e:
+            assert e.status == L.ERR_UNSUPPORTED        # no libroctx64.so on this box
+        assert np.array_equal(ao.render(depth), oracle.run(depth, s, result_only=True)["result"])
+        ao.set_tracing(False)
+    finally:
+        ao.close()
