@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -232,7 +233,11 @@ int reallocate(meao_ctx *ctx, const meao_config &cfg, bool two_ds_sets)
     update_plan(ctx);
     layout_slot(ctx);
     char *fresh = nullptr;
-    const hipError_t e = hipMalloc(reinterpret_cast<void **>(&fresh), ctx->slot_bytes * ctx->cfg.max_batch);
+    // fault injection for tests (tests/test_gpu_more.py): MEAO_DEBUG_FAIL_ALLOC=1 makes this allocation fail
+    const char *inject = std::getenv("MEAO_DEBUG_FAIL_ALLOC");
+    const hipError_t e = (inject && inject[0] == '1')
+                             ? hipErrorOutOfMemory
+                             : hipMalloc(reinterpret_cast<void **>(&fresh), ctx->slot_bytes * ctx->cfg.max_batch);
     if (e != hipSuccess) {
         ctx->cfg = old_cfg;
         ctx->two_ds_sets = old_two;
