@@ -380,16 +380,21 @@ def main() -> int:
     # hipGraphLaunch per call (MEAO_LAUNCH_GRAPH); back-to-back calls, and call + wait per frame
     latency_ms, single = None, None
     if not args.skip_latency:
-        g = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=1,
-                             near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
-                             reversed_z=cam.reversed_z, hq_levels=args.hq_levels,
-                             sample_set=_lib.SAMPLES_EXHAUSTIVE if args.exhaustive else _lib.SAMPLES_CHECKER,
-                             numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT,
-                             launch_mode=_lib.LAUNCH_GRAPH)
-        g.intensity = intensity
+        def one_frame_ctx(**kw):
+            c = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=1,
+                                 near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
+                                 reversed_z=cam.reversed_z, hq_levels=args.hq_levels,
+                                 sample_set=_lib.SAMPLES_EXHAUSTIVE if args.exhaustive else _lib.SAMPLES_CHECKER,
+                                 numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT, **kw)
+            c.intensity = intensity
+            return c
         lat_iters = 50
         single = {}
-        for name, c in (("direct", ao), ("graph", g)):
+        variants = (("direct", {}), ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}),
+                    ("direct_concurrent_levels", {"concurrent_levels": True}),
+                    ("graph_concurrent_levels", {"launch_mode": _lib.LAUNCH_GRAPH, "concurrent_levels": True}))
+        for name, kw in variants:
+            c = one_frame_ctx(**kw)
             for sync_each in (False, True):
                 for _ in range(3):
                     c.execute_device(dptr[:1], optr[:1], stream)
@@ -402,7 +407,7 @@ def main() -> int:
                 torch.cuda.synchronize(dev)
                 single[name + ("_call_and_wait_ms" if sync_each else "_back_to_back_ms")] = \
                     round((time.perf_counter() - t0) / lat_iters * 1e3, 4)
-        g.close()
+            c.close()
         latency_ms = single["direct_back_to_back_ms"]
 
     if rank == 0:

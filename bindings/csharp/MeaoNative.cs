@@ -136,6 +136,18 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_get_pass_times(IntPtr ctx, [Out] float[] ms7, out int samples);
         [DllImport(Lib)] public static extern int meao_selftest(IntPtr ctx, int which, out ulong mismatches);
         [DllImport(Lib)] public static extern int meao_set_tracing(IntPtr ctx, int enable);
+
+        // multi-GPU pool: frame f of a batch runs on member f mod G (one context + stream per device)
+        [DllImport(Lib)] public static extern int meao_pool_create(ref MeaoConfig cfg, int[] devices, int num_devices, out IntPtr pool);
+        [DllImport(Lib)] public static extern int meao_pool_destroy(IntPtr pool);
+        [DllImport(Lib)] public static extern int meao_pool_size(IntPtr pool);
+        [DllImport(Lib)] public static extern IntPtr meao_pool_context(IntPtr pool, int member);
+        [DllImport(Lib)] public static extern int meao_pool_device_of_frame(IntPtr pool, int frame);
+        [DllImport(Lib)] public static extern IntPtr meao_pool_last_error(IntPtr pool);
+        [DllImport(Lib)] public static extern int meao_pool_set_params(IntPtr pool, ref MeaoParams p);
+        [DllImport(Lib)] public static extern int meao_pool_execute_batch(IntPtr pool, int n, IntPtr[] depth, int depth_loc, IntPtr[] ao_out, int out_loc);
+        [DllImport(Lib)] public static extern int meao_pool_gather_to_device(IntPtr pool, int n, IntPtr[] ao_src, IntPtr[] dst, int dst_device);
+        [DllImport(Lib)] public static extern int meao_pool_synchronize(IntPtr pool);
         [DllImport(Lib)] public static extern int meao_debug_view(IntPtr ctx, int frame, int debug_id, IntPtr dst, int out_loc, IntPtr stream);
         [DllImport(Lib)] public static extern int meao_composite(IntPtr ctx, int mode, IntPtr ao, IntPtr color_rgba16f, IntPtr gbuffer0_rgba8, int loc, IntPtr stream);
     }

@@ -311,6 +311,38 @@ MEAO_API int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, voi
 MEAO_API int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable);
 MEAO_API int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *out_samples);
 
+/* ---- multi-GPU: a pool of contexts, one per device, driven by one host thread -------------------
+ * The path shards across independent frames only (the reference keeps no temporal state,
+ * AO.cs:291-308): frame f of a batch goes to member f mod G, every member owns a complete context
+ * and a stream on its device, there is no data-path exchange (SURVEY.md 8e / DESIGN.md 7).  This is
+ * what an in-process host (the C# component) binds; bench.py's one-process-per-GPU launch over
+ * torch.distributed / RCCL is the other way to the same partition.
+ * devices: num_devices HIP ordinals (repeats allowed: several members on one device), or NULL for
+ * 0..num_devices-1 modulo the visible device count.  cfg.device is ignored; cfg.max_batch is per member. */
+typedef struct meao_pool meao_pool;
+MEAO_API int32_t meao_pool_create(const meao_config *cfg, const int32_t *devices, int32_t num_devices,
+                                  meao_pool **out_pool);
+MEAO_API int32_t meao_pool_destroy(meao_pool *pool);
+MEAO_API int32_t meao_pool_size(const meao_pool *pool);
+/* Member context (owned by the pool), e.g. for meao_get_intermediate / meao_set_profiling; NULL if out of range. */
+MEAO_API meao_ctx *meao_pool_context(meao_pool *pool, int32_t member);
+/* HIP ordinal that processes frame `frame` of a batch (= where DEVICE pointers of that frame must live); -1 on error. */
+MEAO_API int32_t meao_pool_device_of_frame(const meao_pool *pool, int32_t frame);
+MEAO_API const char *meao_pool_last_error(const meao_pool *pool);
+/* meao_set_params on every member. */
+MEAO_API int32_t meao_pool_set_params(meao_pool *pool, const meao_params *p);
+/* n <= max_batch * members frames; frame f runs on member f mod G, each member's share as one batched
+ * launch sequence on its own stream.  DEVICE pointers of frame f must be resident on
+ * meao_pool_device_of_frame(f); the call is then asynchronous (meao_pool_synchronize).  HOST pointers
+ * are staged per member and the call returns after completion. */
+MEAO_API int32_t meao_pool_execute_batch(meao_pool *pool, int32_t n, const void *const *depth, int32_t depth_loc,
+                                         void *const *ao_out, int32_t out_loc);
+/* Copies the n DEVICE results ao_src[f] (on their owning devices) to dst[f] on dst_device with
+ * hipMemcpyPeerAsync (xGMI), each on its producer's stream, i.e. ordered behind the kernels that wrote it. */
+MEAO_API int32_t meao_pool_gather_to_device(meao_pool *pool, int32_t n, const void *const *ao_src,
+                                            void *const *dst, int32_t dst_device);
+MEAO_API int32_t meao_pool_synchronize(meao_pool *pool);
+
 /* roctx ranges ("meao:downsample", "meao:render", "meao:upsample_L1_to_L0", ...) around the launches
  * of every pass, so that rocprofv3 --marker-trace output is self-describing even where passes are
  * fused.  Off by default; libroctx64.so is loaded on first use (MEAO_ERR_UNSUPPORTED if absent). */

@@ -9,11 +9,11 @@ using the hot path without the built library raises ImportError (no CPU fallback
 from . import synth  # noqa: F401
 from .sharding import frames_for_rank  # noqa: F401
 
-__all__ = ["AmbientOcclusion", "synth", "frames_for_rank"]
+__all__ = ["AmbientOcclusion", "AmbientOcclusionPool", "synth", "frames_for_rank"]
 
 
 def __getattr__(name):
-    if name == "AmbientOcclusion":
-        from .ambient_occlusion import AmbientOcclusion
-        return AmbientOcclusion
+    if name in ("AmbientOcclusion", "AmbientOcclusionPool"):
+        from . import ambient_occlusion
+        return getattr(ambient_occlusion, name)
     raise AttributeError(name)

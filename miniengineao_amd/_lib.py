@@ -111,6 +111,17 @@ SIGNATURES = {
     "meao_get_pass_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float * NUM_PASSES), C.POINTER(C.c_int32)]),
     "meao_selftest": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "meao_set_tracing": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "meao_pool_create": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
+    "meao_pool_destroy": (C.c_int32, [C.c_void_p]),
+    "meao_pool_size": (C.c_int32, [C.c_void_p]),
+    "meao_pool_context": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "meao_pool_device_of_frame": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "meao_pool_last_error": (C.c_char_p, [C.c_void_p]),
+    "meao_pool_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
+    "meao_pool_execute_batch": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                            C.POINTER(C.c_void_p), C.c_int32]),
+    "meao_pool_gather_to_device": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32]),
+    "meao_pool_synchronize": (C.c_int32, [C.c_void_p]),
     "meao_debug_view": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "meao_composite": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }

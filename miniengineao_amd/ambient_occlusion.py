@@ -241,3 +241,77 @@ class AmbientOcclusion:
             self.close()
         except Exception:
             pass
+
+
+class AmbientOcclusionPool:
+    """One context per device behind the C ABI's meao_pool_*: frame f of a batch runs on member
+    f mod G, one host thread, no data-path exchange.  ``devices`` may repeat an ordinal
+    (several members on one GPU)."""
+
+    def __init__(self, width: int, height: int, devices: Sequence[int], *, max_batch: int = 1,
+                 ao_format: int = L.AO_R8, near_clip: float = 0.3, far_clip: float = 1000.0,
+                 projection00: Optional[float] = None, reversed_z: bool = True, intensity: float = 1.0,
+                 pipelined: bool = False):
+        self._lib = L.load()
+        cfg = L.Config()
+        self._lib.meao_default_config(C.byref(cfg))
+        cfg.width, cfg.height, cfg.max_batch, cfg.ao_format = width, height, max_batch, ao_format
+        cfg.pipelined = 1 if pipelined else 0
+        self._cfg = cfg
+        self.devices = list(devices)
+        self._pool = C.c_void_p()
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        status = self._lib.meao_pool_create(C.byref(cfg), arr, len(self.devices), C.byref(self._pool))
+        if status != L.OK:
+            raise L.MeaoError(status, self._lib.meao_pool_last_error(None).decode())
+        prm = L.Params()
+        self._lib.meao_default_params(C.byref(prm))
+        prm.near_clip, prm.far_clip, prm.reversed_z, prm.intensity = near_clip, far_clip, 1 if reversed_z else 0, intensity
+        if projection00 is not None:
+            prm.proj00 = projection00
+        self._check(self._lib.meao_pool_set_params(self._pool, C.byref(prm)))
+
+    def _check(self, status: int) -> None:
+        if status != L.OK:
+            raise L.MeaoError(status, self._lib.meao_pool_last_error(self._pool).decode())
+
+    size = property(lambda s: s._lib.meao_pool_size(s._pool))
+
+    def device_of_frame(self, frame: int) -> int:
+        return self._lib.meao_pool_device_of_frame(self._pool, frame)
+
+    def render_batch(self, depths: Sequence[np.ndarray]) -> list:
+        """Host arrays in and out."""
+        n = len(depths)
+        ins = [np.ascontiguousarray(d, dtype=np.float32) for d in depths]
+        dt = np.uint8 if self._cfg.ao_format == L.AO_R8 else np.uint16
+        outs = [np.empty((self._cfg.height, self._cfg.width), dt) for _ in range(n)]
+        pin = (C.c_void_p * n)(*[d.ctypes.data for d in ins])
+        pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        self._check(self._lib.meao_pool_execute_batch(self._pool, n, pin, L.MEM_HOST, pout, L.MEM_HOST))
+        return outs
+
+    def execute_device(self, depth_ptrs: Sequence[int], out_ptrs: Sequence[int]) -> None:
+        """Frame f resident on device_of_frame(f); asynchronous (synchronize())."""
+        n = len(depth_ptrs)
+        pin, pout = (C.c_void_p * n)(*depth_ptrs), (C.c_void_p * n)(*out_ptrs)
+        self._check(self._lib.meao_pool_execute_batch(self._pool, n, pin, L.MEM_DEVICE, pout, L.MEM_DEVICE))
+
+    def gather_to_device(self, src_ptrs: Sequence[int], dst_ptrs: Sequence[int], dst_device: int) -> None:
+        n = len(src_ptrs)
+        self._check(self._lib.meao_pool_gather_to_device(self._pool, n, (C.c_void_p * n)(*src_ptrs),
+                                                         (C.c_void_p * n)(*dst_ptrs), dst_device))
+
+    def synchronize(self) -> None:
+        self._check(self._lib.meao_pool_synchronize(self._pool))
+
+    def close(self) -> None:
+        if self._pool:
+            self._lib.meao_pool_destroy(self._pool)
+            self._pool = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -18,7 +18,7 @@ _INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmeao_hip.so")
 
-SOURCES = ["meao_plan.cpp", "meao_api.cpp", "meao_kernels.hip"]
+SOURCES = ["meao_plan.cpp", "meao_api.cpp", "meao_pool.cpp", "meao_kernels.hip"]
 HEADERS = ["meao_plan.hpp", "meao_kernels.hpp"]
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit mad()/fma2() calls, which
