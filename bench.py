@@ -130,9 +130,6 @@ def main() -> int:
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not use meao_prefetch_batch: every step launches its own downsample pass instead of "
                          "carrying the next step's inside its last upsample kernel")
-    ap.add_argument("--concurrent", action="store_true",
-                    help="cfg.concurrent_levels = 1: render L2..L4 + the two smallest upsample passes on a second "
-                         "stream next to render L1 (A/B; measured: no gain for batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-time-ms", type=float, default=0.0,
                     help="raise --steps so that the timed region lasts at least this long (rank skew matters "
@@ -186,7 +183,7 @@ def main() -> int:
                              reversed_z=cam.reversed_z, hq_levels=args.hq_levels,
                              sample_set=_lib.SAMPLES_EXHAUSTIVE if args.exhaustive else _lib.SAMPLES_CHECKER,
                              numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT,
-                             pipelined=not args.no_pipeline, concurrent_levels=args.concurrent)
+                             pipelined=not args.no_pipeline)
         c.intensity = intensity
         ctxs.append(c)
     ao = ctxs[0]
@@ -390,9 +387,7 @@ def main() -> int:
             return c
         lat_iters = 50
         single = {}
-        variants = (("direct", {}), ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}),
-                    ("direct_concurrent_levels", {"concurrent_levels": True}),
-                    ("graph_concurrent_levels", {"launch_mode": _lib.LAUNCH_GRAPH, "concurrent_levels": True}))
+        variants = (("direct", {}), ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}))
         for name, kw in variants:
             c = one_frame_ctx(**kw)
             for sync_each in (False, True):
@@ -421,7 +416,6 @@ def main() -> int:
                        "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
                        "numerics": "FAST (raw rcp, not bit-exact)" if args.fast_numerics else "strict (bit-exact vs CPU oracle)", "sharding": f"frames x{world}",
                        "batches_in_flight": nfl,
-                       "coarse_chain": "own stream, concurrent with render L1" if args.concurrent else "same stream",
                        "downsample": "pipelined: each step's last kernel carries the next step's downsample pass "
                                      "(meao_prefetch_batch)" if pipelined else "own pass per step"},
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,

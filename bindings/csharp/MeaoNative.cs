@@ -45,7 +45,6 @@ namespace MiniEngineAO.Native
         public int sample_set;
         public int launch_mode;
         public int pipelined;
-        public int concurrent_levels;
     }
 
     [StructLayout(LayoutKind.Sequential)]

@@ -105,9 +105,7 @@ typedef enum meao_sample_set { MEAO_SAMPLES_CHECKER = 0, MEAO_SAMPLES_EXHAUSTIVE
 /* Kernel launches of one frame/batch, in stream order. */
 typedef enum meao_pass {
     MEAO_PASS_DOWNSAMPLE = 0,  /* Downsample1.main + Downsample2.main fused  (AO.cs:627-657) */
-    MEAO_PASS_RENDER = 1,      /* Render.main_interleaved, all levels (AO.cs:519-522): one grid, or -- with
-                                * cfg.concurrent_levels -- one grid for L1 and one for L2..L4 on the second
-                                * stream; the reported time is the sum of the two launches */
+    MEAO_PASS_RENDER = 1,      /* Render.main_interleaved, all levels, one grid (AO.cs:519-522) */
     MEAO_PASS_UPSAMPLE_3 = 2,  /* Upsample.main_blendout L4 -> L3             (AO.cs:528) */
     MEAO_PASS_UPSAMPLE_2 = 3,  /* Upsample.main_blendout L3 -> L2             (AO.cs:529) */
     MEAO_PASS_UPSAMPLE_1 = 4,  /* Upsample.main_blendout L2 -> L1             (AO.cs:530) */
@@ -139,12 +137,6 @@ typedef struct meao_config {
     int32_t pipelined;      /* 1: allocate the second set of downsample buffers at meao_create, so that
                              * meao_prefetch_batch never allocates or synchronises (streams of frames);
                              * 0 (default): the first meao_prefetch_batch call does it, once */
-    int32_t concurrent_levels; /* 1: with 4 levels, render L2..L4 and the two smallest upsample passes
-                             * (L4->L3, L3->L2) run on a second, context-owned stream next to render L1
-                             * (fork / join with events on the caller's stream): they only depend on each
-                             * other.  0 (default): every pass on the caller's stream, in the reference's
-                             * order.  Same results.  Measured on MI355X: no gain for batches (the GPU is
-                             * already full; 0.661 vs 0.661 ms per 16-frame step), see profiles/README.md. */
 } meao_config;
 
 /* The component's serialized properties (AO.cs:20-68; defaults there) and the camera terms

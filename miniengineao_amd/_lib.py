@@ -50,8 +50,7 @@ class Config(C.Structure):
                 ("height", C.c_int32), ("num_levels", C.c_int32), ("ao_format", C.c_int32),
                 ("f16_rounding", C.c_int32), ("numerics", C.c_int32), ("max_batch", C.c_int32),
                 ("depth_format", C.c_int32), ("hq_levels", C.c_int32), ("sample_set", C.c_int32),
-                ("launch_mode", C.c_int32), ("pipelined", C.c_int32),
-                ("concurrent_levels", C.c_int32)]
+                ("launch_mode", C.c_int32), ("pipelined", C.c_int32)]
 
 
 class Params(C.Structure):

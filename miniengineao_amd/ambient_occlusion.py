@@ -38,8 +38,7 @@ class AmbientOcclusion:
                  near_clip: float = 0.3, far_clip: float = 1000.0,
                  projection00: Optional[float] = None, reversed_z: bool = True,
                  hq_levels: int = 0, sample_set: int = L.SAMPLES_CHECKER, single_pass_stereo: bool = False,
-                 launch_mode: int = L.LAUNCH_DIRECT, pipelined: bool = False,
-                 concurrent_levels: bool = False):
+                 launch_mode: int = L.LAUNCH_DIRECT, pipelined: bool = False):
         """hq_levels / sample_set / single_pass_stereo: variants the reference's shaders and host carry
         but its command buffer never (or only in VR) uses; see include/meao.h.  ``width`` is the
         double-wide eye pair when single_pass_stereo is set (AO.cs:339)."""
@@ -54,7 +53,6 @@ class AmbientOcclusion:
         cfg.hq_levels, cfg.sample_set = hq_levels, sample_set
         cfg.launch_mode = launch_mode      # LAUNCH_GRAPH: one hipGraphLaunch per call (real-time single frames)
         cfg.pipelined = 1 if pipelined else 0   # second downsample set from the start (prefetch_device never allocates)
-        cfg.concurrent_levels = 1 if concurrent_levels else 0   # coarse chain on a second stream next to render L1
         self._cfg = cfg
         prm = L.Params()
         self._lib.meao_default_params(C.byref(prm))

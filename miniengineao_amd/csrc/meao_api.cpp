@@ -22,10 +22,7 @@ thread_local std::string g_last_error;   // for failures that have no context (m
 
 constexpr uint64_t kAlign = 256;
 constexpr int kProfileRing = 256;         // executes buffered before timings are folded
-// launch slots of one execute: the MEAO_NUM_PASSES passes + the coarse-level render launch of the
-// concurrent mode (its time is reported as part of MEAO_PASS_RENDER)
-constexpr int kSlotRenderCoarse = MEAO_NUM_PASSES;
-constexpr int kProfSlots = MEAO_NUM_PASSES + 1;
+constexpr int kProfSlots = MEAO_NUM_PASSES;   // launch slots of one execute: one start / end event pair each
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 }  // namespace
@@ -83,11 +80,6 @@ struct meao_ctx {
     };
     std::vector<CapturedBatch> graphs;
 
-    // Concurrent coarse chain (cfg.concurrent_levels): render L2..L4 and the two smallest upsample
-    // passes run on aux_stream next to render L1 on the caller's stream (fork / join with events).
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-
     // profiling: a ring of per-execute event sets (one start/end pair per launch slot); each entry
     // remembers which slots it used
     bool profiling = false;
@@ -142,7 +134,6 @@ bool config_valid(const meao_config &c, std::string *why)
     if (c.sample_set != MEAO_SAMPLES_CHECKER && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE) { *why = "unknown sample_set"; return false; }
     if (c.launch_mode != MEAO_LAUNCH_DIRECT && c.launch_mode != MEAO_LAUNCH_GRAPH) { *why = "unknown launch_mode"; return false; }
     if (c.pipelined != 0 && c.pipelined != 1) { *why = "pipelined must be 0 or 1"; return false; }
-    if (c.concurrent_levels != 0 && c.concurrent_levels != 1) { *why = "concurrent_levels must be 0 or 1"; return false; }
     return true;
 }
 
@@ -269,9 +260,8 @@ void fold_profile(meao_ctx *ctx)
             (void)hipEventSynchronize(b);
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, a, b) != hipSuccess) continue;
-            const int pass = k == kSlotRenderCoarse ? MEAO_PASS_RENDER : k;
-            ctx->pass_ms_sum[pass] += ms;
-            if (k != kSlotRenderCoarse) ++ctx->pass_samples[pass];
+            ctx->pass_ms_sum[k] += ms;
+            ++ctx->pass_samples[k];
         }
         ++ctx->executes_profiled;
     }
@@ -441,48 +431,21 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         return MEAO_OK;
     };
 
-    // Concurrent coarse chain: render L2..L4 -> upsample L4->L3 -> L3->L2 only depend on each other and
-    // are latency-bound (few workgroups, three barriers each); on a second stream they run next to
-    // render L1, which has 3/4 of the render work, instead of serialising five launches.
-    const bool concurrent = c.concurrent_levels != 0 && c.num_levels == 4 && c.hq_levels == 0 && ctx->aux_stream != nullptr;
-    if (concurrent) {
-        hipStream_t aux = ctx->aux_stream;
-        MEAO_HIP(ctx, hipEventRecord(ctx->ev_fork, stream));
-        MEAO_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
-        {
-            TraceRange tr(ctx, "meao:render_L2_L3_L4");
-            MEAO_HIP(ctx, begin(kSlotRenderCoarse, aux));
-            MEAO_HIP(ctx, launch_render(render_args(2, 4, false), c.ao_format, n, aux));
-            MEAO_HIP(ctx, end(kSlotRenderCoarse, aux));
-        }
-        {
-            TraceRange tr(ctx, "meao:render_L1");
-            MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
-            MEAO_HIP(ctx, launch_render(render_args(1, 1, false), c.ao_format, n, stream));
-            MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
-        }
-        int rc = launch_blend(3, aux);
-        if (rc == MEAO_OK) rc = launch_blend(2, aux);
+    {
+        TraceRange tr(ctx, "meao:render");
+        MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
+        MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false), c.ao_format, n, stream));
+        MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
+    }
+    if (c.hq_levels > 0) {   // Render.main (wide) on LowDepth<k> for the levels cfg.hq_levels enables, one grid
+        TraceRange tr(ctx, "meao:render_hq");
+        MEAO_HIP(ctx, begin(MEAO_PASS_RENDER_HQ, stream));
+        MEAO_HIP(ctx, launch_render_wide(render_args(1, c.num_levels, true), c.ao_format, n, stream));
+        MEAO_HIP(ctx, end(MEAO_PASS_RENDER_HQ, stream));
+    }
+    for (int hi = c.num_levels - 1; hi >= 2; --hi) {
+        const int rc = launch_blend(hi, stream);
         if (rc != MEAO_OK) return rc;
-        MEAO_HIP(ctx, hipEventRecord(ctx->ev_join, aux));
-        MEAO_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
-    } else {
-        {
-            TraceRange tr(ctx, "meao:render");
-            MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
-            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false), c.ao_format, n, stream));
-            MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
-        }
-        if (c.hq_levels > 0) {   // Render.main (wide) on LowDepth<k> for the levels cfg.hq_levels enables, one grid
-            TraceRange tr(ctx, "meao:render_hq");
-            MEAO_HIP(ctx, begin(MEAO_PASS_RENDER_HQ, stream));
-            MEAO_HIP(ctx, launch_render_wide(render_args(1, c.num_levels, true), c.ao_format, n, stream));
-            MEAO_HIP(ctx, end(MEAO_PASS_RENDER_HQ, stream));
-        }
-        for (int hi = c.num_levels - 1; hi >= 2; --hi) {
-            const int rc = launch_blend(hi, stream);
-            if (rc != MEAO_OK) return rc;
-        }
     }
     if (c.num_levels >= 2) {
         const int rc = launch_blend(1, stream);
@@ -602,7 +565,6 @@ void meao_default_config(meao_config *cfg)
     cfg->max_batch = 1;
     cfg->depth_format = MEAO_DEPTH_F32;
     cfg->pipelined = 0;
-    cfg->concurrent_levels = 0;
 }
 
 void meao_default_params(meao_params *p)
@@ -716,12 +678,6 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
         e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
         if (e != hipSuccess) rc = fail_hip(ctx, e, "hipStreamCreateWithFlags");
     }
-    if (rc == MEAO_OK && cfg->concurrent_levels) {
-        e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
-        if (e != hipSuccess) rc = fail_hip(ctx, e, "aux stream / events");
-    }
     if (rc == MEAO_OK) {
         // hostile-depth flags: 2 downsample sets x MEAO_MAX_BATCH frames, zero = never hostile (generations start at 1)
         const size_t bytes = 2 * MEAO_MAX_BATCH * sizeof(uint32_t);
@@ -752,9 +708,6 @@ int32_t meao_destroy(meao_ctx *ctx)
     if (ctx->hostile) (void)hipFree(ctx->hostile);
     if (ctx->roctx_lib) (void)dlclose(ctx->roctx_lib);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MEAO_OK;

@@ -25,7 +25,7 @@ frames = [make_frame(kind, w, h, frame_seed(0x1234ABCD, f)) for f in range(B)]
 dd = [torch.from_numpy(f).to(dev) for f in frames]
 out = [torch.empty((h, w), dtype=torch.uint8 if ao_format == _lib.AO_R8 else torch.int16, device=dev) for _ in range(B)]
 ao = AmbientOcclusion(w, h, num_levels=4, ao_format=ao_format, max_batch=B, near_clip=cam.near, far_clip=cam.far,
-                      projection00=cam.proj00(w, h), reversed_z=cam.reversed_z, pipelined=a.pipeline, concurrent_levels=False)
+                      projection00=cam.proj00(w, h), reversed_z=cam.reversed_z, pipelined=a.pipeline)
 ao.intensity = intensity
 dp, op = [t.data_ptr() for t in dd], [t.data_ptr() for t in out]
 st = torch.cuda.current_stream(dev).cuda_stream

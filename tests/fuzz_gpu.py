@@ -54,7 +54,7 @@ for k in range(count):
                           depth_format=depth_format, near_clip=s.near_clip, far_clip=s.far_clip,
                           projection00=s.proj00, reversed_z=reversed_z, max_batch=2, hq_levels=s.hq_levels,
                           sample_set=s.sample_set, single_pass_stereo=s.single_pass_stereo,
-                          pipelined=bool(k % 2), concurrent_levels=bool((k // 2) % 2))
+                          pipelined=bool(k % 2))
     ao.noiseFilterTolerance, ao.blurTolerance, ao.upsampleTolerance = s.noise_filter_tolerance, s.blur_tolerance, s.upsample_tolerance
     ao.thicknessModifier, ao.intensity = s.thickness_modifier, s.intensity
     outs = ao.render_batch([depth, depth])

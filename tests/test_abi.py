@@ -44,7 +44,7 @@ def test_product_library_does_not_link_the_oracle():
 
 def test_struct_layouts_match_header():
     # every member is a 4-byte scalar except meao_desc.bytes (u64, naturally aligned)
-    assert C.sizeof(L.Config) == 15 * 4 and C.sizeof(L.Params) == 11 * 4
+    assert C.sizeof(L.Config) == 14 * 4 and C.sizeof(L.Params) == 11 * 4
     assert C.sizeof(L.Desc) == 32 and L.Desc.bytes.offset == 24
     assert C.sizeof(L.RenderConstants) == 28 * 4 and C.sizeof(L.UpsampleConstants) == 8 * 4
     for struct, cname in ((L.Config, "meao_config"), (L.Params, "meao_params"), (L.Desc, "meao_desc")):

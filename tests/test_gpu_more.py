@@ -287,34 +287,6 @@ def test_pipelined_downsample(oracle, variant, w, h, batch):
 
 # ---- round 2: contract enforcement, robustness of the boundary ------------------------------------
 
-@pytest.mark.parametrize("launch_mode", [L.LAUNCH_DIRECT, L.LAUNCH_GRAPH])
-@pytest.mark.parametrize("w,h,batch", [(320, 180, 2), (203, 117, 1), (640, 360, 3)])
-def test_concurrent_levels_match_the_single_stream_order(oracle, w, h, batch, launch_mode):
-    """cfg.concurrent_levels: the coarse chain on the context's second stream (fork / join) produces the
-    same buffers as the reference's launch order, also when captured into a graph and replayed."""
-    import torch
-    dev = torch.device("cuda", 0)
-    s = H.settings(oracle, w, h)
-    frames = [synth.make("S2", w, h, seed=40 + f) for f in range(batch)]
-    want = [oracle.run(f, s) for f in frames]
-    ao = H.component(s, max_batch=batch, concurrent_levels=True, launch_mode=launch_mode)
-    try:
-        dd = [torch.from_numpy(f).to(dev) for f in frames]
-        out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in frames]
-        for _ in range(3):       # capture, replay, replay
-            for t in out:
-                t.zero_()
-            ao.execute_device([t.data_ptr() for t in dd], [t.data_ptr() for t in out], torch.cuda.current_stream(dev).cuda_stream)
-            torch.cuda.synchronize(dev)
-            for f in range(batch):
-                assert np.array_equal(out[f].cpu().numpy(), want[f]["result"]), f
-        for f in range(batch):
-            for i in H.valid_debug_ids(4):
-                assert np.array_equal(ao.debug_buffer(i, f), want[f][H.NAMES[i]]), (f, H.NAMES[i])
-    finally:
-        ao.close()
-
-
 def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
     """The pipelining contract is enforced: a consumer on a different stream than the carrying execute
     runs its own downsample pass (and is still correct); the same stream consumes the prefetched set."""

@@ -26,7 +26,7 @@ def test_pool_host_batch_matches_oracle(oracle, members):
     cam = synth.DEFAULT_CAMERA
     s = H.settings(oracle, w, h)
     frames = [synth.make("S2", w, h, seed=500 + f) for f in range(n)]
-    with AmbientOcclusionPool(w, h, [0] * members, max_batch=3, near_clip=cam.near, far_clip=cam.far,
+    with AmbientOcclusionPool(w, h, [0] * members, max_batch=5, near_clip=cam.near, far_clip=cam.far,
                               projection00=cam.proj00(w, h), reversed_z=cam.reversed_z) as pool:
         assert pool.size == members
         assert [pool.device_of_frame(f) for f in range(n)] == [0] * n
