@@ -530,25 +530,41 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     {
         const float pad = through_f16<RTNE>(L.pad_value);
         const bool vec_ok = (lw & 3) == 0;
-        constexpr int kQuadsX = kRenLdsW / 4;
-        for (int q = threadIdx.x; q < kQuadsX * kRenLdsH; q += kRenThreads) {
+        constexpr int kQuadsX = kRenLdsW / 4, kRounds = kQuadsX * kRenLdsH / kRenThreads;
+        static_assert(kQuadsX * kRenLdsH % kRenThreads == 0, "every thread fills the same number of quads");
+        // Phase 1: all 16-byte loads of this thread's quads are issued back to back (the plain loop
+        // waited for each load before issuing the next: five dependent memory latencies per tile);
+        // quads that touch the level's border take the scalar path in phase 2.
+        float4v raw[kRounds];
+        int row_at[kRounds];      // index of the first texel of the quad's row segment, or -1 = all padding
+        bool whole[kRounds];
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int q = threadIdx.x + r * kRenThreads;
             const int qx = q % kQuadsX, qy = q / kQuadsX;
             const int px0 = clampi((X0 >> 2) - (kRenApron >> 2) + qx, 0, L.sw - 1) * 4;
             const int vy = Y0 - kRenApron + qy;
             const int py = clampi(vy >> 2, 0, L.sh - 1) * 4 + (vy & 3);
+            row_at[r] = py < lh ? py * lw + px0 : -1;
+            whole[r] = py < lh && vec_ok && px0 + 3 < lw;
+            if (whole[r]) raw[r] = *reinterpret_cast<const float4v *>(src + row_at[r]);
+        }
+        // Phase 2: the f16 round trip the atlas store applies, then one 16-byte LDS store per quad
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int q = threadIdx.x + r * kRenThreads;
+            const int qx = q % kQuadsX, qy = q / kQuadsX;
             float4v t = {pad, pad, pad, pad};
-            if (py < lh) {
-                const float *row = src + static_cast<size_t>(py) * lw + px0;
-                if (vec_ok && px0 + 3 < lw) {
-                    const float4v r = *reinterpret_cast<const float4v *>(row);
-                    const float2v lo = through_f16_pair<RTNE>(r.x, r.y), hi = through_f16_pair<RTNE>(r.z, r.w);
-                    t = float4v{lo.x, lo.y, hi.x, hi.y};
-                } else {
-                    if (px0 + 0 < lw) t.x = through_f16<RTNE>(row[0]);
-                    if (px0 + 1 < lw) t.y = through_f16<RTNE>(row[1]);
-                    if (px0 + 2 < lw) t.z = through_f16<RTNE>(row[2]);
-                    if (px0 + 3 < lw) t.w = through_f16<RTNE>(row[3]);
-                }
+            if (whole[r]) {
+                const float2v lo = through_f16_pair<RTNE>(raw[r].x, raw[r].y), hi = through_f16_pair<RTNE>(raw[r].z, raw[r].w);
+                t = float4v{lo.x, lo.y, hi.x, hi.y};
+            } else if (row_at[r] >= 0) {
+                const float *row = src + row_at[r];
+                const int px0 = row_at[r] % lw;
+                if (px0 + 0 < lw) t.x = through_f16<RTNE>(row[0]);
+                if (px0 + 1 < lw) t.y = through_f16<RTNE>(row[1]);
+                if (px0 + 2 < lw) t.z = through_f16<RTNE>(row[2]);
+                if (px0 + 3 < lw) t.w = through_f16<RTNE>(row[3]);
             }
             *reinterpret_cast<float4v *>(&tile[qy * kRenLdsW + qx * 4]) = t;
         }
