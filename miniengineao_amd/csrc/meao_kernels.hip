@@ -697,8 +697,16 @@ struct UpsTile {
     static constexpr int kRawPitch = 40;
     static constexpr int kBlurW = kLowW + 2, kBlurH = kLowH + 2;     // blurred texels: 34 x 18|34
     static constexpr int kBlurPitch = 36;
-    static constexpr int kHRun = 4, kHSegs = (kBlurW + kHRun - 1) / kHRun;   // 9 runs of 4 per row
-    static constexpr int kVRun = (kBlurH % 3 == 0) ? 3 : 4;                  // 6 runs of 3 | 9 runs of 4 per column
+#ifndef MEAO_UPS_LONG_RUNS
+#define MEAO_UPS_LONG_RUNS 1   // A/B: -2.2 % on the full-resolution pass (220 -> 215 us per 16 frames)
+#endif
+    // Run lengths are chosen so that each blur phase is ONE round over the 256 lanes (the phases are
+    // latency-bound: a second, partly filled round costs a full LDS round trip): 64-row tiles use
+    // 6 x 38 = 228 horizontal runs of 6 and 7 x 34 = 238 vertical runs of 5 (runs of 4 / 4: 342 and 306
+    // items, two rounds each); 32-row tiles 9 x 22 = 198 runs of 4 and 6 x 34 = 204 runs of 3.
+    static constexpr bool kLong = MEAO_UPS_LONG_RUNS && TILE_H == 64;
+    static constexpr int kHRun = kLong ? 6 : 4, kHSegs = (kBlurW + kHRun - 1) / kHRun;
+    static constexpr int kVRun = kLong ? 5 : ((kBlurH % 3 == 0) ? 3 : 4);
     static constexpr int kVSegs = (kBlurH + kVRun - 1) / kVRun;
     // V-blur runs of the last segment may read (and produce) rows past the window: allocate them
     static constexpr int kVRows = kVSegs * kVRun;                                 // rows of s_vb
@@ -896,14 +904,30 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     for (int i = threadIdx.x; i < T::kHSegs * T::kRawH; i += kThreads) {
         const int r = i / T::kHSegs, c0 = (i % T::kHSegs) * T::kHRun;
         float av[T::kHRun + 4], zv[T::kHRun + 4], o[T::kHRun];
-        const float4v a0 = *reinterpret_cast<const float4v *>(&s_ao[r * T::kRawPitch + c0]);
-        const float4v a1 = *reinterpret_cast<const float4v *>(&s_ao[r * T::kRawPitch + c0 + 4]);
-        const float4v z0 = *reinterpret_cast<const float4v *>(&s_inv[r * T::kRawPitch + c0]);
-        const float4v z1 = *reinterpret_cast<const float4v *>(&s_inv[r * T::kRawPitch + c0 + 4]);
-        av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
-        zv[0] = z0.x; zv[1] = z0.y; zv[2] = z0.z; zv[3] = z0.w; zv[4] = z1.x; zv[5] = z1.y; zv[6] = z1.z; zv[7] = z1.w;
+        if constexpr (T::kHRun == 4) {
+            const float4v a0 = *reinterpret_cast<const float4v *>(&s_ao[r * T::kRawPitch + c0]);
+            const float4v a1 = *reinterpret_cast<const float4v *>(&s_ao[r * T::kRawPitch + c0 + 4]);
+            const float4v z0 = *reinterpret_cast<const float4v *>(&s_inv[r * T::kRawPitch + c0]);
+            const float4v z1 = *reinterpret_cast<const float4v *>(&s_inv[r * T::kRawPitch + c0 + 4]);
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            zv[0] = z0.x; zv[1] = z0.y; zv[2] = z0.z; zv[3] = z0.w; zv[4] = z1.x; zv[5] = z1.y; zv[6] = z1.z; zv[7] = z1.w;
+        } else {    // even run length: 8-byte aligned taps
+            static_assert(T::kHRun % 2 == 0, "runs start on even columns");
+#pragma unroll
+            for (int t = 0; t < T::kHRun + 4; t += 2) {
+                const float2v a2 = *reinterpret_cast<const float2v *>(&s_ao[r * T::kRawPitch + c0 + t]);
+                const float2v z2 = *reinterpret_cast<const float2v *>(&s_inv[r * T::kRawPitch + c0 + t]);
+                av[t] = a2.x; av[t + 1] = a2.y; zv[t] = z2.x; zv[t + 1] = z2.y;
+            }
+        }
         blur_run<T::kHRun>(bk, av, zv, o);
-        *reinterpret_cast<float4v *>(&s_hb[r * T::kBlurPitch + c0]) = float4v{o[0], o[1], o[2], o[3]};
+        if constexpr (T::kHRun == 4) {
+            *reinterpret_cast<float4v *>(&s_hb[r * T::kBlurPitch + c0]) = float4v{o[0], o[1], o[2], o[3]};
+        } else {
+#pragma unroll
+            for (int n = 0; n < T::kHRun; n += 2)
+                *reinterpret_cast<float2v *>(&s_hb[r * T::kBlurPitch + c0 + n]) = float2v{o[n], o[n + 1]};
+        }
     }
     __syncthreads();
 
