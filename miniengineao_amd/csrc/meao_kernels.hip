@@ -471,8 +471,31 @@ __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv
 // checker set REN:162-168 (slots 1,3,4,8,11,6,10), SAMPLE_EXHAUSTIVELY REN:146-157
 // (slots 0,1,2,3,4,8,11,5,6,7,9,10).  L.weight[] etc. are already in term order; L.weight[] carries
 // the 0.5 (axial, diagonal) / 0.25 (L-shaped) factor of TestSamples.
+// The per-term constants of one level, held in SGPRs for the whole tile.  (Read straight from the
+// kernel-argument struct the compiler re-issued the s_load_dword's inside the texel loop, three per
+// term, and their s_waitcnt lgkmcnt(0) also drained the LDS reads in flight.)
+template <bool EXH>
+struct TermConstants {
+    static constexpr int kTerms = EXH ? 12 : 7;
+    float inv_thickness[kTerms], front_depth[kTerms], weight[kTerms];
+    float reject_fadeoff, intensity;
+    __device__ __forceinline__ explicit TermConstants(const RenderLevelArgs &src)
+    {
+#pragma unroll
+        for (int t = 0; t < kTerms; ++t) {
+            inv_thickness[t] = src.inv_thickness[t];
+            front_depth[t] = src.front_depth[t];
+            weight[t] = src.weight[t];
+            asm volatile("" : "+s"(inv_thickness[t]), "+s"(front_depth[t]), "+s"(weight[t]));   // stay in SGPRs
+        }
+        reject_fadeoff = src.reject_fadeoff;
+        intensity = src.intensity;
+        asm volatile("" : "+s"(reject_fadeoff), "+s"(intensity));
+    }
+};
+
 template <bool EXH, int P, int Q, bool FAST>
-__device__ __forceinline__ float2v accumulate_terms(const RenderLevelArgs &L, const float *centre, float2v inv_depth)
+__device__ __forceinline__ float2v accumulate_terms(const TermConstants<EXH> &L, const float *centre, float2v inv_depth)
 {
     const float reject = L.reject_fadeoff;
     float2v ao = splat(0.0f);
@@ -574,6 +597,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     // ---- each lane: a texel pair (X, X+1) in each of the 4 iterations
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
     const bool pair_store = ((lw & 1) == 0);
+    const TermConstants<EXH> terms(L);
     // a wave covers a compact 32 x 4 block (16 lanes x 4 rows) of the tile in each of the 4 iterations
     constexpr int kBlocksX = kRenTileW / 32, kWaves = kRenThreads / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -588,7 +612,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
         const float2v c = *reinterpret_cast<const float2v *>(centre);
         const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
         // the fast path assumes NaN-free distances: the body hostile frames (and RTNE storage, inf samples) run has it off
-        const float2v out = accumulate_terms<EXH, 4 * kRenLdsW, 4, MEAO_REN_FASTPATH && DIV == DIV_EXACT_RCP>(L, centre, inv_depth);
+        const float2v out = accumulate_terms<EXH, 4 * kRenLdsW, 4, MEAO_REN_FASTPATH && DIV == DIV_EXACT_RCP>(terms, centre, inv_depth);
 
         typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
         const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
@@ -651,6 +675,7 @@ __device__ __forceinline__ void render_wide_tile(const RenderArgs &a, float *til
     if (X >= lw) return;
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
     const bool pair_store = ((lw & 1) == 0);
+    const TermConstants<EXH> terms(L);
 
 #pragma unroll 1
     for (int k = 0; k < kRenTileH / 8; ++k) {
@@ -659,7 +684,7 @@ __device__ __forceinline__ void render_wide_tile(const RenderArgs &a, float *til
         const float *centre = &tile[(ly + kWideApron) * kWideLdsW + 2 * txl + kWideApron];
         const float2v c = *reinterpret_cast<const float2v *>(centre);
         const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-        const float2v out = accumulate_terms<EXH, 2 * kWideLdsW, 2, false>(L, centre, inv_depth);
+        const float2v out = accumulate_terms<EXH, 2 * kWideLdsW, 2, false>(terms, centre, inv_depth);
 
         typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
         const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);

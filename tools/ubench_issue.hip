@@ -90,6 +90,52 @@ KERNEL_PK(k_pk_fma, "v_pk_fma_f32 %0, %0, %1, %2")
 KERNEL_PK(k_pk_mul, "v_pk_mul_f32 %0, %0, %1")
 KERNEL_PK(k_pk_add, "v_pk_add_f32 %0, %0, %1")
 
+// three DIFFERENT vector sources per instruction, rotating through 16 registers (real code reads 2-3
+// distinct VGPRs per instruction; the rows above re-read the same two operand registers)
+__global__ __launch_bounds__(256) void k_fma_three_sources(float *out, Stamp *stamps, int iters, float b, float c)
+{
+    float a[16];
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i * b + c;
+    PROLOGUE
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]), "v"(a[(i + 14) & 15]));
+    }
+    EPILOGUE
+    float s = 0; for (int i = 0; i < 16; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// the render pair mix with operands spread over 24 registers (no operand is re-read back to back)
+__global__ __launch_bounds__(256) void k_render_mix_spread(float *out, Stamp *stamps, int iters, float b, float c)
+{
+    float s[16], ir[4], acc[4];
+    for (int i = 0; i < 16; ++i) s[i] = threadIdx.x * 0.001f + i;
+    for (int i = 0; i < 4; ++i) { ir[i] = b + i * 1e-3f; acc[i] = 0.0f; }
+    const float one = 1.0f;
+    PROLOGUE
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float d1, d2, p1, p2, u1, u2, sum;
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d1) : "v"(s[4 * p]), "v"(ir[p]), "v"(c));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d2) : "v"(s[4 * p + 1]), "v"(ir[p]), "v"(c));
+            asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(p1) : "v"(d1), "v"(b));
+            asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(p2) : "v"(d2), "v"(b));
+            asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(u1) : "v"(d1), "v"(p2), "v"(one));
+            asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(u2) : "v"(d2), "v"(p1), "v"(one));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(sum) : "v"(u1), "v"(u2));
+            asm volatile("v_fma_f32 %0, -%1, %2, %3 clamp" : "=v"(acc[p]) : "v"(p1), "v"(p2), "v"(sum));
+            s[4 * p + 2] = acc[p];
+        }
+    }
+    EPILOGUE
+    out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3] + s[2] + s[6] + s[10] + s[14];
+}
+
 // dependent chain: one accumulator, every instruction waits for the previous one
 __global__ __launch_bounds__(256) void k_fma_dependent(float *out, Stamp *stamps, int iters, float b, float c)
 {
@@ -240,6 +286,8 @@ int main(int argc, char **argv)
         {"v_rcp_f32", k_rcp, 32}, {"v_cvt_pkrtz_f16_f32", k_cvt_pkrtz, 32}, {"v_cvt_f32_f16", k_cvt_f32_f16, 32},
         {"v_div_fixup_f32", k_div_fixup, 32},
         {"v_pk_fma_f32", k_pk_fma, 32}, {"v_pk_mul_f32", k_pk_mul, 32}, {"v_pk_add_f32", k_pk_add, 32},
+        {"v_fma_f32, three distinct rotating sources", k_fma_three_sources, 32},
+        {"render pair mix, operands spread over 24 regs", k_render_mix_spread, 32},
         {"v_fma_f32 dependent chain", k_fma_dependent, 32},
         {"render pair mix (8 instr / texel pair-op)", k_render_mix, 32},
         {"render pair mix, packed (10 instr / 2 texels)", k_render_mix_pk, 40},
