@@ -195,3 +195,59 @@ def test_gpu_matches_reference_shader_outputs(name):
             assert np.array_equal(ao.debug_buffer(i), fx[H.NAMES[i]]), H.NAMES[i]
     finally:
         ao.close()
+
+
+# ---- the raster passes of Blit.shader, executed from the reference's ShaderLab/Cg text -----------
+# (tests/golden/make_blit_goldens.py + oracle/shaderlab_interp.py): composite and de-tile view
+
+BLIT_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_blit_passes.npz")
+_COMPOSITE_MODES = {"multiply": 0, "ambient_only": 1, "debug": 2}      # meao_composite_mode
+
+
+@pytest.mark.parametrize("mode", sorted(_COMPOSITE_MODES))
+def test_oracle_composite_matches_the_interpreted_blit_shader(oracle, mode):
+    fx = np.load(BLIT_FIXTURE)
+    color = fx["color_in"].copy()
+    gbuf = fx["gbuffer0_in"].copy()
+    oracle.composite(fx["ao"], color, _COMPOSITE_MODES[mode], oracle.AO_R8,
+                     gbuf if mode == "ambient_only" else None)
+    assert np.array_equal(color, fx[f"color_{mode}"]), H.diff_report("color", color, fx[f"color_{mode}"])
+    assert np.array_equal(gbuf, fx[f"gbuffer0_{mode}"])
+
+
+def test_oracle_detile_view_matches_the_interpreted_blit_shader(oracle):
+    fx = np.load(BLIT_FIXTURE)
+    r = fx["detile_r"]
+    th, tw = r.shape
+    s = oracle.Settings(tw, th)
+    got = oracle.debug_view({"tiled_depth1": fx["tiled_in"]}, 6, s)
+    L = oracle.lib()
+    want = np.vectorize(lambda v: L.meao_oracle_f32_to_unorm8(float(v)), otypes=[np.uint8])(r)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/Assets/MiniEngineAO/Shaders/Blit.shader"),
+                    reason="the reference tree only exists on the build box")
+def test_blit_fixture_is_what_the_reference_text_produces_today(oracle, tmp_path, monkeypatch):
+    from tests.golden import make_blit_goldens as G
+    monkeypatch.setattr(G, "OUT", str(tmp_path / "fresh.npz"))
+    G.main()
+    fresh, kept = np.load(str(tmp_path / "fresh.npz")), np.load(BLIT_FIXTURE)
+    assert sorted(fresh.files) == sorted(kept.files)
+    for k in kept.files:
+        assert np.array_equal(fresh[k], kept[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", sorted(_COMPOSITE_MODES))
+def test_gpu_composite_matches_the_interpreted_blit_shader(mode):
+    from miniengineao_amd import AmbientOcclusion
+    fx = np.load(BLIT_FIXTURE)
+    h, w = fx["ao"].shape
+    color = fx["color_in"].copy()
+    gbuf = fx["gbuffer0_in"].copy()
+    with AmbientOcclusion(w, h) as ao:
+        ao.ambientOnly = mode == "ambient_only"
+        ao.composite(fx["ao"], color, gbuf if mode == "ambient_only" else None, debug=mode == "debug")
+    assert np.array_equal(color, fx[f"color_{mode}"])
+    assert np.array_equal(gbuf, fx[f"gbuffer0_{mode}"])
