@@ -118,6 +118,10 @@ def main() -> int:
     ap.add_argument("--composite", action="store_true",
                     help="also time the next-tier composite kernel (AO x RGBA16F frame, Blit.shader pass 2); "
                          "reported separately, never part of `value`")
+    ap.add_argument("--shaded", action="store_true",
+                    help="next tier, reported separately: 'depth in -> shaded frame out' with the composite of each "
+                         "step riding inside the next step's render kernel (meao_composite_enqueue), next to the "
+                         "same work as separate composite launches")
     ap.add_argument("--ao-format", choices=["r8", "f16"], default=None,
                     help="override the AO storage of the workload (R8 = reference, F16 = fp16 AO)")
     ap.add_argument("--fast-numerics", action="store_true",
@@ -373,6 +377,35 @@ def main() -> int:
                      "algorithmic_MB_per_frame": round(cbytes / 1e6, 2), "GBps": round(cg, 1),
                      "frac": round(cg / HBM_PEAK_GBPS, 4), "bound": "hbm"}
 
+    shaded = None
+    if args.shaded:
+        # depth in -> shaded frame out: every step = AO of B frames + composite (color.rgba *= ao) of those frames
+        colors = [torch.ones((h, w, 4), dtype=torch.float16, device=dev) for _ in range(B)]
+        cptr = [t.data_ptr() for t in colors]
+
+        def shaded_steps(pipelined_composite):
+            for _ in range(args.steps):
+                if pipelined:
+                    ao.prefetch_device(dptr)
+                ao.execute_device(dptr, optr, stream)          # carries the composite enqueued by the previous step
+                if pipelined_composite:
+                    ao.composite_enqueue_device(_lib.COMPOSITE_MULTIPLY, optr, cptr)
+                else:
+                    for f in range(B):
+                        ao.composite_device(_lib.COMPOSITE_MULTIPLY, optr[f], cptr[f], 0, stream)
+            ao.composite_flush(stream)
+        shaded = {}
+        for name, flag in (("separate_composite_launches", False), ("composite_inside_next_render", True)):
+            shaded_steps(flag)                                  # warm-up
+            fence()
+            ts = time.perf_counter()
+            shaded_steps(flag)
+            fence()
+            dt = mdist.max_over_ranks(time.perf_counter() - ts, dev)
+            shaded[name] = {"Mpixels_per_s": round(float(w) * h * B * args.steps * world / dt / 1e6, 1),
+                            "ms_per_step": round(dt / args.steps * 1e3, 4)}
+        shaded["note"] = "next tier, not part of `value`: AO + Blit.shader pass 2 on an RGBA16F frame per step"
+
     # single-frame use (one frame per call, the real-time case): one launch per pass (DIRECT) vs one
     # hipGraphLaunch per call (MEAO_LAUNCH_GRAPH); back-to-back calls, and call + wait per frame
     latency_ms, single = None, None
@@ -419,6 +452,7 @@ def main() -> int:
                        "downsample": "pipelined: each step's last kernel carries the next step's downsample pass "
                                      "(meao_prefetch_batch)" if pipelined else "own pass per step"},
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
+            "depth_in_to_shaded_frame_out": shaded,
             "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
             "world_seen_by_rccl": mdist.world_size(), "validation": validation,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),

@@ -135,6 +135,8 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_get_pass_times(IntPtr ctx, [Out] float[] ms7, out int samples);
         [DllImport(Lib)] public static extern int meao_selftest(IntPtr ctx, int which, out ulong mismatches);
         [DllImport(Lib)] public static extern int meao_set_tracing(IntPtr ctx, int enable);
+        [DllImport(Lib)] public static extern int meao_composite_enqueue(IntPtr ctx, int mode, int n, IntPtr[] ao, IntPtr[] color_rgba16f, IntPtr[] gbuffer0_rgba8);
+        [DllImport(Lib)] public static extern int meao_composite_flush(IntPtr ctx, IntPtr stream);
 
         // multi-GPU pool: frame f of a batch runs on member f mod G (one context + stream per device)
         [DllImport(Lib)] public static extern int meao_pool_create(ref MeaoConfig cfg, int[] devices, int num_devices, out IntPtr pool);

@@ -296,6 +296,20 @@ typedef enum meao_composite_mode {
 MEAO_API int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, void *color_rgba16f,
                                 void *gbuffer0_rgba8, int32_t loc, meao_stream stream);
 
+/* Pipelined composite ("depth in -> shaded frame out" for streams of frames).  The composite moves 17
+ * bytes per texel -- as many bytes as the whole AO path -- while the render pass is VALU-bound with
+ * HBM nearly idle.  meao_composite_enqueue registers the composite of n DEVICE frames (ao[f] produced
+ * by an earlier meao_execute*; same formats and modes as meao_composite); the NEXT meao_execute* on
+ * this context carries it inside its render kernel (every render workgroup first streams its share of
+ * the texel pairs), on that call's stream, i.e. ordered behind the kernels that wrote ao[f] when the
+ * same stream is used.  Results are identical to meao_composite.  One batch can wait at a time: a
+ * second enqueue, meao_resize, meao_destroy and meao_composite_flush run the waiting batch as plain
+ * composite launches (stream NULL = the stream of the last call), so nothing is ever dropped.
+ * ao[f], color[f] and gbuffer0[f] must stay valid and untouched until the carrying call has run. */
+MEAO_API int32_t meao_composite_enqueue(meao_ctx *ctx, int32_t mode, int32_t n, const void *const *ao,
+                                        void *const *color_rgba16f, void *const *gbuffer0_rgba8);
+MEAO_API int32_t meao_composite_flush(meao_ctx *ctx, meao_stream stream);
+
 /* Per-pass device timing: when enabled, meao_execute* brackets every pass with HIP events on
  * the launch stream; meao_get_pass_times averages each pass over the executes that ran it since
  * the last reset (synchronises the stream); *out_samples = executes measured.

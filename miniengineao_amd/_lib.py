@@ -110,6 +110,9 @@ SIGNATURES = {
     "meao_get_pass_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float * NUM_PASSES), C.POINTER(C.c_int32)]),
     "meao_selftest": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "meao_set_tracing": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "meao_composite_enqueue": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_void_p)]),
+    "meao_composite_flush": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "meao_pool_create": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
     "meao_pool_destroy": (C.c_int32, [C.c_void_p]),
     "meao_pool_size": (C.c_int32, [C.c_void_p]),

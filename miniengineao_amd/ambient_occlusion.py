@@ -184,6 +184,18 @@ class AmbientOcclusion:
         L.check(self._lib.meao_composite(self._ctx, mode, ao_ptr, color_ptr, gbuffer0_ptr or None, L.MEM_DEVICE,
                                          C.c_void_p(stream) if stream else None), self._ctx)
 
+    def composite_enqueue_device(self, mode: int, ao_ptrs: Sequence[int], color_ptrs: Sequence[int],
+                                 gbuffer0_ptrs: Optional[Sequence[int]] = None) -> None:
+        """Composite of device frames an earlier execute produced; rides inside the NEXT execute's render
+        kernel (meao_composite_enqueue).  composite_flush() runs whatever still waits."""
+        n = len(ao_ptrs)
+        g = (C.c_void_p * n)(*gbuffer0_ptrs) if gbuffer0_ptrs else None
+        L.check(self._lib.meao_composite_enqueue(self._ctx, mode, n, (C.c_void_p * n)(*ao_ptrs),
+                                                 (C.c_void_p * n)(*color_ptrs), g), self._ctx)
+
+    def composite_flush(self, stream: int = 0) -> None:
+        L.check(self._lib.meao_composite_flush(self._ctx, C.c_void_p(stream) if stream else None), self._ctx)
+
     # ---- observability (the _debug views, AO.cs:787-820) -------------------------------
     def debug_buffer(self, debug_id: int, frame: int = 0) -> np.ndarray:
         d = L.Desc()

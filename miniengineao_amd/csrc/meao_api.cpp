@@ -67,6 +67,9 @@ struct meao_ctx {
     // (meao_kernels.hip "Exact division"); recomputed by update_plan()
     int exact_rcp_div = 0;
 
+    // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue)
+    CompositeBatchArgs pending_comp{};
+
     const void *last_out[MEAO_MAX_BATCH] = {};   // device address of the last results (debug id 17)
     int last_frames = 0;
 
@@ -268,6 +271,21 @@ void fold_profile(meao_ctx *ctx)
     ctx->ring_fill = 0;
 }
 
+// Runs a pending composite batch as plain composite launches (one per frame) on `stream`.
+int flush_pending_composite(meao_ctx *ctx, hipStream_t stream)
+{
+    CompositeBatchArgs &pc = ctx->pending_comp;
+    const int frames = pc.frames;
+    pc.frames = 0;
+    for (int f = 0; f < frames; ++f) {
+        CompositeArgs ca{};
+        ca.ao = pc.ao[f]; ca.color = pc.color[f]; ca.gbuffer0 = pc.gbuffer0[f];
+        ca.pixels = pc.pixels; ca.mode = pc.mode;
+        MEAO_HIP(ctx, launch_composite(ca, ctx->cfg.ao_format, stream));
+    }
+    return MEAO_OK;
+}
+
 struct TraceRange {   // roctx range around one pass (no-op unless meao_set_tracing enabled it)
     meao_ctx *ctx;
     TraceRange(meao_ctx *c, const char *name) : ctx(c) { if (ctx->tracing && ctx->roctx_push) ctx->roctx_push(name); }
@@ -431,10 +449,20 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         return MEAO_OK;
     };
 
+    if (ctx->pending_comp.frames > 0 && c.sample_set == MEAO_SAMPLES_EXHAUSTIVE) {
+        const int rc = flush_pending_composite(ctx, stream);     // the 68-sample render kernel carries nothing
+        if (rc != MEAO_OK) return rc;
+    }
     {
-        TraceRange tr(ctx, "meao:render");
+        TraceRange tr(ctx, ctx->pending_comp.frames > 0 ? "meao:render+composite_of_previous_call" : "meao:render");
         MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
-        MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false), c.ao_format, n, stream));
+        if (ctx->pending_comp.frames > 0) {
+            // the composite of frames an earlier call produced streams under this (VALU-bound) kernel
+            MEAO_HIP(ctx, launch_render_with_composite(render_args(1, c.num_levels, false), ctx->pending_comp, c.ao_format, n, stream));
+            ctx->pending_comp.frames = 0;
+        } else {
+            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false), c.ao_format, n, stream));
+        }
         MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
     }
     if (c.hq_levels > 0) {   // Render.main (wide) on LowDepth<k> for the levels cfg.hq_levels enables, one grid
@@ -482,7 +510,8 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
 // if it is new.  The captured nodes are the very launches run_batch() makes.
 int submit_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream)
 {
-    if (ctx->cfg.launch_mode != MEAO_LAUNCH_GRAPH || ctx->profiling || ctx->next_n > 0 || ctx->ready_n > 0)
+    if (ctx->cfg.launch_mode != MEAO_LAUNCH_GRAPH || ctx->profiling || ctx->next_n > 0 || ctx->ready_n > 0 ||
+        ctx->pending_comp.frames > 0)
         return run_batch(ctx, n, depth_dev, out_dev, stream);   // pipelined calls differ from call to call
     hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &status) != hipSuccess || status != hipStreamCaptureStatusNone) {
@@ -701,6 +730,7 @@ int32_t meao_destroy(meao_ctx *ctx)
 {
     if (!ctx) return MEAO_OK;
     (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->pending_comp.frames > 0) (void)flush_pending_composite(ctx, ctx->last_stream);   // never dropped
     (void)hipDeviceSynchronize();
     drop_graphs(ctx);
     release_buffers(ctx);
@@ -723,6 +753,10 @@ int32_t meao_resize(meao_ctx *ctx, int32_t width, int32_t height)
     if (!config_valid(c, &why)) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_resize: " + why);
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
+    if (ctx->pending_comp.frames > 0) {        // sized for the old geometry: run it now
+        rc = flush_pending_composite(ctx, ctx->last_stream);
+        if (rc != MEAO_OK) return rc;
+    }
     MEAO_HIP(ctx, hipDeviceSynchronize());
     // on failure (e.g. out of memory) the context keeps its previous size and buffers
     return reallocate(ctx, c, ctx->two_ds_sets);
@@ -1041,6 +1075,47 @@ int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, void *color_
     MEAO_HIP(ctx, launch_composite(ca, ctx->cfg.ao_format, stream));
     ctx->last_stream = stream;
     return MEAO_OK;
+}
+
+int32_t meao_composite_enqueue(meao_ctx *ctx, int32_t mode, int32_t n, const void *const *ao, void *const *color_rgba16f,
+                               void *const *gbuffer0_rgba8)
+{
+    if (!ctx || !ao || !color_rgba16f) return MEAO_ERR_INVALID_ARGUMENT;
+    if (mode < MEAO_COMPOSITE_MULTIPLY || mode > MEAO_COMPOSITE_DEBUG) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_composite_enqueue: unknown mode");
+    if (n < 1 || n > MEAO_MAX_BATCH) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_composite_enqueue: n must be 1..MEAO_MAX_BATCH");
+    if (mode == MEAO_COMPOSITE_AMBIENT_ONLY && !gbuffer0_rgba8)
+        return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_composite_enqueue: AMBIENT_ONLY needs the GBuffer0 targets");
+    for (int f = 0; f < n; ++f)
+        if (!ao[f] || !color_rgba16f[f] || (mode == MEAO_COMPOSITE_AMBIENT_ONLY && !gbuffer0_rgba8[f]))
+            return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_composite_enqueue: null frame pointer");
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    if (ctx->pending_comp.frames > 0) {        // one batch can wait at a time: the older one runs now, in order
+        rc = flush_pending_composite(ctx, ctx->last_stream);
+        if (rc != MEAO_OK) return rc;
+    }
+    CompositeBatchArgs &pc = ctx->pending_comp;
+    for (int f = 0; f < n; ++f) {
+        pc.ao[f] = ao[f];
+        pc.color[f] = color_rgba16f[f];
+        pc.gbuffer0[f] = gbuffer0_rgba8 ? gbuffer0_rgba8[f] : nullptr;
+    }
+    pc.pixels = static_cast<int64_t>(ctx->cfg.width) * ctx->cfg.height;
+    pc.mode = mode;
+    pc.frames = n;
+    return MEAO_OK;
+}
+
+int32_t meao_composite_flush(meao_ctx *ctx, meao_stream stream_)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    if (ctx->pending_comp.frames == 0) return MEAO_OK;
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->last_stream;
+    rc = flush_pending_composite(ctx, stream);
+    if (rc == MEAO_OK) ctx->last_stream = stream;
+    return rc;
 }
 
 int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches)

@@ -1229,62 +1229,96 @@ __global__ __launch_bounds__(kThreads) void debug_view_kernel(const DebugViewArg
 
 __device__ __forceinline__ uint16_t f32_to_f16_rtne_bits(float x) { return f32_to_f16_bits<true>(x); }
 
+// Texel pair q (texels 2q, 2q+1) of one frame: one 16-byte colour load / store per lane.
 template <int AOFMT>
-__global__ __launch_bounds__(kThreads) void composite_kernel(const CompositeArgs a)
+__device__ __forceinline__ void composite_pair(const void *ao_base, void *color_base, void *gbuffer0_base, int64_t pixels,
+                                               int32_t mode, int64_t q)
 {
     typedef AoTexel<AOFMT> AO;
     typedef typename AO::type ao_t;
+    const int64_t p0 = q * 2;
+    const bool full = p0 + 1 < pixels;
+    const ao_t *ap = static_cast<const ao_t *>(ao_base) + p0;
+    float aov[2] = {1.0f, 1.0f};
+    if (full) {
+        const typename AO::type2 a2 = *reinterpret_cast<const typename AO::type2 *>(ap);
+        aov[0] = AO::decode(a2.x); aov[1] = AO::decode(a2.y);
+    } else {
+        aov[0] = AO::decode(ap[0]);
+    }
+    uint16_t c[8] = {};
+    uint16_t *cp = static_cast<uint16_t *>(color_base) + p0 * 4;
+    if (full) {
+        const uint4v raw = *reinterpret_cast<const uint4v *>(cp);
+        c[0] = raw.x & 0xffffu; c[1] = raw.x >> 16; c[2] = raw.y & 0xffffu; c[3] = raw.y >> 16;
+        c[4] = raw.z & 0xffffu; c[5] = raw.z >> 16; c[6] = raw.w & 0xffffu; c[7] = raw.w >> 16;
+    } else {
+        for (int k = 0; k < 4; ++k) c[k] = cp[k];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (p0 + e >= pixels) break;
+        const float ao = aov[e];
+        uint16_t *t = c + 4 * e;
+        if (mode == MEAO_COMPOSITE_DEBUG) {                          // pass 3: frag returns ao in every channel
+            t[0] = t[1] = t[2] = t[3] = f32_to_f16_rtne_bits(ao);
+        } else if (mode == MEAO_COMPOSITE_MULTIPLY) {                // pass 2: dst * src.a
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = f32_to_f16_rtne_bits(f16_bits_to_f32(t[k]) * ao);
+        } else {                                                     // pass 1: dst * (1 - src), src = 1 - ao
+            const float occ = 1.0f - ao;                             // Blit.shader:84
+            const float keep = 1.0f - occ;                           // OneMinusSrcColor / OneMinusSrcAlpha
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t[k] = f32_to_f16_rtne_bits(f16_bits_to_f32(t[k]) * keep);
+            uint8_t *g = static_cast<uint8_t *>(gbuffer0_base) + (p0 + e) * 4 + 3;   // GBuffer0.a = occlusion
+            *g = static_cast<uint8_t>(f32_to_unorm8(unorm8_to_f32(*g) * keep));
+        }
+    }
+    if (full) {
+        uint4v outv;
+        outv.x = c[0] | (static_cast<uint32_t>(c[1]) << 16); outv.y = c[2] | (static_cast<uint32_t>(c[3]) << 16);
+        outv.z = c[4] | (static_cast<uint32_t>(c[5]) << 16); outv.w = c[6] | (static_cast<uint32_t>(c[7]) << 16);
+        *reinterpret_cast<uint4v *>(cp) = outv;
+    } else {
+        for (int k = 0; k < 4; ++k) cp[k] = c[k];
+    }
+}
+
+template <int AOFMT>
+__global__ __launch_bounds__(kThreads) void composite_kernel(const CompositeArgs a)
+{
     // one lane = 2 texels = one 16-byte colour load/store; consecutive lanes are contiguous
     const int64_t pairs = (a.pixels + 1) / 2;
     for (int64_t q = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; q < pairs;
-         q += static_cast<int64_t>(gridDim.x) * kThreads) {
-        const int64_t p0 = q * 2;
-        const bool full = p0 + 1 < a.pixels;
-        const ao_t *ap = static_cast<const ao_t *>(a.ao) + p0;
-        float aov[2] = {1.0f, 1.0f};
-        if (full) {
-            const typename AO::type2 a2 = *reinterpret_cast<const typename AO::type2 *>(ap);
-            aov[0] = AO::decode(a2.x); aov[1] = AO::decode(a2.y);
-        } else {
-            aov[0] = AO::decode(ap[0]);
-        }
-        uint16_t c[8] = {};
-        uint16_t *cp = static_cast<uint16_t *>(a.color) + p0 * 4;
-        if (full) {
-            const uint4v raw = *reinterpret_cast<const uint4v *>(cp);
-            c[0] = raw.x & 0xffffu; c[1] = raw.x >> 16; c[2] = raw.y & 0xffffu; c[3] = raw.y >> 16;
-            c[4] = raw.z & 0xffffu; c[5] = raw.z >> 16; c[6] = raw.w & 0xffffu; c[7] = raw.w >> 16;
-        } else {
-            for (int k = 0; k < 4; ++k) c[k] = cp[k];
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (p0 + e >= a.pixels) break;
-            const float ao = aov[e];
-            uint16_t *t = c + 4 * e;
-            if (a.mode == MEAO_COMPOSITE_DEBUG) {                        // pass 3: frag returns ao in every channel
-                t[0] = t[1] = t[2] = t[3] = f32_to_f16_rtne_bits(ao);
-            } else if (a.mode == MEAO_COMPOSITE_MULTIPLY) {              // pass 2: dst * src.a
-#pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = f32_to_f16_rtne_bits(f16_bits_to_f32(t[k]) * ao);
-            } else {                                                     // pass 1: dst * (1 - src), src = 1 - ao
-                const float occ = 1.0f - ao;                             // Blit.shader:84
-                const float keep = 1.0f - occ;                           // OneMinusSrcColor / OneMinusSrcAlpha
-#pragma unroll
-                for (int k = 0; k < 3; ++k) t[k] = f32_to_f16_rtne_bits(f16_bits_to_f32(t[k]) * keep);
-                uint8_t *g = static_cast<uint8_t *>(a.gbuffer0) + (p0 + e) * 4 + 3;   // GBuffer0.a = occlusion
-                *g = static_cast<uint8_t>(f32_to_unorm8(unorm8_to_f32(*g) * keep));
-            }
-        }
-        if (full) {
-            uint4v outv;
-            outv.x = c[0] | (static_cast<uint32_t>(c[1]) << 16); outv.y = c[2] | (static_cast<uint32_t>(c[3]) << 16);
-            outv.z = c[4] | (static_cast<uint32_t>(c[5]) << 16); outv.w = c[6] | (static_cast<uint32_t>(c[7]) << 16);
-            *reinterpret_cast<uint4v *>(cp) = outv;
-        } else {
-            for (int k = 0; k < 4; ++k) cp[k] = c[k];
+         q += static_cast<int64_t>(gridDim.x) * kThreads)
+        composite_pair<AOFMT>(a.ao, a.color, a.gbuffer0, a.pixels, a.mode, q);
+}
+
+// The render pass carrying the composite of frames that an EARLIER call produced (meao_composite_enqueue):
+// the composite is pure streaming (17 bytes per texel, as many bytes as the whole AO path) and render
+// is VALU-bound with HBM nearly idle, so every render workgroup first streams its share of the
+// composite texel pairs and then renders its tile.
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_with_composite_kernel(const RenderArgs a,
+                                                                                         const CompositeBatchArgs c)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(false) + 2 * kRenApron)];
+    {
+        const int64_t pairs = (c.pixels + 1) / 2, total = pairs * c.frames;
+        const int64_t stride = static_cast<int64_t>(gridDim.x) * gridDim.y * blockDim.x;
+        for (int64_t i = (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int f = static_cast<int>(i / pairs);
+            composite_pair<AOFMT>(c.ao[f], c.color[f], c.gbuffer0[f], c.pixels, c.mode, i - f * pairs);
         }
     }
+    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(a.hostile, a.generation, frame)) {
+            render_tile<AOFMT, RTNE, DIV_IEEE, false>(a, tile, frame, block);
+            return;
+        }
+    }
+    render_tile<AOFMT, RTNE, DIV, false>(a, tile, frame, block);
 }
 
 // which = 4: rcp_strict, 5: div_const<3>, div_const<9>, 6: div_strict on hashed operand pairs
@@ -1380,6 +1414,30 @@ static hipError_t launch_render_any(const RenderArgs &a, int ao_format, int fram
 hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s)
 {
     return launch_render_any<false>(a, ao_format, frames, s);
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+static void launch_render_composite_t(const RenderArgs &a, const CompositeBatchArgs &c, dim3 grid, hipStream_t s)
+{
+    render_with_composite_kernel<AOFMT, RTNE, DIV><<<grid, dim3(ren_tile_w(false) * 4), 0, s>>>(a, c);
+}
+
+hipError_t launch_render_with_composite(const RenderArgs &a, const CompositeBatchArgs &c, int ao_format, int frames, hipStream_t s)
+{
+    if (a.exhaustive) return hipErrorInvalidValue;     // the 68-sample variant keeps its own launch; the caller flushes instead
+    const dim3 grid(a.blocks_per_frame, frames, 1);
+    if (ao_format == MEAO_AO_R8) {
+        if (a.f16_rtne) launch_render_composite_t<MEAO_AO_R8, true, DIV_IEEE>(a, c, grid, s);
+        else if (a.exact_rcp_div == 2) launch_render_composite_t<MEAO_AO_R8, false, DIV_FAST>(a, c, grid, s);
+        else if (a.exact_rcp_div) launch_render_composite_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(a, c, grid, s);
+        else launch_render_composite_t<MEAO_AO_R8, false, DIV_IEEE>(a, c, grid, s);
+    } else {
+        if (a.f16_rtne) launch_render_composite_t<MEAO_AO_F16, true, DIV_IEEE>(a, c, grid, s);
+        else if (a.exact_rcp_div == 2) launch_render_composite_t<MEAO_AO_F16, false, DIV_FAST>(a, c, grid, s);
+        else if (a.exact_rcp_div) launch_render_composite_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, c, grid, s);
+        else launch_render_composite_t<MEAO_AO_F16, false, DIV_IEEE>(a, c, grid, s);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s)

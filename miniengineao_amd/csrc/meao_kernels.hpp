@@ -135,6 +135,17 @@ struct CompositeArgs {
     int32_t mode;
 };
 hipError_t launch_composite(const CompositeArgs &a, int ao_format, hipStream_t s);
+// A batch of composites carried by a render launch (meao_composite_enqueue): frame f = ao[f] x color[f].
+struct CompositeBatchArgs {
+    const void *ao[MEAO_MAX_BATCH];
+    void *color[MEAO_MAX_BATCH];
+    void *gbuffer0[MEAO_MAX_BATCH];
+    int64_t pixels;      // per frame
+    int32_t frames;
+    int32_t mode;
+};
+hipError_t launch_render_with_composite(const RenderArgs &a, const CompositeBatchArgs &c, int ao_format, int frames,
+                                        hipStream_t s);
 // Exhaustive conversion self-tests; *count (device) receives the number of mismatches.
 hipError_t launch_selftest(int which, unsigned long long *count, hipStream_t s);
 

@@ -60,3 +60,77 @@ def test_gpu_composite_matches_oracle(oracle, ao_format, mode, w, h):
         assert np.array_equal(got_g, want_g)
     finally:
         ao_comp.close()
+
+
+# ---- the pipelined composite: rides inside the next execute's render kernel ------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("ao_format", [0, 1])
+def test_enqueued_composite_rides_in_the_next_render_and_matches_oracle(oracle, mode, ao_format):
+    torch = pytest.importorskip("torch")
+    from tests import helpers as H
+    from miniengineao_amd import synth
+    w, h, n = 200, 88, 3
+    s = H.settings(oracle, w, h, ao_format=ao_format)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(31 + mode)
+    frames = [synth.make("S2", w, h, seed=900 + f) for f in range(n)]
+    next_frames = [synth.make("S2", w, h, seed=950 + f) for f in range(n)]
+    want_ao = [oracle.run(f, s, result_only=True)["result"] for f in frames]
+    want_next = [oracle.run(f, s, result_only=True)["result"] for f in next_frames]
+    colors = [(rng.random((h, w, 4)) * 3.0).astype(np.float16).view(np.uint16) for _ in range(n)]
+    gbufs = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for _ in range(n)]
+    want_c, want_g = [c.copy() for c in colors], [g.copy() for g in gbufs]
+    for f in range(n):
+        oracle.composite(want_ao[f], want_c[f], mode, ao_format, want_g[f] if mode == 1 else None)
+    ao_dt = torch.uint8 if ao_format == 0 else torch.int16
+    dd = [torch.from_numpy(f).to(dev) for f in frames]
+    dn = [torch.from_numpy(f).to(dev) for f in next_frames]
+    out = [torch.zeros((h, w), dtype=ao_dt, device=dev) for _ in range(n)]
+    out2 = [torch.zeros((h, w), dtype=ao_dt, device=dev) for _ in range(n)]
+    dc = [torch.from_numpy(c.view(np.int16)).to(dev) for c in colors]
+    dg = [torch.from_numpy(g).to(dev) for g in gbufs]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ao = H.component(s, max_batch=n)
+    try:
+        ao.execute_device([t.data_ptr() for t in dd], [t.data_ptr() for t in out], st)
+        ao.composite_enqueue_device(mode, [t.data_ptr() for t in out], [t.data_ptr() for t in dc],
+                                    [t.data_ptr() for t in dg] if mode == 1 else None)
+        ao.execute_device([t.data_ptr() for t in dn], [t.data_ptr() for t in out2], st)   # carries the composite
+        torch.cuda.synchronize(dev)
+        for f in range(n):
+            assert np.array_equal(out2[f].cpu().numpy().view(want_next[f].dtype), want_next[f]), f
+            assert np.array_equal(dc[f].cpu().numpy().view(np.uint16), want_c[f]), (f, "color")
+            assert np.array_equal(dg[f].cpu().numpy(), want_g[f]), (f, "gbuffer0")
+    finally:
+        ao.close()
+
+
+@pytest.mark.gpu
+def test_enqueued_composite_is_never_dropped(oracle):
+    """flush, a second enqueue and close() all run a waiting batch."""
+    torch = pytest.importorskip("torch")
+    from tests import helpers as H
+    from miniengineao_amd import synth
+    w, h = 96, 64
+    s = H.settings(oracle, w, h)
+    dev = torch.device("cuda", 0)
+    depth = synth.make("S1", w, h)
+    want_ao = oracle.run(depth, s, result_only=True)["result"]
+    base = (np.random.default_rng(5).random((h, w, 4)) * 2.0).astype(np.float16).view(np.uint16)
+    want = base.copy()
+    oracle.composite(want_ao, want, 0)
+    d = torch.from_numpy(depth).to(dev)
+    out = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+    cols = [torch.from_numpy(base.view(np.int16).copy()).to(dev) for _ in range(3)]
+    ao = H.component(s)
+    ao.execute_device([d.data_ptr()], [out.data_ptr()])
+    ao.composite_enqueue_device(0, [out.data_ptr()], [cols[0].data_ptr()])
+    ao.composite_flush()                                             # 1: explicit flush
+    ao.composite_enqueue_device(0, [out.data_ptr()], [cols[1].data_ptr()])
+    ao.composite_enqueue_device(0, [out.data_ptr()], [cols[2].data_ptr()])   # 2: pushes the older one out
+    ao.close()                                                       # 3: destroy runs what still waits
+    torch.cuda.synchronize(dev)
+    for k in range(3):
+        assert np.array_equal(cols[k].cpu().numpy().view(np.uint16), want), k
