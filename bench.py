@@ -420,15 +420,21 @@ def main() -> int:
             return c
         lat_iters = 50
         single = {}
-        variants = (("direct", {}), ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}))
+        # "pipelined": a stream of single frames whose next depth buffer is known one call ahead
+        # (meao_prefetch_batch with n = 1: each call's last kernel carries the next frame's downsample pass)
+        variants = (("direct", {}), ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}), ("direct_pipelined", {"pipelined": True}))
         for name, kw in variants:
             c = one_frame_ctx(**kw)
             for sync_each in (False, True):
                 for _ in range(3):
+                    if name == "direct_pipelined":
+                        c.prefetch_device(dptr[:1])
                     c.execute_device(dptr[:1], optr[:1], stream)
                 fence()
                 t0 = time.perf_counter()
                 for _ in range(lat_iters):
+                    if name == "direct_pipelined":
+                        c.prefetch_device(dptr[:1])
                     c.execute_device(dptr[:1], optr[:1], stream)
                     if sync_each:
                         torch.cuda.synchronize(dev)

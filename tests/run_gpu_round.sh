@@ -8,6 +8,8 @@ timeout 600 python bench.py 2>/dev/null | grep '^{' > gpurun_out/bench_$TAG.json
 timeout 600 python bench.py --workload 1080p 2>/dev/null | grep '^{' > gpurun_out/bench_${TAG}_1080p.json
 timeout 600 python bench.py --workload 8k 2>/dev/null | grep '^{' > gpurun_out/bench_${TAG}_8k.json
 MEAO_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --skip-latency --min-time-ms 100 > gpurun_out/bench_force_dist_$TAG.log 2>&1
+timeout 600 python bench.py --shaded --no-cpu-baseline --skip-latency 2>/dev/null | grep '^{' > gpurun_out/bench_${TAG}_shaded.json
+timeout 600 python tests/fuzz_gpu.py 200 12000 > gpurun_out/fuzz_$TAG.log 2>&1
 bash tests/run_rocprof.sh $TAG > gpurun_out/rocprof_$TAG.log 2>&1
 bash tests/run_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
 timeout 300 miniengineao_amd/lib/ubench_issue 5.0 > gpurun_out/ubench_issue_$TAG.txt 2>&1
