@@ -214,11 +214,14 @@ def main() -> int:
     def fence():
         mdist.fence(dev)     # synchronize + barrier + synchronize
 
-    # clock ramp: a fixed ~25 ms of untimed work before the W warm-up steps, so that a short run
-    # (small --steps / --warmup) is timed at the same clocks as a long one
+    # clock ramp: ~80 ms of untimed back-to-back work before the W warm-up steps.  The chip's clocks and
+    # power state settle slowly: in the rocprofv3 trace of this command the render kernel goes 260 ->
+    # 200 -> 185 -> 178 us over the first 40 ms of continuous load (profiles/README.md), so a run with a
+    # small --steps / --warmup would otherwise be timed on the slope.
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.025:
-        step()
+    while time.perf_counter() - t_ramp < 0.080:
+        for _ in range(8):
+            step()
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
