@@ -99,7 +99,26 @@ namespace MiniEngineAO
         // that Render then carries its downsample pass inside its last kernel (meao_prefetch_batch).
         public void PrefetchNext(IntPtr nextDeviceDepth)
         {
+            // pending property changes first: meao_set_params would drop the announcement
+            SyncParameters(_cfg.width, _cfg.height);
             Check(Meao.meao_prefetch_batch(_ctx, 1, new IntPtr[] { nextDeviceDepth }));
+        }
+
+        // PushCompositeCommands (AO.cs:822-839) for streams of frames: the composite of a frame this
+        // component produced rides inside the render kernel of the NEXT Render call
+        // (meao_composite_enqueue); FlushComposite runs whatever still waits.
+        public void CompositeWithNextFrame(IntPtr deviceAo, IntPtr deviceColorRgba16f, IntPtr deviceGBuffer0, bool debug)
+        {
+            int mode = debug ? (int)MeaoCompositeMode.Debug
+                             : (ambientOnly && deviceGBuffer0 != IntPtr.Zero ? (int)MeaoCompositeMode.AmbientOnly
+                                                                             : (int)MeaoCompositeMode.Multiply);
+            Check(Meao.meao_composite_enqueue(_ctx, mode, 1, new IntPtr[] { deviceAo }, new IntPtr[] { deviceColorRgba16f },
+                                              mode == (int)MeaoCompositeMode.AmbientOnly ? new IntPtr[] { deviceGBuffer0 } : null));
+        }
+
+        public void FlushComposite(IntPtr stream)
+        {
+            Check(Meao.meao_composite_flush(_ctx, stream));
         }
 
         // Device-resident depth in -> AO texture out (the recorded "SSAO" command buffer,

@@ -114,6 +114,25 @@ public:
 
     void Synchronize(meao_stream stream = nullptr) { check(meao_synchronize(ctx_, stream)); }
 
+    // PushCompositeCommands (AO.cs:822-839).  Composite(): now, on `stream`.  CompositeWithNextFrame(): the
+    // composite of device frames this component produced rides inside the render kernel of the next
+    // Render* call (meao_composite_enqueue); FlushComposite() runs whatever still waits.
+    void Composite(meao_composite_mode mode, const void *deviceAo, void *deviceColorRgba16f, void *deviceGBuffer0 = nullptr,
+                   meao_stream stream = nullptr)
+    {
+        check(meao_composite(ctx_, mode, deviceAo, deviceColorRgba16f, deviceGBuffer0, MEAO_MEM_DEVICE, stream));
+    }
+    void CompositeWithNextFrame(meao_composite_mode mode, const std::vector<const void *> &deviceAo,
+                                const std::vector<void *> &deviceColorRgba16f, const std::vector<void *> &deviceGBuffer0 = {})
+    {
+        check(meao_composite_enqueue(ctx_, mode, static_cast<int32_t>(deviceAo.size()), deviceAo.data(), deviceColorRgba16f.data(),
+                                     deviceGBuffer0.empty() ? nullptr : deviceGBuffer0.data()));
+    }
+    void FlushComposite(meao_stream stream = nullptr) { check(meao_composite_flush(ctx_, stream)); }
+
+    // roctx ranges per pass for rocprofv3 --marker-trace
+    void SetTracing(bool enable) { check(meao_set_tracing(ctx_, enable ? 1 : 0)); }
+
     // The _debug 1..17 views (AO.cs:787-820) and OcclusionHQ1..4 (18..21), copied to the host.
     std::vector<uint8_t> DebugBuffer(int32_t debugId, meao_desc *desc = nullptr, int32_t frame = 0)
     {
