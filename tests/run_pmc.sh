@@ -10,6 +10,8 @@ run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv 
 BENCH_ARGS="$*"
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+run sq3 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT
+run sq4 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU2 SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INST_CYCLES_SALU
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 cd $REPO
