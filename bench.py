@@ -134,6 +134,8 @@ def main() -> int:
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not use meao_prefetch_batch: every step launches its own downsample pass instead of "
                          "carrying the next step's inside its last upsample kernel")
+    ap.add_argument("--roctx", action="store_true",
+                    help="meao_set_tracing: roctx ranges around every pass (for rocprofv3 --marker-trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-time-ms", type=float, default=0.0,
                     help="raise --steps so that the timed region lasts at least this long (rank skew matters "
@@ -189,6 +191,8 @@ def main() -> int:
                              numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT,
                              pipelined=not args.no_pipeline)
         c.intensity = intensity
+        if args.roctx:
+            c.set_tracing(True)
         ctxs.append(c)
     ao = ctxs[0]
     tstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]
