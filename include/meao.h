@@ -351,7 +351,8 @@ MEAO_API int32_t meao_pool_synchronize(meao_pool *pool);
 
 /* roctx ranges ("meao:downsample", "meao:render", "meao:upsample_L1_to_L0", ...) around the launches
  * of every pass, so that rocprofv3 --marker-trace output is self-describing even where passes are
- * fused.  Off by default; libroctx64.so is loaded on first use (MEAO_ERR_UNSUPPORTED if absent). */
+ * fused.  Off by default; librocprofiler-sdk-roctx.so (rocprofv3) or libroctx64.so is loaded on first
+ * use (MEAO_ERR_UNSUPPORTED if neither is present). */
 MEAO_API int32_t meao_set_tracing(meao_ctx *ctx, int32_t enable);
 
 /* Exhaustive device self-tests of what bit-exactness rests on; *out_mismatches = number of

@@ -1023,9 +1023,14 @@ int32_t meao_set_tracing(meao_ctx *ctx, int32_t enable)
 {
     if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
     if (enable && !ctx->roctx_lib) {
-        void *lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) return fail(ctx, MEAO_ERR_UNSUPPORTED, "meao_set_tracing: libroctx64.so not found");
+        // rocprofv3 (rocprofiler-sdk) intercepts the roctx API of its own library; libroctx64.so is the
+        // older roctracer one (rocprof v1/v2) with the same entry points
+        static const char *const kCandidates[] = {"librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                                                  "libroctx64.so", "/opt/rocm/lib/libroctx64.so"};
+        void *lib = nullptr;
+        for (const char *name : kCandidates)
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!lib) return fail(ctx, MEAO_ERR_UNSUPPORTED, "meao_set_tracing: no roctx library found (librocprofiler-sdk-roctx.so / libroctx64.so)");
         ctx->roctx_push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
         ctx->roctx_pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
         if (!ctx->roctx_push || !ctx->roctx_pop) {
