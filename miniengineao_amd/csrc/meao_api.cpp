@@ -67,6 +67,10 @@ struct meao_ctx {
     // (meao_kernels.hip "Exact division"); recomputed by update_plan()
     int exact_rcp_div = 0;
 
+    // Upsample L4->L3 evaluated inside the L3->L2 launch (upsample_two_level_kernel); on unless the
+    // A/B switch MEAO_DEBUG_NO_FUSED_BLEND=1 was set when the context was created
+    bool fuse_coarse_blend = true;
+
     // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue)
     CompositeBatchArgs pending_comp{};
 
@@ -471,9 +475,17 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         MEAO_HIP(ctx, launch_render_wide(render_args(1, c.num_levels, true), c.ao_format, n, stream));
         MEAO_HIP(ctx, end(MEAO_PASS_RENDER_HQ, stream));
     }
-    for (int hi = c.num_levels - 1; hi >= 2; --hi) {
-        const int rc = launch_blend(hi, stream);
-        if (rc != MEAO_OK) return rc;
+    if (ctx->fuse_coarse_blend && c.num_levels == 4 && c.hq_levels == 0) {
+        // L4 -> L3 inside the L3 -> L2 launch: one launch, one latency-bound pass less (Combined3 is still written)
+        TraceRange tr(ctx, "meao:upsample_L4_to_L3+L3_to_L2");
+        MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_2, stream));
+        MEAO_HIP(ctx, launch_upsample_two_level(upsample_args(2), upsample_args(3), c.ao_format, n, stream));
+        MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_2, stream));
+    } else {
+        for (int hi = c.num_levels - 1; hi >= 2; --hi) {
+            const int rc = launch_blend(hi, stream);
+            if (rc != MEAO_OK) return rc;
+        }
     }
     if (c.num_levels >= 2) {
         const int rc = launch_blend(1, stream);
@@ -701,6 +713,8 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
     meao_ctx *ctx = new (std::nothrow) meao_ctx();
     if (!ctx) return fail(nullptr, MEAO_ERR_OUT_OF_MEMORY, "meao_create: host allocation failed");
     ctx->cfg = *cfg;
+    const char *no_fuse = std::getenv("MEAO_DEBUG_NO_FUSED_BLEND");
+    ctx->fuse_coarse_blend = !(no_fuse && no_fuse[0] == '1');
     meao_default_params(&ctx->prm);
     int rc = use_device(ctx);
     if (rc == MEAO_OK) {

@@ -811,7 +811,9 @@ struct UpsLds {
     static constexpr int kFloats = kInvN + kHbN + kDepN + kAoN;
 };
 
-template <int AOFMT, bool RTNE, bool FINAL, int DIV>
+// NESTED: the LoResAO1 taps (s_ao) were already produced in LDS by blend_window_into_lds (the
+// previous pass of the chain evaluated inside this workgroup) instead of being read from global memory.
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false>
 __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame)
 {
     typedef AoTexel<AOFMT> AO;
@@ -891,10 +893,13 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
             const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
             const float4v d4 = *reinterpret_cast<const float4v *>(lo_depth + idx);
-            const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
             const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
-            float av[4] = {AO::decode(a4.x), AO::decode(a4.y), AO::decode(a4.z), AO::decode(a4.w)};
-            if (lo_ao2) {
+            float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (!NESTED) {
+                const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
+                av[0] = AO::decode(a4.x); av[1] = AO::decode(a4.y); av[2] = AO::decode(a4.z); av[3] = AO::decode(a4.w);
+            }
+            if (!NESTED && lo_ao2) {
                 const typename AO::type4 b4 = *reinterpret_cast<const typename AO::type4 *>(lo_ao2 + idx);
                 av[0] = __builtin_fminf(av[0], AO::decode(b4.x)); av[1] = __builtin_fminf(av[1], AO::decode(b4.y));
                 av[2] = __builtin_fminf(av[2], AO::decode(b4.z)); av[3] = __builtin_fminf(av[3], AO::decode(b4.w));
@@ -905,7 +910,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 if (c >= 0 && c < T::kRawW) {
                     if (dep_kept(r, c)) dep_at(r, c) = dv[e];
                     s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
-                    s_ao[r * T::kRawPitch + c] = av[e];
+                    if constexpr (!NESTED) s_ao[r * T::kRawPitch + c] = av[e];
                 }
             }
         }
@@ -917,9 +922,11 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             const float d = lo_depth[idx];
             if (dep_kept(r, c)) dep_at(r, c) = d;
             s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
-            float av = AO::decode(lo_ao[idx]);
-            if (lo_ao2) av = __builtin_fminf(av, AO::decode(lo_ao2[idx]));
-            s_ao[r * T::kRawPitch + c] = av;
+            if constexpr (!NESTED) {
+                float av = AO::decode(lo_ao[idx]);
+                if (lo_ao2) av = __builtin_fminf(av, AO::decode(lo_ao2[idx]));
+                s_ao[r * T::kRawPitch + c] = av;
+            }
         }
     }
     __syncthreads();
@@ -1076,6 +1083,128 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             }
         }
     }
+}
+
+// One blend pass (Upsample.main_blendout) evaluated for an arbitrary window of its OUTPUT level, into LDS:
+// out[r * out_pitch + c] = what a later pass would read back from Combined<k> at virtual texel
+// (vx0 + c, vy0 + r) with clamp addressing (UPS:54-72), i.e. the stored-and-decoded result.
+// Every output of the pass is a pure function of the global inputs (each blurred value only depends
+// on its own 5-tap window of clamped taps, the bilateral taps on the texel's parity), so evaluating it
+// here gives the bits the stand-alone pass writes.  Texels of the window that fall into the "own"
+// rectangle are also stored to the pass's real target, so that the buffer exists for the debug views.
+// Window at most 38 x 22: low-res D range <= 21 x 13, raw taps <= 25 x 17 (scratch: 1905 floats).
+constexpr int kNestLowW = 21, kNestLowH = 13, kNestRawW = kNestLowW + 4, kNestRawH = kNestLowH + 4;
+constexpr int kNestScratch = 3 * kNestRawW * kNestRawH + kNestLowW * kNestRawH + kNestLowW * kNestLowH;
+
+template <int AOFMT, bool RTNE, int DIV>
+__device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, float *out, int out_pitch, int vx0, int vy0,
+                                                      int win_w, int win_h, float *scratch, int frame, int own_x0,
+                                                      int own_y0, int own_w, int own_h)
+{
+    typedef AoTexel<AOFMT> AO;
+    typedef typename AO::type ao_t;
+    float *const r_ao = scratch;                                   // raw LoResAO1 taps
+    float *const r_inv = r_ao + kNestRawW * kNestRawH;             // 1 / LoResDB
+    float *const r_dep = r_inv + kNestRawW * kNestRawH;            // LoResDB
+    float *const hb = r_dep + kNestRawW * kNestRawH;               // after BlurHorizontally
+    float *const vb = hb + kNestLowW * kNestRawH;                  // after BlurVertically
+    const int lw = in.lw, lh = in.lh, hw = in.hw, hh = in.hh;
+    const float *__restrict__ lo_depth = frame_ptr(in.lo_depth, in.frame_stride, frame);
+    const ao_t *__restrict__ lo_ao = frame_ptr(static_cast<const ao_t *>(in.lo_ao), in.frame_stride, frame);
+    const float *__restrict__ hi_depth = frame_ptr(static_cast<const float *>(in.hi_depth), in.frame_stride, frame);
+    const ao_t *__restrict__ hi_ao = frame_ptr(static_cast<const ao_t *>(in.hi_ao), in.frame_stride, frame);
+    ao_t *__restrict__ dst = frame_ptr(static_cast<ao_t *>(in.dst[0]), in.frame_stride, frame);
+    const BlurConsts bk = {in.step_size, in.blur_tolerance};
+
+    // low-res texels the window's bilateral taps touch: D = (X+1)>>1 and D-1, X clamped to the level
+    const int cx_min = clampi(vx0, 0, hw - 1), cx_max = clampi(vx0 + win_w - 1, 0, hw - 1);
+    const int cy_min = clampi(vy0, 0, hh - 1), cy_max = clampi(vy0 + win_h - 1, 0, hh - 1);
+    const int dx_lo = ((cx_min + 1) >> 1) - 1, nlw = ((cx_max + 1) >> 1) - dx_lo + 1;
+    const int dy_lo = ((cy_min + 1) >> 1) - 1, nlh = ((cy_max + 1) >> 1) - dy_lo + 1;
+    const int rx0 = dx_lo - 2, ry0 = dy_lo - 2, rw = nlw + 4, rh = nlh + 4;      // raw taps (virtual, clamped on load)
+
+    for (int i = threadIdx.x; i < rw * rh; i += kThreads) {
+        const int r = i / rw, c = i % rw;
+        const size_t idx = static_cast<size_t>(clampi(ry0 + r, 0, lh - 1)) * lw + clampi(rx0 + c, 0, lw - 1);
+        const float d = lo_depth[idx];
+        r_dep[r * kNestRawW + c] = d;
+        r_inv[r * kNestRawW + c] = rcp_strict<DIV>(d);                       // UPS:67
+        r_ao[r * kNestRawW + c] = AO::decode(lo_ao[idx]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nlw * rh; i += kThreads) {                     // BlurHorizontally, one output per lane
+        const int r = i / nlw, c = i % nlw;
+        float av[5], zv[5], o[1];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { av[t] = r_ao[r * kNestRawW + c + t]; zv[t] = r_inv[r * kNestRawW + c + t]; }
+        blur_run<1>(bk, av, zv, o);
+        hb[r * kNestLowW + c] = o[0];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nlw * nlh; i += kThreads) {                    // BlurVertically
+        const int r = i / nlw, c = i % nlw;
+        float av[5], zv[5], o[1];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { av[t] = hb[(r + t) * kNestLowW + c]; zv[t] = r_inv[(r + t) * kNestRawW + c + 2]; }
+        blur_run<1>(bk, av, zv, o);
+        vb[r * kNestLowW + c] = o[0];
+    }
+    __syncthreads();
+    constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};                // Gather order, as in upsample_tile
+    for (int i = threadIdx.x; i < win_w * win_h; i += kThreads) {
+        const int wr = i / win_w, wc = i % win_w;
+        const int X = clampi(vx0 + wc, 0, hw - 1), Y = clampi(vy0 + wr, 0, hh - 1);
+        const int Dx = (X + 1) >> 1, Dy = (Y + 1) >> 1;
+        const int comp = (X & 1) ? ((Y & 1) ? 3 : 0) : ((Y & 1) ? 2 : 1);
+        float dk[4], ak[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = (comp + k) & 3;
+            const int lx = Dx + gx[g], ly = Dy + gy[g];
+            ak[k] = vb[(ly - dy_lo) * kNestLowW + (lx - dx_lo)];
+            dk[k] = r_dep[(ly - ry0) * kNestRawW + (lx - rx0)];
+        }
+        const size_t at = static_cast<size_t>(Y) * hw + X;
+        const float v = bilateral_upsample<DIV>(hi_depth[at], AO::decode(hi_ao[at]), dk[0], dk[1], dk[2], dk[3], ak[0], ak[1],
+                                                ak[2], ak[3], in.upsample_tolerance, in.noise_filter_strength);
+        const ao_t q = AO::template encode<RTNE>(v);
+        out[wr * out_pitch + wc] = AO::decode(q);
+        if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) dst[at] = q;
+    }
+    __syncthreads();
+}
+
+// Upsample.main_blendout L4 -> L3 evaluated inside the L3 -> L2 pass: the smallest pass of the chain
+// (one wave of workgroups, three barriers, two memory round trips: latency-bound, and a launch of its
+// own) disappears; each L3 -> L2 tile computes the 38 x 22 window of Combined3 it needs itself
+// (1.6x the texels of that pass, which is 1/16 of the last pass's work).
+template <int AOFMT, bool RTNE, int DIV>
+__device__ __forceinline__ void upsample_two_level_tile(const UpsampleArgs &outer, const UpsampleArgs &inner, float *smem, int tile,
+                                                        int frame)
+{
+    typedef UpsTile<ups_tile_h(false)> T;
+    typedef UpsLds<false> Lds;
+    static_assert(kNestScratch <= Lds::kInvN + Lds::kHbN + Lds::kDepN, "the nested pass's scratch precedes s_ao");
+    float *const s_ao = smem + Lds::kInvN + Lds::kHbN + Lds::kDepN;
+    const int tile_x = tile % outer.tiles_x, tile_y = tile / outer.tiles_x;
+    const int LX0 = (tile_x * kUpsTileW) >> 1, LY0 = (tile_y * ups_tile_h(false)) >> 1;
+    blend_window_into_lds<AOFMT, RTNE, DIV>(inner, s_ao, T::kRawPitch, LX0 - 3, LY0 - 3, T::kRawW, T::kRawH, smem, frame,
+                                            LX0, LY0, T::kLowW, T::kLowH);
+    upsample_tile<AOFMT, RTNE, false, DIV, true>(outer, smem, tile, frame);
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(kThreads) void upsample_two_level_kernel(const UpsampleArgs outer, const UpsampleArgs inner)
+{
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<false>::kFloats];
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x), frame = blockIdx.z;
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(outer.hostile, outer.generation, frame)) {
+            upsample_two_level_tile<AOFMT, RTNE, DIV_IEEE>(outer, inner, smem, tile, frame);
+            return;
+        }
+    }
+    upsample_two_level_tile<AOFMT, RTNE, DIV>(outer, inner, smem, tile, frame);
 }
 
 // The (rare) hostile-frame variant of a tile: the same code with IEEE division.
@@ -1466,6 +1595,29 @@ hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f
         else if (a.exact_rcp_div == 2) launch_upsample_t<MEAO_AO_F16, false, DIV_FAST>(a, hi_depth_f16, grid, s);
         else if (a.exact_rcp_div) launch_upsample_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, hi_depth_f16, grid, s);
         else launch_upsample_t<MEAO_AO_F16, false, DIV_IEEE>(a, hi_depth_f16, grid, s);
+    }
+    return hipGetLastError();
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+static void launch_upsample_two_level_t(const UpsampleArgs &outer, const UpsampleArgs &inner, dim3 grid, hipStream_t s)
+{
+    upsample_two_level_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(outer, inner);
+}
+
+hipError_t launch_upsample_two_level(const UpsampleArgs &outer, const UpsampleArgs &inner, int ao_format, int frames, hipStream_t s)
+{
+    const dim3 grid(outer.tiles_x * outer.tiles_y, 1, frames);
+    if (ao_format == MEAO_AO_R8) {
+        if (outer.f16_rtne) launch_upsample_two_level_t<MEAO_AO_R8, true, DIV_IEEE>(outer, inner, grid, s);
+        else if (outer.exact_rcp_div == 2) launch_upsample_two_level_t<MEAO_AO_R8, false, DIV_FAST>(outer, inner, grid, s);
+        else if (outer.exact_rcp_div) launch_upsample_two_level_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(outer, inner, grid, s);
+        else launch_upsample_two_level_t<MEAO_AO_R8, false, DIV_IEEE>(outer, inner, grid, s);
+    } else {
+        if (outer.f16_rtne) launch_upsample_two_level_t<MEAO_AO_F16, true, DIV_IEEE>(outer, inner, grid, s);
+        else if (outer.exact_rcp_div == 2) launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_FAST>(outer, inner, grid, s);
+        else if (outer.exact_rcp_div) launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(outer, inner, grid, s);
+        else launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_IEEE>(outer, inner, grid, s);
     }
     return hipGetLastError();
 }

@@ -113,6 +113,10 @@ hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStre
 hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
+// Two blend passes in one launch: `inner` (e.g. L4 -> L3) is evaluated per tile of `outer` (L3 -> L2) for the
+// window of its output that the tile reads; inner's target is still written (each tile stores its own part).
+hipError_t launch_upsample_two_level(const UpsampleArgs &outer, const UpsampleArgs &inner, int ao_format, int frames,
+                                     hipStream_t s);
 // Upsample.main of this batch + the downsample pass of the next one in a single kernel.
 hipError_t launch_upsample_final_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format,
                                                  int frames, hipStream_t s);
