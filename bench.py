@@ -322,6 +322,12 @@ def main() -> int:
         alg[u0] += alg[d0]
         alg[d0] = 0
         names[u0] = "upsample_L1_to_L0+downsample_next"
+    u3, u2 = names.index("upsample_L4_to_L3"), names.index("upsample_L3_to_L2")
+    if pass_ms[u3] <= 0 < pass_ms[u2]:
+        # the library evaluates L4 -> L3 inside the L3 -> L2 launch (upsample_two_level_kernel): its bytes move there
+        alg[u2] += alg[u3]
+        alg[u3] = 0
+        names[u2] = "upsample_L4_to_L3+L3_to_L2"
     dominant = int(np.argmax(pass_ms))
     passes = []
     for k in range(_lib.NUM_PASSES):
