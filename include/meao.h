@@ -106,7 +106,10 @@ typedef enum meao_sample_set { MEAO_SAMPLES_CHECKER = 0, MEAO_SAMPLES_EXHAUSTIVE
 typedef enum meao_pass {
     MEAO_PASS_DOWNSAMPLE = 0,  /* Downsample1.main + Downsample2.main fused  (AO.cs:627-657) */
     MEAO_PASS_RENDER = 1,      /* Render.main_interleaved, all levels, one grid (AO.cs:519-522) */
-    MEAO_PASS_UPSAMPLE_3 = 2,  /* Upsample.main_blendout L4 -> L3             (AO.cs:528) */
+    MEAO_PASS_UPSAMPLE_3 = 2,  /* Upsample.main_blendout L4 -> L3             (AO.cs:528).  With 4 levels and
+                                * hq_levels = 0 it is evaluated inside the L3 -> L2 launch (each tile computes the
+                                * window of Combined3 it reads; Combined3 is still written): no launch of its
+                                * own, meao_get_pass_times reports 0 here and the joint time under UPSAMPLE_2 */
     MEAO_PASS_UPSAMPLE_2 = 3,  /* Upsample.main_blendout L3 -> L2             (AO.cs:529) */
     MEAO_PASS_UPSAMPLE_1 = 4,  /* Upsample.main_blendout L2 -> L1             (AO.cs:530) */
     MEAO_PASS_UPSAMPLE_0 = 5,  /* Upsample.main          L1 -> L0 result      (AO.cs:531) */
