@@ -22,7 +22,8 @@ KERNELS = {
     "downsample_kernel": ("downsample", 2.0, "reads are one 16 B/lane stream: FETCH_SIZE x2 (calibrated: equals 4*W*H bytes/frame)"),
     "render_kernel": ("render", 2.0, "window fill is 16 B/lane: FETCH_SIZE x2"),
     "upsample_kernel<0, false, true": ("upsample_L1_to_L0", 1.0, "8 B/lane (f16 depth) + 16 B/lane + 4 B/lane reads: FETCH_SIZE left raw (uncalibrated width); raw value equals compulsory + apron bytes"),
-    "upsample_kernel<0, false, false": ("upsample_blend_passes", 1.0, "mean of the three main_blendout launches; FETCH_SIZE raw"),
+    "upsample_kernel<0, false, false": ("upsample_blend_passes", 1.0, "mean of the stand-alone main_blendout launches (L2->L1 only when L4->L3 rides inside L3->L2); FETCH_SIZE raw"),
+    "upsample_two_level_kernel<0, false": ("upsample_L4_to_L3+L3_to_L2", 1.0, "the fused two-level launch; FETCH_SIZE raw"),
     # the last upsample kernel carrying the next batch's downsample pass (meao_prefetch_batch): the carried
     # 16 B/lane depth stream (4*W*H bytes per frame, known exactly) is tallied at half size like in
     # downsample_kernel, the upsample reads are raw -> add the missing half of the depth stream
