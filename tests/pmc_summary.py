@@ -1,4 +1,7 @@
-"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel (mean per dispatch)."""
+"""Per-kernel means of every counter in a tests/run_pmc.sh output directory.
+
+    python tests/pmc_summary.py gpurun_out/pmc_<tag>
+"""
 import collections
 import csv
 import glob
@@ -6,23 +9,24 @@ import re
 import sys
 
 
-def short(name):
+def kernel_key(name):
     m = re.search(r"(\w+_kernel<[^>]*>)", name)
-    return m.group(1) if m else name[:60]
+    return m.group(1) if m else name[:48]
 
 
-def main(root):
-    for f in sorted(glob.glob(root + "/*/*counter_collection.csv")):
+def main():
+    out = sys.argv[1]
+    for f in sorted(glob.glob(out + "/*/*counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         cnt = collections.Counter()
         for row in csv.DictReader(open(f)):
-            k = short(row["Kernel_Name"])
+            k = kernel_key(row["Kernel_Name"])
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[(k, row["Counter_Name"])] += 1
         print("==", f)
         for k, d in sorted(agg.items()):
-            print(f"{k:44s}", {c: round(v / cnt[(k, c)], 1) for c, v in sorted(d.items())}, "dispatches", cnt[(k, next(iter(d)))])
+            print(k, {c: round(v / cnt[(k, c)], 1) for c, v in sorted(d.items())})
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main()

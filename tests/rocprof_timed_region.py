@@ -22,7 +22,9 @@ def main():
         v.sort()
         d = [x[1] for x in v]
         groups = [("", d)]
-        if "upsample_kernel" in k and ", false," in k.split("<")[1][3:]:     # the three blend passes alternate
+        if k.startswith("upsample_kernel") and ", false," in k.split("<")[1][3:] and not any(
+                x.startswith("upsample_two_level_kernel") for x in by):
+            # without the fused two-level launch the three blend passes alternate in this one kernel
             groups = [(" " + name, d[j::3]) for j, name in enumerate(("L4->L3", "L3->L2", "L2->L1"))]
         for name, dd in groups:
             us = lambda xs: sum(xs) / max(len(xs), 1) / 1e3    # noqa: E731

@@ -2,7 +2,7 @@
 set -x
 TAG=${1:-r01}; shift
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/pmc_$TAG
+export OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 120 rocprofv3 -L > $OUT/counters_available.txt 2>&1
@@ -15,16 +15,5 @@ run sq4 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU2 SQ_INST_LEVEL_LDS SQ_LEVEL_WA
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 cd $REPO
-python - <<'PY'
-import csv, glob, collections, os, sys
-out = os.environ.get('OUT') or sorted(glob.glob('gpurun_out/pmc_*'))[-1]
-for f in sorted(glob.glob(out + '/*/*counter_collection.csv')):
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-    for row in csv.DictReader(open(f)):
-        k = row['Kernel_Name'].split('(')[0][-60:]; agg[k][row['Counter_Name']] += float(row['Counter_Value']); 
-        cnt[(k,row['Counter_Name'])] += 1
-    print('==', f)
-    for k, d in agg.items():
-        print(k, {c: round(v / cnt[(k,c)], 1) for c, v in d.items()})
-PY
+python tests/pmc_summary.py $OUT
 find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete
