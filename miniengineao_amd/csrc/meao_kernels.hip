@@ -39,6 +39,21 @@
 #ifndef MEAO_UPS_HOIST
 #define MEAO_UPS_HOIST 1        // hi-res depth / AO loads of the bilateral phase issued at the top of the tile
 #endif
+#ifndef MEAO_REN_SWPIPE
+#define MEAO_REN_SWPIPE 1       // render texel loop with hand-pipelined LDS reads (accumulate_terms_pipelined); 0 = compiler-scheduled
+#endif
+#ifndef MEAO_REN_SWPIPE_DEPTH
+#define MEAO_REN_SWPIPE_DEPTH 1 // sample pairs in flight ahead of the one being evaluated (1 or 2)
+#endif
+#ifndef MEAO_REN_VGPR_CONSTS
+#define MEAO_REN_VGPR_CONSTS 1  // pipelined render loop: -frontDepth and the reject fade-off as VGPR instead of SGPR operands (an SGPR source halves the VALU rate)
+#endif
+#ifndef MEAO_UPS_VGPR_CONSTS
+#define MEAO_UPS_VGPR_CONSTS 0  // bilateral phase: tolerance, noise strength and the 3 / 9 of the weights as VGPR operands
+#endif
+#ifndef MEAO_FUSE_SPLIT_DS
+#define MEAO_FUSE_SPLIT_DS 2    // fused last kernel: the carried downsample tile's loads are issued inside the upsample tile
+#endif                          // (1 = after its prefetch, 2 = before its bilateral phase) and consumed after it; 0 = tile first
 #ifndef MEAO_REN_FASTPATH
 #define MEAO_REN_FASTPATH 0     // wave-uniform "all distances >= 0" path in the render kernel (bit-exact; slower, see test_samples)
 #endif
@@ -198,13 +213,13 @@ __device__ __forceinline__ float rcp_strict(float x)
 }
 
 template <int DIV, int K>
-__device__ __forceinline__ float div_const(float x)   // K / x, K in {1, 3, 9}
+__device__ __forceinline__ float div_const(float x, float k_value = static_cast<float>(K))   // K / x, K in {1, 3, 9}; k_value == K (a register copy of it)
 {
     if constexpr (DIV == DIV_EXACT_RCP) {
         if constexpr (K == 1) return rcp_strict<DIV>(x);
         const float r = __builtin_amdgcn_rcpf(x);
-        const float q = static_cast<float>(K) * r;
-        const float e = mad(-x, q, static_cast<float>(K));
+        const float q = k_value * r;
+        const float e = mad(-x, q, k_value);
         return mad(e, r, q);
     } else if constexpr (DIV == DIV_FAST) {
         return static_cast<float>(K) * __builtin_amdgcn_rcpf(x);
@@ -263,33 +278,28 @@ __device__ __forceinline__ bool nice_denominator(float den)
     return __builtin_amdgcn_fmed3f(den, 0x1p-20f, 0x1p24f) == den;   // false for NaN
 }
 
-template <bool RTNE, bool VEC, int DIV>
-__device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int tile, int frame)
+// First half of a downsample tile: the raw depth texels of this lane, 4 per row in each of the 4 row passes.
+// F32_ONLY: the caller has established a.depth_format == MEAO_DEPTH_F32 (no format switch in the code).
+template <bool VEC, bool F32_ONLY = false>
+__device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, int tile, int frame,
+                                                     float (&v)[kDsTileH / kDsRowsPerPass][4])
 {
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const void *__restrict__ depth = a.depth[frame];
-    uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
-    float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
-    float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
-    float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
-    float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
     const int W = a.w[0], H = a.h[0];
-    const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
-
     const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
     const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
     if (x0 >= W) return;
 
     // The depth-copy blit of the reference (Blit.shader pass 0) is folded into this load: the
     // texel format is decoded here (wave-uniform switch), 4 texels per lane per row.
-    float v[kDsTileH / kDsRowsPerPass][4];
 #pragma unroll
     for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
         const int y = yb + k * kDsRowsPerPass;
         v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.5f;
         if (y < H) {
             const size_t at = static_cast<size_t>(y) * W + x0;
-            if (a.depth_format == MEAO_DEPTH_F32) {
+            if (F32_ONLY || a.depth_format == MEAO_DEPTH_F32) {
                 const float *row = static_cast<const float *>(depth) + at;
                 if constexpr (VEC) {
                     const float4v q = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(row));
@@ -329,6 +339,24 @@ __device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int til
             }
         }
     }
+}
+
+// Second half: linearize, store LinearZ and the four point-sampled levels.
+template <bool RTNE, bool VEC, int DIV>
+__device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, int tile, int frame,
+                                                       const float (&v)[kDsTileH / kDsRowsPerPass][4])
+{
+    const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+    uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
+    float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
+    float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
+    float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
+    float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
+    const int W = a.w[0], H = a.h[0];
+    const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
+    const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
+    const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
+    if (x0 >= W) return;
 #pragma unroll
     for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
         const int y = yb + k * kDsRowsPerPass;
@@ -382,6 +410,14 @@ __device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int til
             }
         }
     }
+}
+
+template <bool RTNE, bool VEC, int DIV>
+__device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int tile, int frame)
+{
+    float v[kDsTileH / kDsRowsPerPass][4];
+    downsample_tile_load<VEC>(a, tile, frame, v);
+    downsample_tile_finish<RTNE, VEC, DIV>(a, tile, frame, v);
 }
 
 template <bool RTNE, bool VEC, int DIV>
@@ -514,6 +550,118 @@ __device__ __forceinline__ float2v accumulate_terms(const TermConstants<EXH> &L,
     return fma2(splat(L.intensity), ao - splat(1.0f), splat(1.0f));   // lerp(1, ao, gIntensity) REN:176
 }
 
+// ---- the same sum with the LDS reads pipelined by hand (MEAO_REN_SWPIPE) ----------------------
+// clang issues the ds_read's of a term right before their first use (s_waitcnt a few instructions
+// later): every wave exposes the LDS latency 12+ times per texel pair.  Here the 18 sample pairs of
+// the checker set are one flat sequence; the two 8-byte reads of pair k + DEPTH are issued before pair k
+// is evaluated, as separate ds_read_b64 (the merged ds_read2_b64 form runs at half the LDS rate,
+// tools/ubench_lds.hip).  The reads are inline asm, so the waits are too: LDS operations return in
+// order, `s_waitcnt lgkmcnt(2 * DEPTH)` therefore means "pair k has arrived" whatever else is in flight
+// behind it.  Arithmetic and its order are those of test_samples / accumulate_terms.
+struct SamplePair { float2v s1, s2; };
+
+constexpr int kCheckerTerms[7][2] = {{2, 0}, {4, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 3}, {2, 4}};   // REN:162-168
+constexpr int kCheckerPairs = 18;
+
+constexpr int checker_pairs_in_term(int t) { return (kCheckerTerms[t][1] == 0 || kCheckerTerms[t][0] == kCheckerTerms[t][1]) ? 2 : 4; }
+constexpr int checker_term_of_pair(int k)
+{
+    int t = 0;
+    while (k >= checker_pairs_in_term(t)) { k -= checker_pairs_in_term(t); ++t; }
+    return t;
+}
+constexpr int checker_index_in_term(int k)
+{
+    int t = 0;
+    while (k >= checker_pairs_in_term(t)) { k -= checker_pairs_in_term(t); ++t; }
+    return k;
+}
+// LDS offset (floats) of the first sample of pair i of term (X, Y); the second one is at minus that
+constexpr int checker_pair_offset(int X, int Y, int P, int Q, int i)
+{
+    return i == 0 ? (Y == 0 ? X * Q : (X == Y ? X * P - X * Q : Y * P + X * Q))
+         : i == 1 ? (Y == 0 ? X * P : (X == Y ? X * P + X * Q : Y * P - X * Q))
+         : i == 2 ? X * P + Y * Q : X * P - Y * Q;
+}
+
+template <int BYTE_OFF>
+__device__ __forceinline__ void lds_read_b64_async(uint32_t lds_addr, float2v &v)
+{
+    static_assert(BYTE_OFF >= 0 && BYTE_OFF < 65536 && BYTE_OFF % 8 == 0, "ds_read_b64 immediate offset");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(BYTE_OFF));
+}
+
+template <int K, int P, int Q>
+__device__ __forceinline__ void issue_checker_pair(uint32_t base, SamplePair &into)
+{
+    if constexpr (K < kCheckerPairs) {
+        constexpr int t = checker_term_of_pair(K);
+        constexpr int off = checker_pair_offset(kCheckerTerms[t][0], kCheckerTerms[t][1], P, Q, checker_index_in_term(K));
+        constexpr int centre_at = 4 * P + 4 * Q;                 // `base` is that many floats before the centre texel
+        lds_read_b64_async<(centre_at + off) * 4>(base, into.s1);
+        lds_read_b64_async<(centre_at - off) * 4>(base, into.s2);
+    }
+}
+
+// Waits until at most PENDING LDS reads are outstanding.  The operands tie the wait into the data flow:
+// the arrived pair is only readable after it, and the running sums (= the previous pair's arithmetic)
+// are complete before it, so the schedule keeps one pair's arithmetic between two waits.
+template <int PENDING>
+__device__ __forceinline__ void wait_checker_pair(SamplePair &arrived, float2v &term_sum, float2v &ao)
+{
+    static_assert(PENDING == 0 || PENDING == 2 || PENDING == 4, "");
+    if constexpr (PENDING == 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(arrived.s1), "+v"(arrived.s2), "+v"(term_sum), "+v"(ao));
+    else if constexpr (PENDING == 2)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(arrived.s1), "+v"(arrived.s2), "+v"(term_sum), "+v"(ao));
+    else
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(arrived.s1), "+v"(arrived.s2), "+v"(term_sum), "+v"(ao));
+}
+
+template <int K, int P, int Q, int DEPTH>
+__device__ __forceinline__ void pipelined_checker_step(const TermConstants<false> &L, uint32_t base, float2v inv_depth, float reject,
+                                                       SamplePair (&ring)[DEPTH + 1], float2v &inv_range, float &neg_front,
+                                                       float2v &term_sum, float2v &ao)
+{
+    if constexpr (K < kCheckerPairs) {
+        constexpr int t = checker_term_of_pair(K), i = checker_index_in_term(K), n = checker_pairs_in_term(t);
+        issue_checker_pair<K + DEPTH, P, Q>(base, ring[(K + DEPTH) % (DEPTH + 1)]);
+        constexpr int behind = (K + DEPTH < kCheckerPairs ? DEPTH : kCheckerPairs - 1 - K);    // pairs issued after pair K
+        SamplePair &s = ring[K % (DEPTH + 1)];
+        wait_checker_pair<2 * behind>(s, term_sum, ao);
+        if constexpr (i == 0) {
+            inv_range = splat(L.inv_thickness[t]) * inv_depth;
+            neg_front = -L.front_depth[t];
+            if constexpr (MEAO_REN_VGPR_CONSTS) asm volatile("" : "+v"(neg_front));
+        }
+        const float2v d1 = float2v{mad(s.s1.x, inv_range.x, neg_front), mad(s.s1.y, inv_range.y, neg_front)};
+        const float2v d2 = float2v{mad(s.s2.x, inv_range.x, neg_front), mad(s.s2.y, inv_range.y, neg_front)};
+        const float2v r = float2v{pair_from_distances(d1.x, d2.x, reject), pair_from_distances(d1.y, d2.y, reject)};
+        if constexpr (i == 0) term_sum = r;
+        else term_sum = term_sum + r;                                       // (r0 + r1) (+ r2) (+ r3), REN:92-109
+        if constexpr (i == n - 1) ao = fma2(splat(L.weight[t]), term_sum, ao);
+        pipelined_checker_step<K + 1, P, Q, DEPTH>(L, base, inv_depth, reject, ring, inv_range, neg_front, term_sum, ao);
+    }
+}
+
+template <int P, int Q, int DEPTH>
+__device__ __forceinline__ float2v accumulate_terms_pipelined(const TermConstants<false> &L, const float *centre, float2v inv_depth)
+{
+    typedef __attribute__((address_space(3))) const float lds_float;
+    const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_float *)(centre - (4 * P + 4 * Q))));
+    SamplePair ring[DEPTH + 1];
+    float2v ao = splat(0.0f), term_sum = splat(0.0f), inv_range = splat(0.0f);
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) {
+        if (k == 0) issue_checker_pair<0, P, Q>(base, ring[0]);
+        if (k == 1) issue_checker_pair<1, P, Q>(base, ring[1]);
+    }
+    float reject = L.reject_fadeoff, neg_front = 0.0f;
+    if constexpr (MEAO_REN_VGPR_CONSTS) asm volatile("" : "+v"(reject));
+    pipelined_checker_step<0, P, Q, DEPTH>(L, base, inv_depth, reject, ring, inv_range, neg_front, term_sum, ao);
+    return fma2(splat(L.intensity), ao - splat(1.0f), splat(1.0f));   // lerp(1, ao, gIntensity) REN:176
+}
+
 // Workgroup ids are dealt round-robin to the 8 XCDs (id mod 8), each with its own L2.  This maps the
 // ids one XCD receives to a contiguous range of tiles, so that neighbouring tiles -- which share their
 // aprons -- share an L2.  Bijection of [0, n).
@@ -612,7 +760,11 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
         const float2v c = *reinterpret_cast<const float2v *>(centre);
         const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
         // the fast path assumes NaN-free distances: the body hostile frames (and RTNE storage, inf samples) run has it off
-        const float2v out = accumulate_terms<EXH, 4 * kRenLdsW, 4, MEAO_REN_FASTPATH && DIV == DIV_EXACT_RCP>(terms, centre, inv_depth);
+        float2v out;
+        if constexpr (MEAO_REN_SWPIPE && !EXH)
+            out = accumulate_terms_pipelined<4 * kRenLdsW, 4, MEAO_REN_SWPIPE_DEPTH>(terms, centre, inv_depth);
+        else
+            out = accumulate_terms<EXH, 4 * kRenLdsW, 4, MEAO_REN_FASTPATH && DIV == DIV_EXACT_RCP>(terms, centre, inv_depth);
 
         typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
         const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
@@ -779,15 +931,28 @@ __device__ __forceinline__ void blur_run(const BlurConsts &k, const float (&a)[N
 }
 
 // BilateralUpsample (UPS:177-183); taps already in weight order 9,3,1,3.
+// The uniform operands of the bilateral phase.  With MEAO_UPS_VGPR_CONSTS they are pinned in VGPRs: an
+// SGPR (or literal) source costs the VALU ~0.2 cycles per instruction (tools/ubench_issue.hip, "constants
+// in SGPRs"), and 9 of the 41 instructions per upsampled texel read one.
+struct BilateralConsts {
+    float tolerance, noise, three, nine;
+    __device__ __forceinline__ BilateralConsts(float upsample_tolerance, float noise_filter_strength)
+        : tolerance(upsample_tolerance), noise(noise_filter_strength), three(3.0f), nine(9.0f)
+    {
+        if constexpr (MEAO_UPS_VGPR_CONSTS) asm volatile("" : "+v"(tolerance), "+v"(noise), "+v"(three), "+v"(nine));
+    }
+};
+
 template <int DIV>
 __device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao, float d0, float d1, float d2,
                                                     float d3, float a0, float a1, float a2, float a3,
-                                                    float tolerance, float noise)
+                                                    const BilateralConsts &k)
 {
-    const float w0 = div_const<DIV, 9>(__builtin_fabsf(hi_depth - d0) + tolerance);
-    const float w1 = div_const<DIV, 3>(__builtin_fabsf(hi_depth - d1) + tolerance);
+    const float tolerance = k.tolerance, noise = k.noise;
+    const float w0 = div_const<DIV, 9>(__builtin_fabsf(hi_depth - d0) + tolerance, k.nine);
+    const float w1 = div_const<DIV, 3>(__builtin_fabsf(hi_depth - d1) + tolerance, k.three);
     const float w2 = div_const<DIV, 1>(__builtin_fabsf(hi_depth - d2) + tolerance);
-    const float w3 = div_const<DIV, 3>(__builtin_fabsf(hi_depth - d3) + tolerance);
+    const float w3 = div_const<DIV, 3>(__builtin_fabsf(hi_depth - d3) + tolerance, k.three);
     float total = ((w0 + w1) + w2) + w3;
     total = total + noise;
     float sum = a0 * w0;
@@ -813,8 +978,17 @@ struct UpsLds {
 
 // NESTED: the LoResAO1 taps (s_ao) were already produced in LDS by blend_window_into_lds (the
 // previous pass of the chain evaluated inside this workgroup) instead of being read from global memory.
-template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false>
-__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame)
+// Places inside an upsample tile where every thread of the workgroup can put unrelated global loads in flight:
+// after_prefetch()   the tile's own low-res window is in LDS (its loads have landed); blur and bilateral follow
+// before_bilateral() the hoisted hi-res operands have landed too: nothing in the bilateral phase waits on vmcnt
+struct NoHook {
+    static constexpr bool kBeforeBilateral = false;
+    __device__ __forceinline__ void after_prefetch() const {}
+    __device__ __forceinline__ void before_bilateral() const {}
+};
+
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook>
+__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
 {
     typedef AoTexel<AOFMT> AO;
     typedef typename AO::type ao_t;
@@ -850,6 +1024,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     // main_premin*: LoResAO1 = min(LoResAO1, LoResAO2) (COMBINE_LOWER_RESOLUTIONS, UPS:58-60)
     const ao_t *__restrict__ lo_ao2 = a.lo_ao2 ? frame_ptr(static_cast<const ao_t *>(a.lo_ao2), a.frame_stride, frame) : nullptr;
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
+    const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
 
 #if MEAO_UPS_HOIST
     // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
@@ -930,6 +1105,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         }
     }
     __syncthreads();
+    hook.after_prefetch();
 
     // ---- BlurHorizontally: runs of 4 outputs; output (r, c) is centred on raw column c+2.
     // (Columns 34, 35 of the last run are scratch: they read the row padding.)
@@ -980,6 +1156,18 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         for (int n = 0; n < T::kVRun; ++n) s_vb[(r0 + n) * T::kBlurPitch + c] = o[n];
     }
     __syncthreads();
+#if MEAO_UPS_HOIST
+    if constexpr (Hook::kBeforeBilateral && FINAL) {
+        // vmcnt retires in order: a load issued here would sit behind nothing only if the hoisted operands
+        // are waited for first -- naming them in an asm makes the compiler put that wait here
+#pragma unroll
+        for (int pass = 0; pass < kPasses; ++pass)
+            asm volatile("" : : "v"(hoist_hd16[pass][0]), "v"(hoist_hd16[pass][1]));
+        __builtin_amdgcn_sched_barrier(0);
+        hook.before_bilateral();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
 
     // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
@@ -1067,7 +1255,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                     dl[rr + gy[g2]][cc + gx[g2]], dl[rr + gy[g3]][cc + gx[g3]],
                     vb[rr + gy[g0]][cc + gx[g0]], vb[rr + gy[g1]][cc + gx[g1]],
                     vb[rr + gy[g2]][cc + gx[g2]], vb[rr + gy[g3]][cc + gx[g3]],
-                    a.upsample_tolerance, a.noise_filter_strength);
+                    bilateral_k);
                 res[e] = AO::template encode<RTNE>(v);
             }
             ao_t *o = dst + hrow;
@@ -1115,6 +1303,7 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
     const ao_t *__restrict__ hi_ao = frame_ptr(static_cast<const ao_t *>(in.hi_ao), in.frame_stride, frame);
     ao_t *__restrict__ dst = frame_ptr(static_cast<ao_t *>(in.dst[0]), in.frame_stride, frame);
     const BlurConsts bk = {in.step_size, in.blur_tolerance};
+    const BilateralConsts bilateral_k(in.upsample_tolerance, in.noise_filter_strength);
 
     // low-res texels the window's bilateral taps touch: D = (X+1)>>1 and D-1, X clamped to the level
     const int cx_min = clampi(vx0, 0, hw - 1), cx_max = clampi(vx0 + win_w - 1, 0, hw - 1);
@@ -1166,7 +1355,7 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
         }
         const size_t at = static_cast<size_t>(Y) * hw + X;
         const float v = bilateral_upsample<DIV>(hi_depth[at], AO::decode(hi_ao[at]), dk[0], dk[1], dk[2], dk[3], ak[0], ak[1],
-                                                ak[2], ak[3], in.upsample_tolerance, in.noise_filter_strength);
+                                                ak[2], ak[3], bilateral_k);
         const ao_t q = AO::template encode<RTNE>(v);
         out[wr * out_pitch + wc] = AO::decode(q);
         if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) dst[at] = q;
@@ -1208,16 +1397,16 @@ __global__ __launch_bounds__(kThreads) void upsample_two_level_kernel(const Upsa
 }
 
 // The (rare) hostile-frame variant of a tile: the same code with IEEE division.
-template <int AOFMT, bool RTNE, bool FINAL, int DIV>
-__device__ __forceinline__ void upsample_tile_checked(const UpsampleArgs &a, float *smem, int tile, int frame)
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, typename Hook = NoHook>
+__device__ __forceinline__ void upsample_tile_checked(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
 {
     if constexpr (DIV == DIV_EXACT_RCP) {
         if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
-            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE>(a, smem, tile, frame);
+            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE, false, Hook>(a, smem, tile, frame, hook);
             return;
         }
     }
-    upsample_tile<AOFMT, RTNE, FINAL, DIV>(a, smem, tile, frame);
+    upsample_tile<AOFMT, RTNE, FINAL, DIV, false, Hook>(a, smem, tile, frame, hook);
 }
 
 template <int AOFMT, bool RTNE, bool FINAL, int DIV>
@@ -1226,6 +1415,18 @@ __global__ __launch_bounds__(kThreads, FINAL ? 7 : 1) void upsample_kernel(const
     __shared__ __attribute__((aligned(16))) float smem[UpsLds<FINAL>::kFloats];
     upsample_tile_checked<AOFMT, RTNE, FINAL, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
+
+// Hook of the fused last kernel (MEAO_FUSE_SPLIT_DS): puts the four 16-byte depth loads of the carried
+// downsample tile in flight inside the upsample tile; 1 = after its prefetch, 2 = before its bilateral phase.
+struct IssueCarriedLoads {
+    static constexpr bool kBeforeBilateral = MEAO_FUSE_SPLIT_DS == 2;
+    const DownsampleArgs &d;
+    float (&v)[kDsTileH / kDsRowsPerPass][4];
+    bool mine;
+    __device__ __forceinline__ void issue() const { if (mine) downsample_tile_load<true, true>(d, blockIdx.x, blockIdx.z, v); }
+    __device__ __forceinline__ void after_prefetch() const { if constexpr (!kBeforeBilateral) issue(); }
+    __device__ __forceinline__ void before_bilateral() const { if constexpr (kBeforeBilateral) issue(); }
+};
 
 // Upsample.main of this batch carrying the downsample pass of the NEXT batch (meao_prefetch_batch):
 // the final upsample is VALU-bound (five exact divides per texel) and leaves HBM idle, the
@@ -1247,8 +1448,27 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsamp
                 else downsample_tile<RTNE, false, DIV>(d, t, f);
             }
     };
+#if MEAO_FUSE_SPLIT_DS
+    // One downsample tile per workgroup (the usual case: both grids tile the same frame) with 16-byte f32
+    // loads: its four loads per lane go out after the upsample tile's prefetch wait -- issued earlier they
+    // would sit in front of that wait (vmcnt counts in order) -- and are consumed after the bilateral phase.
+    const int ds_tiles = d.tiles_x * d.tiles_y;
+    const bool split = d.vec_ok != 0 && d.depth_format == MEAO_DEPTH_F32 && gridDim.x >= static_cast<unsigned>(ds_tiles) &&
+                       gridDim.z >= static_cast<unsigned>(d.frames);
+    if (!split) {
+        carried_downsample();
+        upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
+        return;
+    }
+    const bool mine = blockIdx.x < static_cast<unsigned>(ds_tiles) && blockIdx.z < static_cast<unsigned>(d.frames);
+    float v[kDsTileH / kDsRowsPerPass][4];
+    const IssueCarriedLoads issue = {d, v, mine};
+    upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z, issue);
+    if (mine) downsample_tile_finish<RTNE, true, DIV>(d, blockIdx.x, blockIdx.z, v);
+#else
     carried_downsample();
     upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

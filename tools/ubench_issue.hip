@@ -54,6 +54,22 @@ struct Stamp { unsigned long long cycles, realtime; };
         out[blockIdx.x * 256 + threadIdx.x] = s;                                          \
     }
 
+// the same with b, c as SGPR operands (uniform kernel arguments), %1 = b, %2 = c
+#define KERNEL_F32_SGPR(NAME, ASM)                                                        \
+    __global__ __launch_bounds__(256) void NAME(float *out, Stamp *stamps, int iters, float b, float c) \
+    {                                                                                     \
+        float a[16];                                                                      \
+        for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i;                     \
+        PROLOGUE                                                                          \
+        for (int it = 0; it < iters; ++it) {                                              \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile(ASM : "+v"(a[i]) : "s"(b), "s"(c)); \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile(ASM : "+v"(a[i]) : "s"(b), "s"(c)); \
+        }                                                                                 \
+        EPILOGUE                                                                          \
+        float s = 0; for (int i = 0; i < 16; ++i) s += a[i];                              \
+        out[blockIdx.x * 256 + threadIdx.x] = s;                                          \
+    }
+
 #define KERNEL_PK(NAME, ASM)                                                              \
     __global__ __launch_bounds__(256) void NAME(float *out, Stamp *stamps, int iters, float b, float c) \
     {                                                                                     \
@@ -86,6 +102,21 @@ KERNEL_F32(k_rcp, "v_rcp_f32 %0, %0")
 KERNEL_F32(k_cvt_pkrtz, "v_cvt_pkrtz_f16_f32 %0, %0, %1")
 KERNEL_F32(k_cvt_f32_f16, "v_cvt_f32_f16 %0, %0")
 KERNEL_F32(k_div_fixup, "v_div_fixup_f32 %0, %0, %1, %2")
+KERNEL_F32(k_sub, "v_sub_f32 %0, %0, %1")
+KERNEL_F32(k_fmac, "v_fmac_f32 %0, %1, %2")
+KERNEL_F32(k_add_u32, "v_add_u32 %0, %0, %1")
+KERNEL_F32(k_lshl_add_u32, "v_lshl_add_u32 %0, %0, 2, %1")
+KERNEL_F32(k_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2")
+KERNEL_F32(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1")
+KERNEL_F32(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL_F32(k_cvt_u32_f32, "v_cvt_u32_f32 %0, %0")
+KERNEL_F32(k_cvt_f32_ubyte0, "v_cvt_f32_ubyte0 %0, %0")
+KERNEL_F32(k_min_f32, "v_min_f32 %0, %0, %1")
+KERNEL_F32_SGPR(k_add_sgpr, "v_add_f32 %0, %1, %0")
+KERNEL_F32_SGPR(k_fma_sgpr, "v_fma_f32 %0, %0, %0, %2")
+KERNEL_F32_SGPR(k_mul_sgpr, "v_mul_f32 %0, %1, %0")
+KERNEL_F32(k_mul_literal, "v_mul_f32 %0, 0x3f7fbe77, %0")
+KERNEL_PK(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 2, %1")
 KERNEL_PK(k_pk_fma, "v_pk_fma_f32 %0, %0, %1, %2")
 KERNEL_PK(k_pk_mul, "v_pk_mul_f32 %0, %0, %1")
 KERNEL_PK(k_pk_add, "v_pk_add_f32 %0, %0, %1")
@@ -125,6 +156,34 @@ __global__ __launch_bounds__(256) void k_render_mix_spread(float *out, Stamp *st
             asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d2) : "v"(s[4 * p + 1]), "v"(ir[p]), "v"(c));
             asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(p1) : "v"(d1), "v"(b));
             asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(p2) : "v"(d2), "v"(b));
+            asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(u1) : "v"(d1), "v"(p2), "v"(one));
+            asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(u2) : "v"(d2), "v"(p1), "v"(one));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(sum) : "v"(u1), "v"(u2));
+            asm volatile("v_fma_f32 %0, -%1, %2, %3 clamp" : "=v"(acc[p]) : "v"(p1), "v"(p2), "v"(sum));
+            s[4 * p + 2] = acc[p];
+        }
+    }
+    EPILOGUE
+    out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3] + s[2] + s[6] + s[10] + s[14];
+}
+
+// the same, with the per-term constants where the compiled kernel has them: -frontDepth and the reject
+// fade-off as SGPR operands of v_fma_f32 / v_mul_f32 (one constant-bus read each)
+__global__ __launch_bounds__(256) void k_render_mix_sgpr(float *out, Stamp *stamps, int iters, float b, float c)
+{
+    float s[16], ir[4], acc[4];
+    for (int i = 0; i < 16; ++i) s[i] = threadIdx.x * 0.001f + i;
+    for (int i = 0; i < 4; ++i) { ir[i] = b + i * 1e-3f; acc[i] = 0.0f; }
+    const float one = 1.0f;
+    PROLOGUE
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float d1, d2, p1, p2, u1, u2, sum;
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d1) : "v"(s[4 * p]), "v"(ir[p]), "s"(c));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d2) : "v"(s[4 * p + 1]), "v"(ir[p]), "s"(c));
+            asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(p1) : "v"(d1), "s"(b));
+            asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(p2) : "v"(d2), "s"(b));
             asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(u1) : "v"(d1), "v"(p2), "v"(one));
             asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(u2) : "v"(d2), "v"(p1), "v"(one));
             asm volatile("v_add_f32 %0, %1, %2" : "=v"(sum) : "v"(u1), "v"(u2));
@@ -285,9 +344,16 @@ int main(int argc, char **argv)
         {"v_cmp_gt_f32", k_cmp, 32}, {"v_cmp_class_f32", k_cmp_class, 32}, {"v_cndmask_b32 (e64)", k_cndmask, 32},
         {"v_rcp_f32", k_rcp, 32}, {"v_cvt_pkrtz_f16_f32", k_cvt_pkrtz, 32}, {"v_cvt_f32_f16", k_cvt_f32_f16, 32},
         {"v_div_fixup_f32", k_div_fixup, 32},
+        {"v_sub_f32", k_sub, 32}, {"v_fmac_f32 (VOP2)", k_fmac, 32}, {"v_min_f32", k_min_f32, 32},
+        {"v_add_u32", k_add_u32, 32}, {"v_lshl_add_u32", k_lshl_add_u32, 32}, {"v_mad_u32_u24", k_mad_u32_u24, 32},
+        {"v_mul_lo_u32", k_mul_lo_u32, 32}, {"v_and_or_b32", k_and_or, 32}, {"v_cvt_u32_f32", k_cvt_u32_f32, 32},
+        {"v_cvt_f32_ubyte0", k_cvt_f32_ubyte0, 32}, {"v_lshl_add_u64", k_lshl_add_u64, 32},
+        {"v_add_f32, one SGPR source", k_add_sgpr, 32}, {"v_mul_f32, one SGPR source", k_mul_sgpr, 32},
+        {"v_fma_f32, one SGPR source", k_fma_sgpr, 32}, {"v_mul_f32, 32-bit literal source", k_mul_literal, 32},
         {"v_pk_fma_f32", k_pk_fma, 32}, {"v_pk_mul_f32", k_pk_mul, 32}, {"v_pk_add_f32", k_pk_add, 32},
         {"v_fma_f32, three distinct rotating sources", k_fma_three_sources, 32},
         {"render pair mix, operands spread over 24 regs", k_render_mix_spread, 32},
+        {"render pair mix, spread, constants in SGPRs", k_render_mix_sgpr, 32},
         {"v_fma_f32 dependent chain", k_fma_dependent, 32},
         {"render pair mix (8 instr / texel pair-op)", k_render_mix, 32},
         {"render pair mix, packed (10 instr / 2 texels)", k_render_mix_pk, 40},
