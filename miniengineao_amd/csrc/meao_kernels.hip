@@ -54,6 +54,9 @@
 #ifndef MEAO_FUSE_SPLIT_DS
 #define MEAO_FUSE_SPLIT_DS 2    // fused last kernel: the carried downsample tile's loads are issued inside the upsample tile
 #endif                          // (1 = after its prefetch, 2 = before its bilateral phase) and consumed after it; 0 = tile first
+#ifndef MEAO_UPS_LOADS_ORDER
+#define MEAO_UPS_LOADS_ORDER 1  // interior upsample tiles: low-res window loads first, hoisted hi-res loads behind them, all
+#endif                          // straight-line (vmcnt retires in order: the window wait then no longer includes the hi-res loads)
 #ifndef MEAO_REN_FASTPATH
 #define MEAO_REN_FASTPATH 0     // wave-uniform "all distances >= 0" path in the render kernel (bit-exact; slower, see test_samples)
 #endif
@@ -1034,14 +1037,19 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     float4v hoist_hd32[kPasses][2];
     typename AO::type4 hoist_ha[kPasses][2];
     const bool hoist_ok = a.vec_ok != 0;
-    if (hoist_ok) {
-        const int htx = threadIdx.x & 15, hhx0 = HX0 + 4 * htx;
+    // CLAMPED: every lane loads (out-of-frame lanes re-read the frame's last row / quad and never use it), so
+    // that the code is branch-free and the compiler's s_waitcnt counts stay exact
+    auto issue_hoisted = [&](auto clamped) {
+        constexpr bool CLAMPED = decltype(clamped)::value;
+        const int htx = threadIdx.x & 15;
+        const int hhx0 = CLAMPED ? min(HX0 + 4 * htx, hw - 4) : HX0 + 4 * htx;
 #pragma unroll
         for (int pass = 0; pass < kPasses; ++pass)
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                const int hy = HY0 + 2 * ((threadIdx.x >> 4) + 16 * pass) + f;
-                if (hhx0 < hw && hy < hh) {
+                const int hy_raw = HY0 + 2 * ((threadIdx.x >> 4) + 16 * pass) + f;
+                const int hy = CLAMPED ? min(hy_raw, hh - 1) : hy_raw;
+                if (CLAMPED || (hhx0 < hw && hy < hh)) {
                     const size_t hrow = static_cast<size_t>(hy) * hw + hhx0;
                     if constexpr (FINAL) {
                         hoist_hd16[pass][f] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(
@@ -1054,12 +1062,66 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                     }
                 }
             }
-    }
+    };
+    // interior tile, 16-byte loads everywhere, no second AO input: window loads first (see below)
+    const bool window_first = MEAO_UPS_LOADS_ORDER && !NESTED && hoist_ok && !lo_ao2 && ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
+    if (hoist_ok && !window_first) issue_hoisted(std::false_type());
 #endif
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
     // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
     const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
+#if MEAO_UPS_HOIST && MEAO_UPS_LOADS_ORDER
+    if (window_first) {
+        // The window comes from L2 (written by the previous pass), the hi-res operands of the final pass from
+        // HBM; vmcnt retires loads in issue order, so with the hi-res loads in front the window wait lasts an
+        // HBM latency.  Here: all window loads of the lane, then the hi-res loads, then the window is consumed.
+        constexpr int kItems = 10 * T::kRawH, kRounds = (kItems + kThreads - 1) / kThreads;
+        float4v wd[kRounds];
+        typename AO::type4 wa[kRounds];
+#pragma unroll
+        for (int round = 0; round < kRounds; ++round) {
+            const int i = min(static_cast<int>(threadIdx.x) + round * kThreads, kItems - 1);
+            const int r = i / 10, k = i % 10;
+            const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
+            const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
+            wd[round] = *reinterpret_cast<const float4v *>(lo_depth + idx);
+            if constexpr (!NESTED) wa[round] = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
+        issue_hoisted(std::true_type());
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int round = 0; round < kRounds; ++round) {
+            // an unconditional use: the compiler would otherwise sink the loads of the partial last round into
+            // its branch, behind the hi-res loads
+            asm volatile("" : : "v"(wd[round]));
+            if constexpr (!NESTED) {
+                typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type bits_t;
+                asm volatile("" : : "v"(__builtin_bit_cast(bits_t, wa[round])));
+            }
+            const int i = threadIdx.x + round * kThreads;
+            if (i < kItems) {
+                const int r = i / 10, k = i % 10;
+                const float dv[4] = {wd[round].x, wd[round].y, wd[round].z, wd[round].w};
+                float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (!NESTED) {
+                    av[0] = AO::decode(wa[round].x); av[1] = AO::decode(wa[round].y);
+                    av[2] = AO::decode(wa[round].z); av[3] = AO::decode(wa[round].w);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * k + e - 1;
+                    if (c >= 0 && c < T::kRawW) {
+                        if (dep_kept(r, c)) dep_at(r, c) = dv[e];
+                        s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
+                        if constexpr (!NESTED) s_ao[r * T::kRawPitch + c] = av[e];
+                    }
+                }
+            }
+        }
+    } else
+#endif
     if (interior_x) {
         // no horizontal clamping inside this tile: one aligned 16-byte depth load (+ 4 AO texels)
         // per lane covers the 40-texel row segment [LX0-4, LX0+35]
