@@ -57,6 +57,9 @@
 #ifndef MEAO_UPS_LOADS_ORDER
 #define MEAO_UPS_LOADS_ORDER 1  // interior upsample tiles: low-res window loads first, hoisted hi-res loads behind them, all
 #endif                          // straight-line (vmcnt retires in order: the window wait then no longer includes the hi-res loads)
+#ifndef MEAO_DS_LEAN
+#define MEAO_DS_LEAN 0          // downsample tile: 32-bit byte offsets from uniform bases (saddr addressing), arguments pinned in
+#endif                          // SGPRs, the four f16 conversions of a row as two v_cvt_pkrtz_f16_f32
 #ifndef MEAO_REN_FASTPATH
 #define MEAO_REN_FASTPATH 0     // wave-uniform "all distances >= 0" path in the render kernel (bit-exact; slower, see test_samples)
 #endif
@@ -186,6 +189,15 @@ __device__ __forceinline__ T *frame_ptr(T *base, uint64_t stride_bytes, int fram
     return reinterpret_cast<T *>(reinterpret_cast<byte_t *>(base) + stride_bytes * static_cast<uint64_t>(frame));
 }
 
+// Uniform base + 32-bit byte offset: the form the global_load/store "saddr" addressing mode takes (SGPR base,
+// zero-extended VGPR offset), no 64-bit VALU address arithmetic.  Every intermediate of a frame is < 4 GB.
+template <typename T>
+__device__ __forceinline__ T *at_byte_offset(T *uniform_base, uint32_t byte_offset)
+{
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type byte_t;
+    return reinterpret_cast<T *>(reinterpret_cast<byte_t *>(uniform_base) + byte_offset);
+}
+
 // ------------------------------------------------------------------------------------------
 // Exact division without the generic IEEE expansion.
 //
@@ -303,7 +315,9 @@ __device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, in
         if (y < H) {
             const size_t at = static_cast<size_t>(y) * W + x0;
             if (F32_ONLY || a.depth_format == MEAO_DEPTH_F32) {
-                const float *row = static_cast<const float *>(depth) + at;
+                const float *row = MEAO_DS_LEAN ? at_byte_offset(static_cast<const float *>(depth),
+                                                                 (static_cast<uint32_t>(y) * static_cast<uint32_t>(W) + static_cast<uint32_t>(x0)) * 4u)
+                                                : static_cast<const float *>(depth) + at;
                 if constexpr (VEC) {
                     const float4v q = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(row));
                     v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
@@ -360,6 +374,15 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
     const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
     const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
     if (x0 >= W) return;
+#if MEAO_DS_LEAN
+    // level widths and Z-buffer parameters once, in SGPRs (left to itself the compiler re-issues the s_load of
+    // every one of them inside each store branch, with an s_waitcnt lgkmcnt(0) behind it)
+    uint32_t w1 = a.w[1], w2 = a.w[2], w3 = a.w[3], w4 = a.w[4];
+    float zp0 = a.zp0, zp1 = a.zp1;
+    asm volatile("" : "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(zp0), "+s"(zp1));
+#else
+    const float zp0 = a.zp0, zp1 = a.zp1;
+#endif
 #pragma unroll
     for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
         const int y = yb + k * kDsRowsPerPass;
@@ -371,19 +394,48 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
             bool nice = true;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                nice = nice && nice_denominator(mad(a.zp0, v[k][e], a.zp1));
-                lin[e] = linearize<DIV_EXACT_RCP>(v[k][e], a.zp0, a.zp1, sky_depth);
+                nice = nice && nice_denominator(mad(zp0, v[k][e], zp1));
+                lin[e] = linearize<DIV_EXACT_RCP>(v[k][e], zp0, zp1, sky_depth);
             }
             if (__builtin_expect(!nice, 0)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[k][e], a.zp0, a.zp1, sky_depth);
+                for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[k][e], zp0, zp1, sky_depth);
                 a.hostile[frame] = a.generation;     // racing stores of the same value
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], a.zp0, a.zp1, sky_depth);
+            for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], zp0, zp1, sky_depth);
         }
 
+#if MEAO_DS_LEAN
+        if constexpr (VEC) {
+            const uint32_t ux = x0, uy = y;
+            uint32_t lo, hi;                                              // LinearZ[st] = dist (DS1:46)
+            if constexpr (RTNE) {
+                lo = f32_to_f16_bits<true>(lin[0]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[1])) << 16);
+                hi = f32_to_f16_bits<true>(lin[2]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[3])) << 16);
+            } else {
+                lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[0], lin[1]));
+                hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[2], lin[3]));
+            }
+            typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(uint2v{lo, hi}, reinterpret_cast<uint2v *>(
+                at_byte_offset(linear, (uy * static_cast<uint32_t>(W) + ux) * 2u)));
+            if ((y & 1) == 0) {                                           // DS2x (DS1:64-70)
+                __builtin_nontemporal_store(float2v{lin[0], lin[2]}, reinterpret_cast<float2v *>(
+                    at_byte_offset(low1, ((uy >> 1) * w1 + (ux >> 1)) * 4u)));
+                if ((y & 3) == 0) {                                       // DS4x (DS1:73-77)
+                    *at_byte_offset(low2, ((uy >> 2) * w2 + (ux >> 2)) * 4u) = lin[0];
+                    if ((y & 7) == 0 && (x0 & 7) == 0) {                  // DS8x (DS2:35-40)
+                        *at_byte_offset(low3, ((uy >> 3) * w3 + (ux >> 3)) * 4u) = lin[0];
+                        if ((y & 15) == 0 && (x0 & 15) == 0)              // DS16x (DS2:43-49)
+                            *at_byte_offset(low4, ((uy >> 4) * w4 + (ux >> 4)) * 4u) = lin[0];
+                    }
+                }
+            }
+            continue;
+        }
+#endif
         uint16_t *lrow = linear + static_cast<size_t>(y) * W + x0;    // LinearZ[st] = dist (DS1:46)
         if constexpr (VEC) {
             ushort4v h;
