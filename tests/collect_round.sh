@@ -1,0 +1,18 @@
+# usage: bash tests/collect_round.sh <tag> [frames-per-launch=16]   (here, after `gpurun ... tests/run_gpu_round.sh <tag>`)
+# copies the judged evidence of a round from gpurun_out/ (scratch) into profiles/ (tracked)
+set -e
+T=$1; N=${2:-16}
+python tests/rocprof_timed_region.py gpurun_out/prof_$T/trace_kernel_trace.csv 30 > profiles/${T}_kernel_trace_timed_region.txt
+cp gpurun_out/prof_$T/trace_kernel_stats.csv profiles/${T}_kernel_stats.csv
+cp gpurun_out/bench_$T.json profiles/${T}_bench_4k_batch16.json
+cp gpurun_out/bench_${T}_1080p.json profiles/${T}_bench_1080p_batch64.json
+cp gpurun_out/bench_${T}_8k.json profiles/${T}_bench_8k_f16_batch4.json
+cp gpurun_out/bench_${T}_shaded.json profiles/${T}_bench_4k_shaded.json
+cp gpurun_out/bench_force_dist_$T.log profiles/${T}_bench_force_dist.log
+cp gpurun_out/fuzz_$T.log profiles/${T}_fuzz_gpu.log
+cp gpurun_out/pytest_gpu_$T.log profiles/${T}_pytest_gpu.log
+cp gpurun_out/ubench_issue_$T.txt profiles/${T}_ubench_issue.txt
+cp gpurun_out/ubench_lds_$T.txt profiles/${T}_ubench_lds.txt
+python tests/pmc_summary.py gpurun_out/pmc_$T > profiles/${T}_pmc_summary.txt
+python tests/make_pmc_traffic.py gpurun_out/pmc_$T 4k $N > /dev/null
+ls -la profiles/${T}_*
