@@ -285,6 +285,38 @@ def test_pipelined_downsample(oracle, variant, w, h, batch):
         ao.close()
 
 
+@pytest.mark.parametrize("depth_format", [0, 3, 1])             # f32, f16, unorm16
+@pytest.mark.parametrize("w,h,batch", [(132, 40, 2), (260, 36, 1), (512, 256, 2), (192, 108, 3)])
+def test_pipelined_downsample_tile_counts_and_formats(oracle, w, h, batch, depth_format):
+    """The last kernel carries the next call's downsample tiles one per workgroup with their loads issued
+    inside the upsample tile (16-byte f32 rows), and falls back to "tiles first" otherwise: more downsample
+    tiles than upsample tiles (132x40: 4 vs 3; 260x36: 6 vs 5), 16-bit depth formats, odd batches."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = H.settings(oracle, w, h, depth_format=depth_format)
+    ao = H.component(s, max_batch=batch, depth_format=depth_format, pipelined=True)
+    try:
+        sets = [[oracle.encode_depth(synth.make("S2", w, h, seed=31 * k + f), depth_format) for f in range(batch)]
+                for k in range(4)]
+        as_torch = lambda f: torch.from_numpy(f.view(np.int16) if f.dtype == np.uint16 else f).to(dev)   # noqa: E731
+        d_in = [[as_torch(np.ascontiguousarray(f)) for f in fs] for fs in sets]
+        d_out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(batch)]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for k in range(4):
+            if k + 1 < 4:
+                ao.prefetch_device([t.data_ptr() for t in d_in[k + 1]])
+            ao.execute_device([t.data_ptr() for t in d_in[k]], [t.data_ptr() for t in d_out], stream)
+            torch.cuda.synchronize(dev)
+            for f in range(batch):
+                want = oracle.run(sets[k][f], s, result_only=(k != 2))
+                assert np.array_equal(d_out[f].cpu().numpy(), want["result"]), (k, f)
+                if k == 2:          # every intermediate of a consumed, carried downsample set
+                    for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+                        assert np.array_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]]), (H.NAMES[i], f)
+    finally:
+        ao.close()
+
+
 # ---- round 2: contract enforcement, robustness of the boundary ------------------------------------
 
 def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
