@@ -70,6 +70,7 @@ struct meao_ctx {
     // Upsample L4->L3 evaluated inside the L3->L2 launch (upsample_two_level_kernel); on unless the
     // A/B switch MEAO_DEBUG_NO_FUSED_BLEND=1 was set when the context was created
     bool fuse_coarse_blend = true;
+    int nested_max_tiles = 512;        // calls with at most this many L2->L1 tiles (frames x tiles) run the three blend passes as one launch
 
     // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue)
     CompositeBatchArgs pending_comp{};
@@ -475,7 +476,18 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         MEAO_HIP(ctx, launch_render_wide(render_args(1, c.num_levels, true), c.ao_format, n, stream));
         MEAO_HIP(ctx, end(MEAO_PASS_RENDER_HQ, stream));
     }
-    if (ctx->fuse_coarse_blend && c.num_levels == 4 && c.hq_levels == 0) {
+    bool blend_done = false;
+    const int l1_tiles = ((p.mip[1].w + kUpsTileW - 1) / kUpsTileW) * ((p.mip[1].h + ups_tile_h(false) - 1) / ups_tile_h(false));
+    if (ctx->fuse_coarse_blend && c.num_levels == 4 && c.hq_levels == 0 && n * l1_tiles <= ctx->nested_max_tiles) {
+        // a small frame or two per call (at most two workgroups per CU): all three blend passes in one launch --
+        // their latency chains, not their arithmetic, are what such a call waits for (1080p: 39.2 -> 36.9 us per
+        // frame; at 4K, 1020 tiles, it is a wash).  Combined3 and Combined2 are still written
+        TraceRange tr(ctx, "meao:upsample_L4_to_L3+L3_to_L2+L2_to_L1");
+        MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_1, stream));
+        MEAO_HIP(ctx, launch_upsample_three_level(upsample_args(1), upsample_args(2), upsample_args(3), c.ao_format, n, stream));
+        MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_1, stream));
+        blend_done = true;
+    } else if (ctx->fuse_coarse_blend && c.num_levels == 4 && c.hq_levels == 0) {
         // L4 -> L3 inside the L3 -> L2 launch: one launch, one latency-bound pass less (Combined3 is still written)
         TraceRange tr(ctx, "meao:upsample_L4_to_L3+L3_to_L2");
         MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_2, stream));
@@ -487,7 +499,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             if (rc != MEAO_OK) return rc;
         }
     }
-    if (c.num_levels >= 2) {
+    if (c.num_levels >= 2 && !blend_done) {
         const int rc = launch_blend(1, stream);
         if (rc != MEAO_OK) return rc;
     }
@@ -715,6 +727,7 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
     ctx->cfg = *cfg;
     const char *no_fuse = std::getenv("MEAO_DEBUG_NO_FUSED_BLEND");
     ctx->fuse_coarse_blend = !(no_fuse && no_fuse[0] == '1');
+    if (const char *m = std::getenv("MEAO_DEBUG_NESTED_MAX_TILES")) ctx->nested_max_tiles = std::atoi(m);   // A/B switch
     meao_default_params(&ctx->prm);
     int rc = use_device(ctx);
     if (rc == MEAO_OK) {

@@ -1398,7 +1398,25 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
 constexpr int kNestLowW = 21, kNestLowH = 13, kNestRawW = kNestLowW + 4, kNestRawH = kNestLowH + 4;
 constexpr int kNestScratch = 3 * kNestRawW * kNestRawH + kNestLowW * kNestRawH + kNestLowW * kNestLowH;
 
-template <int AOFMT, bool RTNE, int DIV>
+// The low-res texels a window of the pass's output level touches (bilateral taps D = (X+1)>>1 and D-1, X clamped
+// to the level) and, two further out on every side, the raw LoResAO1 / LoResDB taps of the blur (virtual
+// coordinates, clamped on load).
+struct NestExtent {
+    int dx_lo, dy_lo, nlw, nlh, rx0, ry0, rw, rh;
+    __device__ __forceinline__ NestExtent(const UpsampleArgs &in, int vx0, int vy0, int win_w, int win_h)
+    {
+        const int cx_min = clampi(vx0, 0, in.hw - 1), cx_max = clampi(vx0 + win_w - 1, 0, in.hw - 1);
+        const int cy_min = clampi(vy0, 0, in.hh - 1), cy_max = clampi(vy0 + win_h - 1, 0, in.hh - 1);
+        dx_lo = ((cx_min + 1) >> 1) - 1; nlw = ((cx_max + 1) >> 1) - dx_lo + 1;
+        dy_lo = ((cy_min + 1) >> 1) - 1; nlh = ((cy_max + 1) >> 1) - dy_lo + 1;
+        rx0 = dx_lo - 2; ry0 = dy_lo - 2; rw = nlw + 4; rh = nlh + 4;
+    }
+};
+
+// TAPS_IN_LDS: the raw LoResAO1 taps (scratch[r * kNestRawW + c], r < rh, c < rw of NestExtent) were produced by
+// another blend_window_into_lds call (the pass below, evaluated for exactly that window) instead of being
+// read from Combined<k+1> in global memory.
+template <int AOFMT, bool RTNE, int DIV, bool TAPS_IN_LDS = false>
 __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, float *out, int out_pitch, int vx0, int vy0,
                                                       int win_w, int win_h, float *scratch, int frame, int own_x0,
                                                       int own_y0, int own_w, int own_h)
@@ -1419,12 +1437,9 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
     const BlurConsts bk = {in.step_size, in.blur_tolerance};
     const BilateralConsts bilateral_k(in.upsample_tolerance, in.noise_filter_strength);
 
-    // low-res texels the window's bilateral taps touch: D = (X+1)>>1 and D-1, X clamped to the level
-    const int cx_min = clampi(vx0, 0, hw - 1), cx_max = clampi(vx0 + win_w - 1, 0, hw - 1);
-    const int cy_min = clampi(vy0, 0, hh - 1), cy_max = clampi(vy0 + win_h - 1, 0, hh - 1);
-    const int dx_lo = ((cx_min + 1) >> 1) - 1, nlw = ((cx_max + 1) >> 1) - dx_lo + 1;
-    const int dy_lo = ((cy_min + 1) >> 1) - 1, nlh = ((cy_max + 1) >> 1) - dy_lo + 1;
-    const int rx0 = dx_lo - 2, ry0 = dy_lo - 2, rw = nlw + 4, rh = nlh + 4;      // raw taps (virtual, clamped on load)
+    const NestExtent ext(in, vx0, vy0, win_w, win_h);
+    const int dx_lo = ext.dx_lo, dy_lo = ext.dy_lo, nlw = ext.nlw, nlh = ext.nlh;
+    const int rx0 = ext.rx0, ry0 = ext.ry0, rw = ext.rw, rh = ext.rh;           // raw taps (virtual, clamped on load)
 
     for (int i = threadIdx.x; i < rw * rh; i += kThreads) {
         const int r = i / rw, c = i % rw;
@@ -1432,7 +1447,7 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
         const float d = lo_depth[idx];
         r_dep[r * kNestRawW + c] = d;
         r_inv[r * kNestRawW + c] = rcp_strict<DIV>(d);                       // UPS:67
-        r_ao[r * kNestRawW + c] = AO::decode(lo_ao[idx]);
+        if constexpr (!TAPS_IN_LDS) r_ao[r * kNestRawW + c] = AO::decode(lo_ao[idx]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nlw * rh; i += kThreads) {                     // BlurHorizontally, one output per lane
@@ -1528,6 +1543,46 @@ __global__ __launch_bounds__(kThreads, FINAL ? 7 : 1) void upsample_kernel(const
 {
     __shared__ __attribute__((aligned(16))) float smem[UpsLds<FINAL>::kFloats];
     upsample_tile_checked<AOFMT, RTNE, FINAL, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
+}
+
+// ---- one frame per call: L4 -> L3 and L3 -> L2 inside the L2 -> L1 launch ---------------------------------
+// With one or two frames per call the three blend passes are three launches of a few hundred workgroups that
+// each wait out a memory round trip and three barriers; their arithmetic is nothing.  Here every L2 -> L1 tile
+// evaluates the window of Combined2 it reads (as in the two-level launch), and for that the window of
+// Combined3 those taps come from: inner -> the raw-tap array of mid -> the raw-tap array of the outer tile.
+// ~2.6x the arithmetic of the two small passes, one launch and one latency chain instead of three; both
+// intermediate buffers are still written (each tile its own 16 x 8 of Combined3 and 32 x 16 of Combined2).
+template <int AOFMT, bool RTNE, int DIV>
+__device__ __forceinline__ void upsample_three_level_tile(const UpsampleArgs &outer, const UpsampleArgs &mid, const UpsampleArgs &inner,
+                                                          float *smem, int tile, int frame)
+{
+    typedef UpsTile<ups_tile_h(false)> T;
+    typedef UpsLds<false> Lds;
+    float *const s_ao = smem + Lds::kInvN + Lds::kHbN + Lds::kDepN;      // raw taps of the outer tile
+    float *const inner_scratch = smem + Lds::kFloats;
+    const int tile_x = tile % outer.tiles_x, tile_y = tile / outer.tiles_x;
+    const int LX0 = (tile_x * kUpsTileW) >> 1, LY0 = (tile_y * ups_tile_h(false)) >> 1;      // L2 coordinates
+    const NestExtent mid_ext(mid, LX0 - 3, LY0 - 3, T::kRawW, T::kRawH);                   // what mid reads of Combined3
+    blend_window_into_lds<AOFMT, RTNE, DIV>(inner, smem, kNestRawW, mid_ext.rx0, mid_ext.ry0, mid_ext.rw, mid_ext.rh,
+                                            inner_scratch, frame, LX0 >> 1, LY0 >> 1, T::kLowW / 2, T::kLowH / 2);
+    blend_window_into_lds<AOFMT, RTNE, DIV, true>(mid, s_ao, T::kRawPitch, LX0 - 3, LY0 - 3, T::kRawW, T::kRawH, smem, frame,
+                                                  LX0, LY0, T::kLowW, T::kLowH);
+    upsample_tile<AOFMT, RTNE, false, DIV, true>(outer, smem, tile, frame);
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(kThreads) void upsample_three_level_kernel(const UpsampleArgs outer, const UpsampleArgs mid,
+                                                                        const UpsampleArgs inner)
+{
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<false>::kFloats + kNestScratch];
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x), frame = blockIdx.z;
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(outer.hostile, outer.generation, frame)) {
+            upsample_three_level_tile<AOFMT, RTNE, DIV_IEEE>(outer, mid, inner, smem, tile, frame);
+            return;
+        }
+    }
+    upsample_three_level_tile<AOFMT, RTNE, DIV>(outer, mid, inner, smem, tile, frame);
 }
 
 // Hook of the fused last kernel (MEAO_FUSE_SPLIT_DS): puts the four 16-byte depth loads of the carried
@@ -1952,6 +2007,31 @@ hipError_t launch_upsample_two_level(const UpsampleArgs &outer, const UpsampleAr
         else if (outer.exact_rcp_div == 2) launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_FAST>(outer, inner, grid, s);
         else if (outer.exact_rcp_div) launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(outer, inner, grid, s);
         else launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_IEEE>(outer, inner, grid, s);
+    }
+    return hipGetLastError();
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+static void launch_upsample_three_level_t(const UpsampleArgs &outer, const UpsampleArgs &mid, const UpsampleArgs &inner, dim3 grid,
+                                          hipStream_t s)
+{
+    upsample_three_level_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(outer, mid, inner);
+}
+
+hipError_t launch_upsample_three_level(const UpsampleArgs &outer, const UpsampleArgs &mid, const UpsampleArgs &inner, int ao_format,
+                                       int frames, hipStream_t s)
+{
+    const dim3 grid(outer.tiles_x * outer.tiles_y, 1, frames);
+    if (ao_format == MEAO_AO_R8) {
+        if (outer.f16_rtne) launch_upsample_three_level_t<MEAO_AO_R8, true, DIV_IEEE>(outer, mid, inner, grid, s);
+        else if (outer.exact_rcp_div == 2) launch_upsample_three_level_t<MEAO_AO_R8, false, DIV_FAST>(outer, mid, inner, grid, s);
+        else if (outer.exact_rcp_div) launch_upsample_three_level_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(outer, mid, inner, grid, s);
+        else launch_upsample_three_level_t<MEAO_AO_R8, false, DIV_IEEE>(outer, mid, inner, grid, s);
+    } else {
+        if (outer.f16_rtne) launch_upsample_three_level_t<MEAO_AO_F16, true, DIV_IEEE>(outer, mid, inner, grid, s);
+        else if (outer.exact_rcp_div == 2) launch_upsample_three_level_t<MEAO_AO_F16, false, DIV_FAST>(outer, mid, inner, grid, s);
+        else if (outer.exact_rcp_div) launch_upsample_three_level_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(outer, mid, inner, grid, s);
+        else launch_upsample_three_level_t<MEAO_AO_F16, false, DIV_IEEE>(outer, mid, inner, grid, s);
     }
     return hipGetLastError();
 }

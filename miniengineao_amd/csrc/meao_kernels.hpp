@@ -117,6 +117,9 @@ hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f
 // window of its output that the tile reads; inner's target is still written (each tile stores its own part).
 hipError_t launch_upsample_two_level(const UpsampleArgs &outer, const UpsampleArgs &inner, int ao_format, int frames,
                                      hipStream_t s);
+// one or two frames per call: L4->L3 and L3->L2 inside the L2->L1 launch (outer = L2->L1, mid = L3->L2, inner = L4->L3)
+hipError_t launch_upsample_three_level(const UpsampleArgs &outer, const UpsampleArgs &mid, const UpsampleArgs &inner, int ao_format,
+                                       int frames, hipStream_t s);
 // Upsample.main of this batch + the downsample pass of the next one in a single kernel.
 hipError_t launch_upsample_final_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format,
                                                  int frames, hipStream_t s);

@@ -317,6 +317,33 @@ def test_pipelined_downsample_tile_counts_and_formats(oracle, w, h, batch, depth
         ao.close()
 
 
+@pytest.mark.parametrize("mode", ["separate", "two_level", "three_level"])
+@pytest.mark.parametrize("w,h,batch", [(203, 117, 3), (256, 128, 1), (640, 360, 2), (67, 45, 2)])
+def test_every_blend_launch_structure_is_bit_exact(oracle, monkeypatch, mode, w, h, batch):
+    """The three blend passes run as three launches, as L4->L3 inside L3->L2, or all inside the L2->L1
+    launch (chosen by the size of the call; the MEAO_DEBUG_* switches are read by meao_create).  Every
+    buffer of every frame -- one of them hostile -- must equal the oracle's in each structure."""
+    if mode == "separate":
+        monkeypatch.setenv("MEAO_DEBUG_NO_FUSED_BLEND", "1")
+    else:
+        monkeypatch.setenv("MEAO_DEBUG_NESTED_MAX_TILES", "0" if mode == "two_level" else "1000000")
+    s = H.settings(oracle, w, h)
+    frames = [synth.make("S2", w, h, seed=50 + f) for f in range(batch)]
+    frames[-1] = H.hostile_frame(w, h, 77, density=0.01)
+    ao = H.component(s, max_batch=batch)
+    try:
+        outs = ao.render_batch(frames)
+        for f in range(batch):
+            want = oracle.run(frames[f], s)
+            ok, bad = H.nan_aware_equal(outs[f], want["result"])
+            assert ok, (f, int(bad.sum()))
+            for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+                ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
+                assert ok, (H.NAMES[i], f, int(bad.sum()))
+    finally:
+        ao.close()
+
+
 # ---- round 2: contract enforcement, robustness of the boundary ------------------------------------
 
 def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
