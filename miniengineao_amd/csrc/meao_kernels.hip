@@ -733,8 +733,15 @@ __device__ __forceinline__ bool frame_is_hostile(const uint32_t *hostile, uint32
     return __builtin_nontemporal_load(hostile + frame) == generation;
 }
 
-template <int AOFMT, bool RTNE, int DIV, bool EXH>
-__device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, int frame, int block)
+// Hook of the texel loop: begin(k) / end(k) are executed by every thread of the workgroup around iteration k
+// (render_with_composite_kernel puts the loads of unrelated streaming work in flight under the arithmetic).
+struct NoRenderHook {
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void end(int) {}
+};
+
+template <int AOFMT, bool RTNE, int DIV, bool EXH, typename Hook = NoRenderHook>
+__device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, int frame, int block, Hook hook = Hook())
 {
     typedef AoTexel<AOFMT> AO;
     constexpr int kRenTileW = ren_tile_w(EXH), kRenThreads = kRenTileW * 4, kRenLdsW = kRenTileW + 2 * kRenApron;
@@ -810,26 +817,29 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
         const int blk = k * kWaves + wave;
         const int txl = (blk % kBlocksX) * 16 + (lane & 15), ly = (blk / kBlocksX) * 4 + (lane >> 4);
         const int X = X0 + 2 * txl, Y = Y0 + ly;
-        if (X >= lw || Y >= lh) continue;
-        const float *centre = &tile[(ly + kRenApron) * kRenLdsW + 2 * txl + kRenApron];
-        const float2v c = *reinterpret_cast<const float2v *>(centre);
-        const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-        // the fast path assumes NaN-free distances: the body hostile frames (and RTNE storage, inf samples) run has it off
-        float2v out;
-        if constexpr (MEAO_REN_SWPIPE && !EXH)
-            out = accumulate_terms_pipelined<4 * kRenLdsW, 4, MEAO_REN_SWPIPE_DEPTH>(terms, centre, inv_depth);
-        else
-            out = accumulate_terms<EXH, 4 * kRenLdsW, 4, MEAO_REN_FASTPATH && DIV == DIV_EXACT_RCP>(terms, centre, inv_depth);
+        hook.begin(k);
+        if (X < lw && Y < lh) {
+            const float *centre = &tile[(ly + kRenApron) * kRenLdsW + 2 * txl + kRenApron];
+            const float2v c = *reinterpret_cast<const float2v *>(centre);
+            const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
+            // the fast path assumes NaN-free distances: the body hostile frames (and RTNE storage, inf samples) run has it off
+            float2v out;
+            if constexpr (MEAO_REN_SWPIPE && !EXH)
+                out = accumulate_terms_pipelined<4 * kRenLdsW, 4, MEAO_REN_SWPIPE_DEPTH>(terms, centre, inv_depth);
+            else
+                out = accumulate_terms<EXH, 4 * kRenLdsW, 4, MEAO_REN_FASTPATH && DIV == DIV_EXACT_RCP>(terms, centre, inv_depth);
 
-        typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
-        const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
-        if (pair_store) {
-            typename AO::type2 pr; pr.x = e0; pr.y = e1;
-            *reinterpret_cast<typename AO::type2 *>(p) = pr;
-        } else {
-            p[0] = e0;
-            if (X + 1 < lw) p[1] = e1;
+            typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
+            const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
+            if (pair_store) {
+                typename AO::type2 pr; pr.x = e0; pr.y = e1;
+                *reinterpret_cast<typename AO::type2 *>(p) = pr;
+            } else {
+                p[0] = e0;
+                if (X + 1 < lw) p[1] = e1;
+            }
         }
+        hook.end(k);
     }
 }
 
@@ -1816,12 +1826,95 @@ __global__ __launch_bounds__(kThreads) void composite_kernel(const CompositeArgs
 // the composite is pure streaming (17 bytes per texel, as many bytes as the whole AO path) and render
 // is VALU-bound with HBM nearly idle, so every render workgroup first streams its share of the
 // composite texel pairs and then renders its tile.
+#ifndef MEAO_COMPOSITE_IN_LOOP
+#define MEAO_COMPOSITE_IN_LOOP 1   // carried composite (multiply mode): two pixel pairs per lane in flight under every texel-loop iteration
+#endif
+#ifndef MEAO_COMPOSITE_PER_ITERATION
+#define MEAO_COMPOSITE_PER_ITERATION 2
+#endif
+constexpr int kCompositePerIteration = MEAO_COMPOSITE_PER_ITERATION;          // pixel pairs per lane in flight under one iteration
+constexpr int kCompositePairsInLoop = kCompositePerIteration * (kRenTileH / 8);
+
+// Pass 2 of Blit.shader (dst * src.a) for pixel pairs of ONE frame, as the hook of the render texel loop:
+// begin(k) issues the 16-byte colour and 2/4-byte AO loads of two pairs, end(k) multiplies and stores them.
+// Pair j of a lane is q = (j * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x (a workgroup touches 8 KB
+// of contiguous colour per j); j < kCompositePairsInLoop here, the rest in the plain loop before the tile.
+template <int AOFMT>
+struct CarriedComposite {
+    typedef AoTexel<AOFMT> AO;
+    const typename AO::type *ao;
+    uint16_t *color;
+    uint32_t q0, q_step, full_pairs;          // q0 = pair of j = 0; pairs below full_pairs have both pixels
+    bool active;
+    uint4v col[kCompositePerIteration];
+    typedef typename std::conditional<sizeof(typename AO::type) == 1, uint16_t, uint32_t>::type ao_pair_bits;
+    uint32_t ao2[kCompositePerIteration];     // two AO texels, undecoded (taken apart in end(), not next to the load)
+    __device__ __forceinline__ uint32_t pair_of(int k, int s) const { return q0 + static_cast<uint32_t>(kCompositePerIteration * k + s) * q_step; }
+    __device__ __forceinline__ void begin(int k)
+    {
+        if (!active) return;
+#pragma unroll
+        for (int s = 0; s < kCompositePerIteration; ++s) {
+            const uint32_t q = pair_of(k, s);
+            if (q < full_pairs) {
+                col[s] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(at_byte_offset(color, q * 16u)));
+                ao2[s] = *reinterpret_cast<const ao_pair_bits *>(at_byte_offset(ao, q * static_cast<uint32_t>(sizeof(ao_pair_bits))));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);        // the loads stay here; their first use is behind the texel arithmetic
+    }
+    __device__ __forceinline__ void end(int k)
+    {
+        if (!active) return;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < kCompositePerIteration; ++s) {
+            const uint32_t q = pair_of(k, s);
+            if (q < full_pairs) {
+                constexpr int kAoBits = 8 * sizeof(typename AO::type);
+                asm volatile("" : "+v"(ao2[s]));          // opaque here: nothing derived from the loaded word moves up to the load
+                const float a0 = AO::decode(static_cast<typename AO::type>(ao2[s] & ((1u << kAoBits) - 1u)));
+                const float a1 = AO::decode(static_cast<typename AO::type>(ao2[s] >> kAoBits));
+                const uint32_t w[4] = {col[s].x, col[s].y, col[s].z, col[s].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {                      // words 0, 1: pixel 0 (rg, ba); words 2, 3: pixel 1
+                    const float m = h < 2 ? a0 : a1;
+                    const uint32_t lo = f32_to_f16_rtne_bits(f16_bits_to_f32(static_cast<uint16_t>(w[h] & 0xffffu)) * m);
+                    const uint32_t hi = f32_to_f16_rtne_bits(f16_bits_to_f32(static_cast<uint16_t>(w[h] >> 16)) * m);
+                    o[h] = lo | (hi << 16);
+                }
+                __builtin_nontemporal_store(uint4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<uint4v *>(at_byte_offset(color, q * 16u)));
+            }
+        }
+    }
+};
+
 template <int AOFMT, bool RTNE, int DIV>
 __global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_with_composite_kernel(const RenderArgs a,
                                                                                          const CompositeBatchArgs c)
 {
     __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(false) + 2 * kRenApron)];
-    {
+    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
+    // In-loop form: one composite frame per render frame, multiply mode, frames below 2^28 pairs (32-bit byte offsets)
+    const bool in_loop = MEAO_COMPOSITE_IN_LOOP && c.mode == MEAO_COMPOSITE_MULTIPLY && c.frames == static_cast<int32_t>(gridDim.y) &&
+                         c.pixels < (int64_t(1) << 29);
+    CarriedComposite<AOFMT> carried;
+    carried.active = in_loop;
+    if (in_loop) {
+        const int64_t pairs = (c.pixels + 1) / 2;
+        carried.ao = static_cast<const typename AoTexel<AOFMT>::type *>(c.ao[frame]);
+        carried.color = static_cast<uint16_t *>(c.color[frame]);
+        carried.q_step = gridDim.x * blockDim.x;
+        carried.q0 = blockIdx.x * blockDim.x + threadIdx.x;
+        carried.full_pairs = static_cast<uint32_t>(c.pixels / 2);
+        // what the loop does not take: pairs j >= kCompositePairsInLoop of this lane and the half pair of an odd frame
+        for (int64_t q = static_cast<int64_t>(carried.q0) + static_cast<int64_t>(kCompositePairsInLoop) * carried.q_step; q < pairs; q += carried.q_step)
+            composite_pair<AOFMT>(c.ao[frame], c.color[frame], c.gbuffer0[frame], c.pixels, c.mode, q);
+        if ((c.pixels & 1) && carried.q0 == 0 && pairs - 1 < static_cast<int64_t>(kCompositePairsInLoop) * carried.q_step &&
+            (pairs - 1) % carried.q_step == 0)
+            composite_pair<AOFMT>(c.ao[frame], c.color[frame], c.gbuffer0[frame], c.pixels, c.mode, pairs - 1);
+    } else {
         const int64_t pairs = (c.pixels + 1) / 2, total = pairs * c.frames;
         const int64_t stride = static_cast<int64_t>(gridDim.x) * gridDim.y * blockDim.x;
         for (int64_t i = (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -1829,14 +1922,13 @@ __global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_with_composit
             composite_pair<AOFMT>(c.ao[f], c.color[f], c.gbuffer0[f], c.pixels, c.mode, i - f * pairs);
         }
     }
-    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
     if constexpr (DIV == DIV_EXACT_RCP) {
         if (frame_is_hostile(a.hostile, a.generation, frame)) {
-            render_tile<AOFMT, RTNE, DIV_IEEE, false>(a, tile, frame, block);
+            render_tile<AOFMT, RTNE, DIV_IEEE, false>(a, tile, frame, block, carried);
             return;
         }
     }
-    render_tile<AOFMT, RTNE, DIV, false>(a, tile, frame, block);
+    render_tile<AOFMT, RTNE, DIV, false>(a, tile, frame, block, carried);
 }
 
 // which = 4: rcp_strict, 5: div_const<3>, div_const<9>, 6: div_strict on hashed operand pairs
