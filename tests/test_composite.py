@@ -108,6 +108,45 @@ def test_enqueued_composite_rides_in_the_next_render_and_matches_oracle(oracle, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h,n_composite,n_render", [(131, 77, 2, 2), (640, 360, 1, 1), (200, 88, 2, 3), (96, 64, 3, 1)])
+def test_carried_composite_shapes(oracle, w, h, n_composite, n_render):
+    """Multiply mode inside the render texel loop: an odd pixel count (131 x 77: the half pair at the end),
+    more pairs per lane than the loop takes (640 x 360: the remainder runs before the tile), and a
+    carrying call with a different frame count than the composite batch (falls back to "composite first")."""
+    torch = pytest.importorskip("torch")
+    from tests import helpers as H
+    from miniengineao_amd import synth
+    mode = 0          # MEAO_COMPOSITE_MULTIPLY
+    s = H.settings(oracle, w, h)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(w + h)
+    nmax = max(n_composite, n_render)
+    frames = [synth.make("S2", w, h, seed=300 + f) for f in range(nmax)]
+    want_ao = [oracle.run(f, s, result_only=True)["result"] for f in frames]
+    colors = [(rng.random((h, w, 4)) * 3.0).astype(np.float16).view(np.uint16) for _ in range(n_composite)]
+    want_c = [c.copy() for c in colors]
+    for f in range(n_composite):
+        oracle.composite(want_ao[f], want_c[f], mode, 0, None)
+    dd = [torch.from_numpy(f).to(dev) for f in frames]
+    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(nmax)]
+    out2 = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(nmax)]
+    dc = [torch.from_numpy(c.view(np.int16)).to(dev) for c in colors]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ao = H.component(s, max_batch=nmax)
+    try:
+        ao.execute_device([t.data_ptr() for t in dd[:n_composite]], [t.data_ptr() for t in out[:n_composite]], st)
+        ao.composite_enqueue_device(mode, [t.data_ptr() for t in out[:n_composite]], [t.data_ptr() for t in dc], None)
+        ao.execute_device([t.data_ptr() for t in dd[:n_render]], [t.data_ptr() for t in out2[:n_render]], st)
+        torch.cuda.synchronize(dev)
+        for f in range(n_render):
+            assert np.array_equal(out2[f].cpu().numpy(), want_ao[f]), f
+        for f in range(n_composite):
+            assert np.array_equal(dc[f].cpu().numpy().view(np.uint16), want_c[f]), (f, "color")
+    finally:
+        ao.close()
+
+
+@pytest.mark.gpu
 def test_enqueued_composite_is_never_dropped(oracle):
     """flush, a second enqueue and close() all run a waiting batch."""
     torch = pytest.importorskip("torch")
