@@ -1911,9 +1911,11 @@ __global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_with_composit
         // what the loop does not take: pairs j >= kCompositePairsInLoop of this lane and the half pair of an odd frame
         for (int64_t q = static_cast<int64_t>(carried.q0) + static_cast<int64_t>(kCompositePairsInLoop) * carried.q_step; q < pairs; q += carried.q_step)
             composite_pair<AOFMT>(c.ao[frame], c.color[frame], c.gbuffer0[frame], c.pixels, c.mode, q);
-        if ((c.pixels & 1) && carried.q0 == 0 && pairs - 1 < static_cast<int64_t>(kCompositePairsInLoop) * carried.q_step &&
-            (pairs - 1) % carried.q_step == 0)
-            composite_pair<AOFMT>(c.ao[frame], c.color[frame], c.gbuffer0[frame], c.pixels, c.mode, pairs - 1);
+        if (c.pixels & 1) {     // the half pair at the end of an odd frame: the lane that owns it, if the loop would have had it
+            const int64_t last = pairs - 1;
+            if (last % carried.q_step == carried.q0 && last / carried.q_step < kCompositePairsInLoop)
+                composite_pair<AOFMT>(c.ao[frame], c.color[frame], c.gbuffer0[frame], c.pixels, c.mode, last);
+        }
     } else {
         const int64_t pairs = (c.pixels + 1) / 2, total = pairs * c.frames;
         const int64_t stride = static_cast<int64_t>(gridDim.x) * gridDim.y * blockDim.x;
