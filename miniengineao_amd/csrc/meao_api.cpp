@@ -343,8 +343,8 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         ds.reversed_z = ctx->prm.reversed_z != 0;
         ds.f16_rtne = rtne;
         ds.exact_rcp_div = ctx->exact_rcp_div;
-        ds.tiles_x = (p.mip[0].w + 127) / 128;
-        ds.tiles_y = (p.mip[0].h + 31) / 32;
+        ds.tiles_x = (p.mip[0].w + kDsTileW - 1) / kDsTileW;
+        ds.tiles_y = (p.mip[0].h + kDsTileH - 1) / kDsTileH;
         ds.hostile = ctx->hostile_of(set);
         ds.generation = generation;
         return ds;

@@ -266,7 +266,6 @@ __device__ __forceinline__ float div_strict(float a, float b)
 // top-left texel of its block, so a lane decides what to store from its own coordinates and
 // no LDS exchange is needed.
 
-constexpr int kDsTileW = 128, kDsTileH = 32, kDsRowsPerPass = 8;
 // The pass is pure streaming: its loads and its two big stores are non-temporal, so that the lines
 // do not displace what the upsample tiles sharing the kernel (meao_prefetch_batch) re-read from L2
 // (A/B: 344 -> 339 us for the fused kernel, no change stand-alone).
@@ -302,8 +301,8 @@ __device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, in
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const void *__restrict__ depth = a.depth[frame];
     const int W = a.w[0], H = a.h[0];
-    const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
-    const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
+    const int x0 = tile_x * kDsTileW + (threadIdx.x % kDsLanesPerRow) * 4;
+    const int yb = tile_y * kDsTileH + (threadIdx.x / kDsLanesPerRow);
     if (x0 >= W) return;
 
     // The depth-copy blit of the reference (Blit.shader pass 0) is folded into this load: the
@@ -371,8 +370,8 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
     float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
     const int W = a.w[0], H = a.h[0];
     const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
-    const int x0 = tile_x * kDsTileW + (threadIdx.x & 31) * 4;
-    const int yb = tile_y * kDsTileH + (threadIdx.x >> 5);
+    const int x0 = tile_x * kDsTileW + (threadIdx.x % kDsLanesPerRow) * 4;
+    const int yb = tile_y * kDsTileH + (threadIdx.x / kDsLanesPerRow);
     if (x0 >= W) return;
 #if MEAO_DS_LEAN
     // level widths and Z-buffer parameters once, in SGPRs (left to itself the compiler re-issues the s_load of
