@@ -13,6 +13,7 @@ cp gpurun_out/fuzz_$T.log profiles/${T}_fuzz_gpu.log
 cp gpurun_out/pytest_gpu_$T.log profiles/${T}_pytest_gpu.log
 cp gpurun_out/ubench_issue_$T.txt profiles/${T}_ubench_issue.txt
 cp gpurun_out/ubench_lds_$T.txt profiles/${T}_ubench_lds.txt
+[ -f gpurun_out/ubench_launch_$T.txt ] && cp gpurun_out/ubench_launch_$T.txt profiles/${T}_ubench_launch.txt
 python tests/pmc_summary.py gpurun_out/pmc_$T > profiles/${T}_pmc_summary.txt
 python tests/make_pmc_traffic.py gpurun_out/pmc_$T 4k $N > /dev/null
 ls -la profiles/${T}_*

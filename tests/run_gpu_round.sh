@@ -14,4 +14,5 @@ bash tests/run_rocprof.sh $TAG > gpurun_out/rocprof_$TAG.log 2>&1
 bash tests/run_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
 timeout 300 miniengineao_amd/lib/ubench_issue 5.0 > gpurun_out/ubench_issue_$TAG.txt 2>&1
 timeout 300 miniengineao_amd/lib/ubench_lds 4.0 > gpurun_out/ubench_lds_$TAG.txt 2>&1
+timeout 120 miniengineao_amd/lib/ubench_launch > gpurun_out/ubench_launch_$TAG.txt 2>&1
 tail -3 gpurun_out/smoke_$TAG.log; tail -4 gpurun_out/pytest_gpu_$TAG.log; cut -c1-400 gpurun_out/bench_$TAG.json
