@@ -1,10 +1,13 @@
 // meao_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the multi-scale SSAO hot path.
 //
-// One workgroup = 256 threads = 4 wave64.  Kernels (stream order, one launch each per batch):
+// One workgroup = 256 threads = 4 wave64 (render: 512).  Kernels (stream order, one launch each per batch):
 //   downsample_kernel  Downsample1.main + Downsample2.main   (DS1:52-81, DS2:32-51)
 //   render_kernel      Render.main_interleaved, all levels   (REN:112-177)
+//   render_with_composite_kernel   the same, carrying the composite of an earlier call in its texel loop
 //   render_wide_kernel Render.main on LowDepth<k> (opt-in hq_levels variant)
 //   upsample_kernel    Upsample.main / main_blendout [/ main_premin*]   (UPS:185-233)
+//   upsample_two_level_kernel / upsample_three_level_kernel   main_blendout L3->L2 (L2->L1) with the
+//                      pass(es) below evaluated inside the same launch
 //   upsample_final_with_next_downsample_kernel   Upsample.main of this batch + the downsample pass
 //                      of the next one (meao_prefetch_batch): streaming hidden under VALU-bound work
 // (DS1/DS2/REN/UPS = Assets/MiniEngineAO/Shaders/{Downsample1,Downsample2,Render,Upsample}.compute)
@@ -17,18 +20,26 @@
 //
 // MI355X design notes:
 //  * The 4x4 de-interleaved TiledDepth arrays are never materialised on the hot path: a
-//    workgroup that renders ALL 16 slices of a 64x32 output tile needs exactly one contiguous
-//    (64+32)x(32+32) window of LowDepth<level>, so the kernel stages that window in LDS
+//    workgroup that renders ALL 16 slices of a 128x32 output tile needs exactly one contiguous
+//    (128+32)x(32+32) window of LowDepth<level>, so the kernel stages that window in LDS
 //    (applying the per-slice clamp addressing and the atlas padding rule while filling) and
 //    samples it with a stride of 4.  Output rows are then contiguous instead of a 4-byte
 //    strided scatter of single R8 texels.
 //  * Each lane renders horizontally adjacent texel pairs so every LDS sample is one
 //    conflict-free ds_read_b64; saturate() folds into the clamp modifier of v_mul/v_fma and
-//    clamp(d, p, 1) is one v_med3_f32, so a sample pair costs exactly 8 VALU ops per texel.
+//    clamp(d, p, 1) is one v_med3_f32, so a sample pair costs exactly 8 VALU ops per texel.  The reads
+//    of the next pair are issued by hand before the current pair is evaluated, and the per-term constants
+//    are VGPR operands: an SGPR source halves the VALU issue rate on this part (tools/ubench_issue.hip).
 //  * Upsample uses 64x64 hi-res tiles in the full-resolution pass (64x32 in the blend passes):
 //    1.4x apron amplification instead of the reference's 2.6x, >= 89 % of the lanes busy in both
 //    blur phases, 16-byte loads of the hi-res depth and 4-byte stores of four AO texels, LDS
 //    carved so that seven workgroups share a CU.
+//  * vmcnt retires loads in issue order: loads whose data is needed late are issued BEHIND the ones
+//    needed first (window before hi-res operands), and unrelated streaming work (the next batch's
+//    downsample tile, a carried composite) puts its loads in flight inside the tile, after the tile's
+//    own loads have landed, through hooks of upsample_tile / render_tile.
+//  * The small blend passes are evaluated inside the launch of the pass above them by recomputation
+//    (blend_window_into_lds): no inter-workgroup synchronisation, bit-identical buffers.
 #include "meao_kernels.hpp"
 
 #include <algorithm>
