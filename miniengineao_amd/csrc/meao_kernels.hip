@@ -71,6 +71,9 @@
 #ifndef MEAO_DS_LEAN
 #define MEAO_DS_LEAN 0          // downsample tile: 32-bit byte offsets from uniform bases (saddr addressing), arguments pinned in
 #endif                          // SGPRs, the four f16 conversions of a row as two v_cvt_pkrtz_f16_f32
+#ifndef MEAO_SETPRIO
+#define MEAO_SETPRIO 1          // waves raise their issue priority while they load a tile's window (render fill / upsample prefetch)
+#endif
 #ifndef MEAO_REN_FASTPATH
 #define MEAO_REN_FASTPATH 0     // wave-uniform "all distances >= 0" path in the render kernel (bit-exact; slower, see test_samples)
 #endif
@@ -766,6 +769,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     const int lw = L.lw, lh = L.lh;
     const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, frame);
 
+    if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(3);
     // ---- stage the (64+32) x (32+32) window.  Window texel (vx,vy) (level coordinates, may
     // be outside the level) belongs to slice (vx&3, vy&3), slice texel (vx>>2, vy>>2); the
     // reference clamps the slice texel per slice (REN:118 Gather + clamp sampler) and finds
@@ -813,6 +817,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
         }
     }
     __syncthreads();
+    if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- each lane: a texel pair (X, X+1) in each of the 4 iterations
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
@@ -1101,6 +1106,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
     const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
 
+    if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(3);
 #if MEAO_UPS_HOIST
     // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
     // are issued first, so that their latency hides behind the prefetch and blur phases.
@@ -1239,6 +1245,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         }
     }
     __syncthreads();
+    if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(0);
     hook.after_prefetch();
 
     // ---- BlurHorizontally: runs of 4 outputs; output (r, c) is centred on raw column c+2.
