@@ -74,6 +74,9 @@
 #ifndef MEAO_SETPRIO
 #define MEAO_SETPRIO 1          // waves raise their issue priority while they load a tile's window (render fill / upsample prefetch)
 #endif
+#ifndef MEAO_UPS_ALIGNED_FILL
+#define MEAO_UPS_ALIGNED_FILL 0 // interior upsample tiles: the window goes to LDS as aligned 16-byte stores (one element from the next lane by DPP)
+#endif
 #ifndef MEAO_REN_FASTPATH
 #define MEAO_REN_FASTPATH 0     // wave-uniform "all distances >= 0" path in the render kernel (bit-exact; slower, see test_samples)
 #endif
@@ -1179,6 +1182,49 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 asm volatile("" : : "v"(__builtin_bit_cast(bits_t, wa[round])));
             }
             const int i = threadIdx.x + round * kThreads;
+#if MEAO_UPS_ALIGNED_FILL
+            if constexpr (!NESTED) {
+                // A lane holds window columns 4k-1 .. 4k+2 (its 16-byte load starts one texel left of the
+                // window): four scalar stores per array at a lane stride of 4 floats are 4-way bank conflicts,
+                // 43 % of this kernel's LDS cycles.  Each lane takes column 4k+3 from the next lane (DPP
+                // wave_shl:1, all lanes active) and stores the aligned quad 4k .. 4k+3 with one ds_write_b128;
+                // at the end of a window row that fourth column is row padding.  The wave's last lane has no
+                // neighbour (stores three), its first lane also stores its own column 4k-1.
+                const float dv[4] = {wd[round].x, wd[round].y, wd[round].z, wd[round].w};
+                const float av[4] = {AO::decode(wa[round].x), AO::decode(wa[round].y), AO::decode(wa[round].z), AO::decode(wa[round].w)};
+                float iv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) iv[e] = rcp_strict<DIV>(dv[e]);                    // UPS:67
+                auto from_next_lane = [](float x) {
+                    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+                };
+                const float d_n = from_next_lane(dv[0]), i_n = from_next_lane(iv[0]), a_n = from_next_lane(av[0]);
+                if (i < kItems) {
+                    const int r = i / 10, k = i % 10, c0 = 4 * k;
+                    const int lane = threadIdx.x & 63;
+                    float *pi = &s_inv[r * T::kRawPitch + c0], *pa = &s_ao[r * T::kRawPitch + c0];
+                    if (lane != 63) {
+                        *reinterpret_cast<float4v *>(pi) = float4v{iv[1], iv[2], iv[3], i_n};
+                        *reinterpret_cast<float4v *>(pa) = float4v{av[1], av[2], av[3], a_n};
+                    } else {
+                        *reinterpret_cast<float2v *>(pi) = float2v{iv[1], iv[2]}; pi[2] = iv[3];
+                        *reinterpret_cast<float2v *>(pa) = float2v{av[1], av[2]}; pa[2] = av[3];
+                    }
+                    // LoResDB keeps columns kDep0 .. kDep0 + kDepW - 1 (even bounds): pairs are kept or dropped whole
+                    if (dep_kept(r, c0)) *reinterpret_cast<float2v *>(&dep_at(r, c0)) = float2v{dv[1], dv[2]};
+                    if (dep_kept(r, c0 + 2)) {
+                        if (lane != 63) *reinterpret_cast<float2v *>(&dep_at(r, c0 + 2)) = float2v{dv[3], d_n};
+                        else dep_at(r, c0 + 2) = dv[3];
+                    }
+                    if (lane == 0 && k > 0) {               // column 4k-1: the previous lane belongs to another wave
+                        s_inv[r * T::kRawPitch + c0 - 1] = iv[0];
+                        s_ao[r * T::kRawPitch + c0 - 1] = av[0];
+                        if (dep_kept(r, c0 - 1)) dep_at(r, c0 - 1) = dv[0];
+                    }
+                }
+                continue;
+            }
+#endif
             if (i < kItems) {
                 const int r = i / 10, k = i % 10;
                 const float dv[4] = {wd[round].x, wd[round].y, wd[round].z, wd[round].w};
