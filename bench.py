@@ -328,6 +328,12 @@ def main() -> int:
         alg[u2] += alg[u3]
         alg[u3] = 0
         names[u2] = "upsample_L4_to_L3+L3_to_L2"
+    u1 = names.index("upsample_L2_to_L1")
+    if pass_ms[u3] <= 0 and pass_ms[u2] <= 0 < pass_ms[u1] and alg[u2] > 0:
+        # small calls: all three blend passes run inside the L2 -> L1 launch (upsample_three_level_kernel)
+        alg[u1] += alg[u2] + alg[u3]
+        alg[u2] = alg[u3] = 0
+        names[u1] = "upsample_L4_to_L3+L3_to_L2+L2_to_L1"
     dominant = int(np.argmax(pass_ms))
     passes = []
     for k in range(_lib.NUM_PASSES):
