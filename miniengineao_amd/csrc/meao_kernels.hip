@@ -1514,6 +1514,20 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
     const int dx_lo = ext.dx_lo, dy_lo = ext.dy_lo, nlw = ext.nlw, nlh = ext.nlh;
     const int rx0 = ext.rx0, ry0 = ext.ry0, rw = ext.rw, rh = ext.rh;           // raw taps (virtual, clamped on load)
 
+    // The hi-res operands of the bilateral step depend on nothing computed here: loaded now, used three
+    // barriers later (at most 38 x 22 window texels: four per lane).
+    constexpr int kHoisted = (38 * 22 + kThreads - 1) / kThreads;
+    float hoist_d[kHoisted];
+    ao_t hoist_a[kHoisted];
+#pragma unroll
+    for (int j = 0; j < kHoisted; ++j) {
+        const int i = min(static_cast<int>(threadIdx.x) + j * kThreads, win_w * win_h - 1);
+        const int X = clampi(vx0 + i % win_w, 0, hw - 1), Y = clampi(vy0 + i / win_w, 0, hh - 1);
+        const size_t at = static_cast<size_t>(Y) * hw + X;
+        hoist_d[j] = hi_depth[at];
+        hoist_a[j] = hi_ao[at];
+    }
+
     for (int i = threadIdx.x; i < rw * rh; i += kThreads) {
         const int r = i / rw, c = i % rw;
         const size_t idx = static_cast<size_t>(clampi(ry0 + r, 0, lh - 1)) * lw + clampi(rx0 + c, 0, lw - 1);
@@ -1542,7 +1556,10 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
     }
     __syncthreads();
     constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};                // Gather order, as in upsample_tile
-    for (int i = threadIdx.x; i < win_w * win_h; i += kThreads) {
+#pragma unroll
+    for (int j = 0; j < kHoisted; ++j) {
+        const int i = threadIdx.x + j * kThreads;
+        if (i >= win_w * win_h) break;
         const int wr = i / win_w, wc = i % win_w;
         const int X = clampi(vx0 + wc, 0, hw - 1), Y = clampi(vy0 + wr, 0, hh - 1);
         const int Dx = (X + 1) >> 1, Dy = (Y + 1) >> 1;
@@ -1556,7 +1573,7 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
             dk[k] = r_dep[(ly - ry0) * kNestRawW + (lx - rx0)];
         }
         const size_t at = static_cast<size_t>(Y) * hw + X;
-        const float v = bilateral_upsample<DIV>(hi_depth[at], AO::decode(hi_ao[at]), dk[0], dk[1], dk[2], dk[3], ak[0], ak[1],
+        const float v = bilateral_upsample<DIV>(hoist_d[j], AO::decode(hoist_a[j]), dk[0], dk[1], dk[2], dk[3], ak[0], ak[1],
                                                 ak[2], ak[3], bilateral_k);
         const ao_t q = AO::template encode<RTNE>(v);
         out[wr * out_pitch + wc] = AO::decode(q);
