@@ -70,6 +70,8 @@ struct meao_ctx {
     // Upsample L4->L3 evaluated inside the L3->L2 launch (upsample_two_level_kernel); on unless the
     // A/B switch MEAO_DEBUG_NO_FUSED_BLEND=1 was set when the context was created
     bool fuse_coarse_blend = true;
+    int final_small_max_tiles = 512;   // plain final pass: calls with at most this many 64x64 tiles use 64x32 tiles
+    int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
     int nested_max_tiles = 512;        // calls with at most this many L2->L1 tiles (frames x tiles) run the three blend passes as one launch
 
     // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue)
@@ -369,9 +371,18 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     const uint32_t generation = ctx->set_gen[ctx->ds_cur];
 
     // ---- PushRenderCommands x num_levels (AO.cs:519-522): the levels [first, last] as one grid
-    auto render_args = [&](int first, int last, bool wide) {
+    auto render_args = [&](int first, int last, bool wide, bool allow_small = false) {
         RenderArgs rn{};
         int blocks = 0, count = 0;
+        // few tiles (a 1080p frame or two): 128 x 8 tiles instead of 128 x 32 (render_small_kernel)
+        int tile_h = kRenTileH;
+        if (allow_small && !wide && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE) {
+            int tiles32 = 0;
+            for (int l = first; l <= last; ++l)
+                tiles32 += ((p.mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p.mip[l].h + kRenTileH - 1) / kRenTileH);
+            if (n * tiles32 <= ctx->render_small_max_tiles) tile_h = kRenTileHSmall;
+        }
+        rn.tile_h = tile_h;
         for (int l = first; l <= last; ++l) {
             if (wide && !level_has_hq(c.num_levels, c.hq_levels, l)) continue;
             RenderLevelArgs &L = rn.level[count++];
@@ -382,7 +393,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             L.sw = p.mip[l + 2].w; L.sh = p.mip[l + 2].h;
             const int tile_w = wide ? kWideTileW : ren_tile_w(c.sample_set == MEAO_SAMPLES_EXHAUSTIVE);
             L.tiles_x = (L.lw + tile_w - 1) / tile_w;
-            L.tiles_y = (L.lh + kRenTileH - 1) / kRenTileH;
+            L.tiles_y = (L.lh + tile_h - 1) / tile_h;
             L.block_begin = blocks;
             blocks += L.tiles_x * L.tiles_y;
             L.pad_value = rp.pad_value;
@@ -420,7 +431,12 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         up.lw = p.mip[hi + 1].w; up.lh = p.mip[hi + 1].h;
         up.hw = p.mip[hi].w; up.hh = p.mip[hi].h;
         up.tiles_x = (up.hw + kUpsTileW - 1) / kUpsTileW;
-        up.tiles_y = (up.hh + ups_tile_h(hi == 0) - 1) / ups_tile_h(hi == 0);
+        up.tile_h = ups_tile_h(hi == 0);
+        // few tiles (one 1080p frame): the plain final pass runs 64 x 32 tiles (upsample_final_small_kernel)
+        if (hi == 0 && ctx->next_n == 0 &&
+            n * up.tiles_x * ((up.hh + up.tile_h - 1) / up.tile_h) <= ctx->final_small_max_tiles)
+            up.tile_h = kUpsTileHSmall;
+        up.tiles_y = (up.hh + up.tile_h - 1) / up.tile_h;
         up.noise_filter_strength = k.noise_filter_strength;
         up.step_size = k.step_size;
         up.blur_tolerance = k.blur_tolerance;
@@ -466,7 +482,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             MEAO_HIP(ctx, launch_render_with_composite(render_args(1, c.num_levels, false), ctx->pending_comp, c.ao_format, n, stream));
             ctx->pending_comp.frames = 0;
         } else {
-            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false), c.ao_format, n, stream));
+            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false, true), c.ao_format, n, stream));
         }
         MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
     }
@@ -728,6 +744,8 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
     const char *no_fuse = std::getenv("MEAO_DEBUG_NO_FUSED_BLEND");
     ctx->fuse_coarse_blend = !(no_fuse && no_fuse[0] == '1');
     if (const char *m = std::getenv("MEAO_DEBUG_NESTED_MAX_TILES")) ctx->nested_max_tiles = std::atoi(m);   // A/B switch
+    if (const char *m = std::getenv("MEAO_DEBUG_RENDER_SMALL_MAX_TILES")) ctx->render_small_max_tiles = std::atoi(m);
+    if (const char *m = std::getenv("MEAO_DEBUG_FINAL_SMALL_MAX_TILES")) ctx->final_small_max_tiles = std::atoi(m);
     meao_default_params(&ctx->prm);
     int rc = use_device(ctx);
     if (rc == MEAO_OK) {

@@ -756,11 +756,12 @@ struct NoRenderHook {
     __device__ __forceinline__ void end(int) {}
 };
 
-template <int AOFMT, bool RTNE, int DIV, bool EXH, typename Hook = NoRenderHook>
+template <int AOFMT, bool RTNE, int DIV, bool EXH, typename Hook = NoRenderHook, int TILE_H = kRenTileH>
 __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, int frame, int block, Hook hook = Hook())
 {
     typedef AoTexel<AOFMT> AO;
     constexpr int kRenTileW = ren_tile_w(EXH), kRenThreads = kRenTileW * 4, kRenLdsW = kRenTileW + 2 * kRenApron;
+    constexpr int kRenTileH = TILE_H, kRenLdsH = TILE_H + 2 * kRenApron;      // shadow the 32-row constants
 
     int b = block, lv = 0;
 #pragma unroll
@@ -780,8 +781,8 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     {
         const float pad = through_f16<RTNE>(L.pad_value);
         const bool vec_ok = (lw & 3) == 0;
-        constexpr int kQuadsX = kRenLdsW / 4, kRounds = kQuadsX * kRenLdsH / kRenThreads;
-        static_assert(kQuadsX * kRenLdsH % kRenThreads == 0, "every thread fills the same number of quads");
+        constexpr int kQuadsX = kRenLdsW / 4, kQuads = kQuadsX * kRenLdsH, kRounds = (kQuads + kRenThreads - 1) / kRenThreads;
+        constexpr bool kEven = kQuads % kRenThreads == 0;            // every thread fills the same number of quads (32-row tiles)
         // Phase 1: all 16-byte loads of this thread's quads are issued back to back (the plain loop
         // waited for each load before issuing the next: five dependent memory latencies per tile);
         // quads that touch the level's border take the scalar path in phase 2.
@@ -795,8 +796,9 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
             const int px0 = clampi((X0 >> 2) - (kRenApron >> 2) + qx, 0, L.sw - 1) * 4;
             const int vy = Y0 - kRenApron + qy;
             const int py = clampi(vy >> 2, 0, L.sh - 1) * 4 + (vy & 3);
-            row_at[r] = py < lh ? py * lw + px0 : -1;
-            whole[r] = py < lh && vec_ok && px0 + 3 < lw;
+            const bool mine = kEven || q < kQuads;              // the last round of the 8-row tile is partly empty
+            row_at[r] = (mine && py < lh) ? py * lw + px0 : -1;
+            whole[r] = mine && py < lh && vec_ok && px0 + 3 < lw;
             if (whole[r]) raw[r] = *reinterpret_cast<const float4v *>(src + row_at[r]);
         }
         // Phase 2: the f16 round trip the atlas store applies, then one 16-byte LDS store per quad
@@ -816,13 +818,13 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
                 if (px0 + 2 < lw) t.z = through_f16<RTNE>(row[2]);
                 if (px0 + 3 < lw) t.w = through_f16<RTNE>(row[3]);
             }
-            *reinterpret_cast<float4v *>(&tile[qy * kRenLdsW + qx * 4]) = t;
+            if (kEven || q < kQuads) *reinterpret_cast<float4v *>(&tile[qy * kRenLdsW + qx * 4]) = t;
         }
     }
     __syncthreads();
     if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(0);
 
-    // ---- each lane: a texel pair (X, X+1) in each of the 4 iterations
+    // ---- each lane: a texel pair (X, X+1) in each of the TILE_H / 8 iterations
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
     const bool pair_store = ((lw & 1) == 0);
     const TermConstants<EXH> terms(L);
@@ -874,6 +876,22 @@ __global__ __launch_bounds__(ren_tile_w(EXH) * 4, EXH ? 1 : 8) void render_kerne
         }
     }
     render_tile<AOFMT, RTNE, DIV, EXH>(a, tile, frame, block);
+}
+
+// One or two small frames per call (fewer 128 x 32 tiles than CUs): 128 x 8 tiles, four times the workgroups,
+// one texel-loop iteration each -- the call waits for one workgroup's serial time, not for throughput.
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(ren_tile_w(false) * 4, 6) void render_small_kernel(const RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[(kRenTileHSmall + 2 * kRenApron) * (ren_tile_w(false) + 2 * kRenApron)];
+    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(a.hostile, a.generation, frame)) {
+            render_tile<AOFMT, RTNE, DIV_IEEE, false, NoRenderHook, kRenTileHSmall>(a, tile, frame, block);
+            return;
+        }
+    }
+    render_tile<AOFMT, RTNE, DIV, false, NoRenderHook, kRenTileHSmall>(a, tile, frame, block);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1048,9 +1066,9 @@ __device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao,
 
 // One tile of Upsample.main (FINAL) / main_blendout; every thread of the workgroup must call it
 // (barriers inside; lanes outside the image leave after the last one).
-template <bool FINAL>
+template <bool FINAL, int TILE_H = ups_tile_h(FINAL)>
 struct UpsLds {
-    typedef UpsTile<ups_tile_h(FINAL)> T;
+    typedef UpsTile<TILE_H> T;
     static constexpr int kDep0 = FINAL ? 2 : 0;                                   // first row / column kept
     static constexpr int kDepH = FINAL ? T::kLowH + 4 : T::kRawH, kDepW = FINAL ? T::kLowW + 4 : T::kRawW;
     static constexpr int kDepPitch = FINAL ? 36 : T::kRawPitch;
@@ -1070,12 +1088,12 @@ struct NoHook {
     __device__ __forceinline__ void before_bilateral() const {}
 };
 
-template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook>
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
 __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
 {
     typedef AoTexel<AOFMT> AO;
     typedef typename AO::type ao_t;
-    constexpr int kTileH = ups_tile_h(FINAL);
+    constexpr int kTileH = TILE_H;
     typedef UpsTile<kTileH> T;
     // One allocation, carved so that the scratch rows the last V-blur run reads past the raw window
     // (rows kRawH .. kRawRows-1 of s_inv and s_hb; their products are never used) fall into the next
@@ -1083,7 +1101,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     // what the bilateral phase gathers (rows / columns 2 .. kLow+5): 22.3 KB per workgroup instead of
     // 24.1 KB, which lets a seventh workgroup share the CU's 160 KB (with __launch_bounds__(.., 7):
     // A/B on one box, 357 -> 343 us for the kernel that also carries the next downsample pass).
-    typedef UpsLds<FINAL> Lds;
+    typedef UpsLds<FINAL, TILE_H> Lds;
     constexpr int kDep0 = Lds::kDep0, kDepH = Lds::kDepH, kDepW = Lds::kDepW, kDepPitch = Lds::kDepPitch;
     constexpr int kInvN = Lds::kInvN, kHbN = Lds::kHbN, kDepN = Lds::kDepN, kAoN = Lds::kAoN;
     static_assert(kDepW <= kDepPitch && (T::kRawRows - T::kRawH) * T::kRawPitch <= kHbN &&
@@ -1616,16 +1634,16 @@ __global__ __launch_bounds__(kThreads) void upsample_two_level_kernel(const Upsa
 }
 
 // The (rare) hostile-frame variant of a tile: the same code with IEEE division.
-template <int AOFMT, bool RTNE, bool FINAL, int DIV, typename Hook = NoHook>
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
 __device__ __forceinline__ void upsample_tile_checked(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
 {
     if constexpr (DIV == DIV_EXACT_RCP) {
         if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
-            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE, false, Hook>(a, smem, tile, frame, hook);
+            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE, false, Hook, TILE_H>(a, smem, tile, frame, hook);
             return;
         }
     }
-    upsample_tile<AOFMT, RTNE, FINAL, DIV, false, Hook>(a, smem, tile, frame, hook);
+    upsample_tile<AOFMT, RTNE, FINAL, DIV, false, Hook, TILE_H>(a, smem, tile, frame, hook);
 }
 
 template <int AOFMT, bool RTNE, bool FINAL, int DIV>
@@ -1633,6 +1651,15 @@ __global__ __launch_bounds__(kThreads, FINAL ? 7 : 1) void upsample_kernel(const
 {
     __shared__ __attribute__((aligned(16))) float smem[UpsLds<FINAL>::kFloats];
     upsample_tile_checked<AOFMT, RTNE, FINAL, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
+}
+
+// Upsample.main for calls with few tiles (one 1080p frame: 510 tiles of 64 x 64 on 256 CUs): 64 x 32 tiles, twice
+// the workgroups, half the serial work in each.
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(kThreads) void upsample_final_small_kernel(const UpsampleArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<true, kUpsTileHSmall>::kFloats];
+    upsample_tile_checked<AOFMT, RTNE, true, DIV, NoHook, kUpsTileHSmall>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
 
 // ---- one frame per call: L4 -> L3 and L3 -> L2 inside the L2 -> L1 launch ---------------------------------
@@ -2081,6 +2108,7 @@ static void launch_render_t(const RenderArgs &a, dim3 grid, hipStream_t s)
         else render_wide_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);
     } else {
         if (a.exhaustive) render_kernel<AOFMT, RTNE, DIV, true><<<grid, block, 0, s>>>(a);
+        else if (a.tile_h == kRenTileHSmall) render_small_kernel<AOFMT, RTNE, DIV><<<grid, block, 0, s>>>(a);
         else render_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);
     }
 }
@@ -2140,7 +2168,8 @@ hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hi
 template <int AOFMT, bool RTNE, int DIV>
 static void launch_upsample_t(const UpsampleArgs &a, bool final_pass, dim3 grid, hipStream_t s)
 {
-    if (final_pass) upsample_kernel<AOFMT, RTNE, true, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
+    if (final_pass && a.tile_h == kUpsTileHSmall) upsample_final_small_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
+    else if (final_pass) upsample_kernel<AOFMT, RTNE, true, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else upsample_kernel<AOFMT, RTNE, false, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
 }
 

@@ -37,6 +37,7 @@ struct DownsampleArgs {
 // variant needs ~95 VGPRs, where the smaller workgroup fits more waves: 64 x 32 with 256 threads.
 constexpr int ren_tile_w(bool exhaustive) { return exhaustive ? 64 : 128; }
 constexpr int kRenTileH = 32;
+constexpr int kRenTileHSmall = 8;               // calls with fewer 128 x 32 tiles than CUs: four times the workgroups, one texel-loop iteration each
 constexpr int kWideTileW = 64;                                 // Render.main (wide) keeps 64 x 32, 256 threads
 #ifndef MEAO_DS_TILE_W
 #define MEAO_DS_TILE_W 128      // A/B: downsample tile 128 x 32 (default), 256 x 16, 512 x 8 -- always 4096 texels, 256 lanes x 4 row passes
@@ -67,6 +68,7 @@ struct RenderArgs {
     int32_t f16_rtne;
     int32_t exact_rcp_div;
     int32_t exhaustive;    // SAMPLE_EXHAUSTIVELY: 12 terms instead of 7
+    int32_t tile_h;        // kRenTileH, or kRenTileHSmall (interleaved checker-set kernel only): the tiling `level[]` was built for
     const uint32_t *hostile;   // per frame, written by the downsample pass that produced `src`
     uint32_t generation;       // hostile[frame] == generation -> IEEE-division body for that frame
 };
@@ -84,6 +86,7 @@ constexpr int kWideLdsW = kWideTileW + 2 * kWideApron, kWideLdsH = kRenTileH + 2
 // frame and run faster with 64 x 32 (measured on one MI355X, see profiles/README.md).
 constexpr int kUpsTileW = 64;
 constexpr int ups_tile_h(bool final_pass) { return final_pass ? 64 : 32; }
+constexpr int kUpsTileHSmall = 32;              // the final pass of calls with few 64 x 64 tiles (UpsampleArgs::tile_h)
 
 struct UpsampleArgs {
     const float *lo_depth;     // LoResDB  f32
@@ -95,6 +98,7 @@ struct UpsampleArgs {
     uint64_t frame_stride;     // applies to lo_*, hi_* (context-owned intermediates)
     int32_t lw, lh, hw, hh;
     int32_t tiles_x, tiles_y;
+    int32_t tile_h;            // rows of a tile: ups_tile_h(final), or kUpsTileHSmall in the final pass of a small call
     float noise_filter_strength, step_size, blur_tolerance, upsample_tolerance;
     int32_t f16_rtne;
     int32_t exact_rcp_div;     // operands proven inside the exact range of the v_rcp_f32 sequences

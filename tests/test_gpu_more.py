@@ -345,6 +345,32 @@ def test_every_blend_launch_structure_is_bit_exact(oracle, monkeypatch, mode, w,
         ao.close()
 
 
+@pytest.mark.parametrize("small_tiles", [0, 1000000])
+@pytest.mark.parametrize("variant", [dict(), dict(ao_format=1, f16_rounding=1), dict(num_levels=2)])
+@pytest.mark.parametrize("w,h,batch", [(203, 117, 2), (512, 300, 1), (131, 77, 3)])
+def test_both_render_tilings_are_bit_exact(oracle, monkeypatch, small_tiles, variant, w, h, batch):
+    """Calls with few tiles use 128 x 8 render tiles (render_small_kernel) and 64 x 32 tiles in the final
+    upsample pass (upsample_final_small_kernel), larger ones 128 x 32 and 64 x 64; the thresholds are forced
+    either way here (MEAO_DEBUG_*_SMALL_MAX_TILES, read by meao_create)."""
+    monkeypatch.setenv("MEAO_DEBUG_RENDER_SMALL_MAX_TILES", str(small_tiles))
+    monkeypatch.setenv("MEAO_DEBUG_FINAL_SMALL_MAX_TILES", str(small_tiles))     # final pass: 64 x 32 / 64 x 64 tiles
+    s = H.settings(oracle, w, h, **variant)
+    frames = [synth.make("S2", w, h, seed=70 + f) for f in range(batch)]
+    frames[0] = H.hostile_frame(w, h, 78, density=0.01)
+    ao = H.component(s, max_batch=batch)
+    try:
+        outs = ao.render_batch(frames)
+        for f in range(batch):
+            want = oracle.run(frames[f], s)
+            ok, bad = H.nan_aware_equal(outs[f], want["result"])
+            assert ok, (f, int(bad.sum()))
+            for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+                ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
+                assert ok, (H.NAMES[i], f, int(bad.sum()))
+    finally:
+        ao.close()
+
+
 # ---- round 2: contract enforcement, robustness of the boundary ------------------------------------
 
 def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
