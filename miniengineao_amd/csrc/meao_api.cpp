@@ -70,6 +70,7 @@ struct meao_ctx {
     // Upsample L4->L3 evaluated inside the L3->L2 launch (upsample_two_level_kernel); on unless the
     // A/B switch MEAO_DEBUG_NO_FUSED_BLEND=1 was set when the context was created
     bool fuse_coarse_blend = true;
+    int ds_small_max_tiles = 1024;     // stand-alone downsample pass: calls with at most this many 128x32 tiles use 128x8 tiles
     int final_small_max_tiles = 512;   // plain final pass: calls with at most this many 64x64 tiles use 64x32 tiles
     int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
     int nested_max_tiles = 512;        // calls with at most this many L2->L1 tiles (frames x tiles) run the three blend passes as one launch
@@ -326,7 +327,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     const uintptr_t depth_align = 4 * depth_elem(c.depth_format), out_align = 4 * ao_elem(c);
 
     // ---- PushDownsampleCommands (AO.cs:604-658)
-    auto downsample_args = [&](int frames, const void *const *depth, int set, uint32_t generation) {
+    auto downsample_args = [&](int frames, const void *const *depth, int set, uint32_t generation, bool small_ok = false) {
         DownsampleArgs ds{};
         bool aligned = (p.mip[0].w & 3) == 0;
         for (int f = 0; f < frames; ++f) {
@@ -347,6 +348,11 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         ds.exact_rcp_div = ctx->exact_rcp_div;
         ds.tiles_x = (p.mip[0].w + kDsTileW - 1) / kDsTileW;
         ds.tiles_y = (p.mip[0].h + kDsTileH - 1) / kDsTileH;
+        ds.row_passes = kDsTileH / kDsRowsPerPass;
+        if (small_ok && frames * ds.tiles_x * ds.tiles_y <= ctx->ds_small_max_tiles) {      // stand-alone pass of a small call
+            ds.row_passes = 1;
+            ds.tiles_y = (p.mip[0].h + kDsRowsPerPass - 1) / kDsRowsPerPass;
+        }
         ds.hostile = ctx->hostile_of(set);
         ds.generation = generation;
         return ds;
@@ -364,7 +370,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         TraceRange tr(ctx, "meao:downsample");
         ctx->set_gen[ctx->ds_cur] = next_generation();
         MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, stream));
-        MEAO_HIP(ctx, launch_downsample(downsample_args(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur]), n, stream));
+        MEAO_HIP(ctx, launch_downsample(downsample_args(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur], true), n, stream));
         MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, stream));
     }
     const uint32_t *hostile = ctx->hostile_of(ctx->ds_cur);
@@ -746,6 +752,7 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
     if (const char *m = std::getenv("MEAO_DEBUG_NESTED_MAX_TILES")) ctx->nested_max_tiles = std::atoi(m);   // A/B switch
     if (const char *m = std::getenv("MEAO_DEBUG_RENDER_SMALL_MAX_TILES")) ctx->render_small_max_tiles = std::atoi(m);
     if (const char *m = std::getenv("MEAO_DEBUG_FINAL_SMALL_MAX_TILES")) ctx->final_small_max_tiles = std::atoi(m);
+    if (const char *m = std::getenv("MEAO_DEBUG_DS_SMALL_MAX_TILES")) ctx->ds_small_max_tiles = std::atoi(m);
     meao_default_params(&ctx->prm);
     int rc = use_device(ctx);
     if (rc == MEAO_OK) {

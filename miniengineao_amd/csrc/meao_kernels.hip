@@ -311,21 +311,22 @@ __device__ __forceinline__ bool nice_denominator(float den)
 
 // First half of a downsample tile: the raw depth texels of this lane, 4 per row in each of the 4 row passes.
 // F32_ONLY: the caller has established a.depth_format == MEAO_DEPTH_F32 (no format switch in the code).
-template <bool VEC, bool F32_ONLY = false>
+// PASSES row passes of kDsRowsPerPass rows: 4 = the 32-row tile, 1 = the 8-row tile of small calls.
+template <bool VEC, bool F32_ONLY = false, int PASSES = kDsTileH / kDsRowsPerPass>
 __device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, int tile, int frame,
-                                                     float (&v)[kDsTileH / kDsRowsPerPass][4])
+                                                     float (&v)[PASSES][4])
 {
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const void *__restrict__ depth = a.depth[frame];
     const int W = a.w[0], H = a.h[0];
     const int x0 = tile_x * kDsTileW + (threadIdx.x % kDsLanesPerRow) * 4;
-    const int yb = tile_y * kDsTileH + (threadIdx.x / kDsLanesPerRow);
+    const int yb = tile_y * (PASSES * kDsRowsPerPass) + (threadIdx.x / kDsLanesPerRow);
     if (x0 >= W) return;
 
     // The depth-copy blit of the reference (Blit.shader pass 0) is folded into this load: the
     // texel format is decoded here (wave-uniform switch), 4 texels per lane per row.
 #pragma unroll
-    for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
+    for (int k = 0; k < PASSES; ++k) {
         const int y = yb + k * kDsRowsPerPass;
         v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.5f;
         if (y < H) {
@@ -375,9 +376,9 @@ __device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, in
 }
 
 // Second half: linearize, store LinearZ and the four point-sampled levels.
-template <bool RTNE, bool VEC, int DIV>
+template <bool RTNE, bool VEC, int DIV, int PASSES = kDsTileH / kDsRowsPerPass>
 __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, int tile, int frame,
-                                                       const float (&v)[kDsTileH / kDsRowsPerPass][4])
+                                                       const float (&v)[PASSES][4])
 {
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
@@ -388,7 +389,7 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
     const int W = a.w[0], H = a.h[0];
     const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
     const int x0 = tile_x * kDsTileW + (threadIdx.x % kDsLanesPerRow) * 4;
-    const int yb = tile_y * kDsTileH + (threadIdx.x / kDsLanesPerRow);
+    const int yb = tile_y * (PASSES * kDsRowsPerPass) + (threadIdx.x / kDsLanesPerRow);
     if (x0 >= W) return;
 #if MEAO_DS_LEAN
     // level widths and Z-buffer parameters once, in SGPRs (left to itself the compiler re-issues the s_load of
@@ -400,7 +401,7 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
     const float zp0 = a.zp0, zp1 = a.zp1;
 #endif
 #pragma unroll
-    for (int k = 0; k < kDsTileH / kDsRowsPerPass; ++k) {
+    for (int k = 0; k < PASSES; ++k) {
         const int y = yb + k * kDsRowsPerPass;
         if (y >= H) continue;
         float lin[4];
@@ -483,18 +484,26 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
     }
 }
 
-template <bool RTNE, bool VEC, int DIV>
+template <bool RTNE, bool VEC, int DIV, int PASSES = kDsTileH / kDsRowsPerPass>
 __device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int tile, int frame)
 {
-    float v[kDsTileH / kDsRowsPerPass][4];
-    downsample_tile_load<VEC>(a, tile, frame, v);
-    downsample_tile_finish<RTNE, VEC, DIV>(a, tile, frame, v);
+    float v[PASSES][4];
+    downsample_tile_load<VEC, false, PASSES>(a, tile, frame, v);
+    downsample_tile_finish<RTNE, VEC, DIV, PASSES>(a, tile, frame, v);
 }
 
 template <bool RTNE, bool VEC, int DIV>
 __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleArgs a)
 {
     downsample_tile<RTNE, VEC, DIV>(a, blockIdx.x, blockIdx.z);
+}
+
+// Small calls (a 1080p frame: 510 tiles of 128 x 32): tiles of one row pass, four times the workgroups, one
+// load-compute-store round each instead of four in a row.
+template <bool RTNE, bool VEC, int DIV>
+__global__ __launch_bounds__(kThreads) void downsample_small_kernel(const DownsampleArgs a)
+{
+    downsample_tile<RTNE, VEC, DIV, 1>(a, blockIdx.x, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2082,6 +2091,22 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
 {
     const dim3 grid(a.tiles_x * a.tiles_y, 1, frames), block(kThreads);
     const bool vec = a.vec_ok != 0;
+    if (a.row_passes == 1) {
+        if (a.f16_rtne) {
+            if (vec) downsample_small_kernel<true, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
+            else downsample_small_kernel<true, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        } else if (a.exact_rcp_div == 2) {
+            if (vec) downsample_small_kernel<false, true, DIV_FAST><<<grid, block, 0, s>>>(a);
+            else downsample_small_kernel<false, false, DIV_FAST><<<grid, block, 0, s>>>(a);
+        } else if (a.exact_rcp_div) {
+            if (vec) downsample_small_kernel<false, true, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
+            else downsample_small_kernel<false, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a);
+        } else {
+            if (vec) downsample_small_kernel<false, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
+            else downsample_small_kernel<false, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
+        }
+        return hipGetLastError();
+    }
     if (a.f16_rtne) {
         if (vec) downsample_kernel<true, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
         else downsample_kernel<true, false, DIV_IEEE><<<grid, block, 0, s>>>(a);

@@ -22,6 +22,7 @@ struct DownsampleArgs {
     int32_t f16_rtne;
     int32_t exact_rcp_div;
     int32_t tiles_x, tiles_y;
+    int32_t row_passes;       // row passes per tile: kDsTileH / kDsRowsPerPass, or 1 (downsample_small_kernel; stand-alone pass of small calls)
     int32_t frames;                      // used by the fused kernel only (the plain launch has grid.z = frames)
     int32_t vec_ok;                      // width % 4 == 0 and every depth pointer aligned for 4-texel loads
     // hostile[frame] = generation when a texel of the frame is outside the range the exact

@@ -354,6 +354,7 @@ def test_both_render_tilings_are_bit_exact(oracle, monkeypatch, small_tiles, var
     either way here (MEAO_DEBUG_*_SMALL_MAX_TILES, read by meao_create)."""
     monkeypatch.setenv("MEAO_DEBUG_RENDER_SMALL_MAX_TILES", str(small_tiles))
     monkeypatch.setenv("MEAO_DEBUG_FINAL_SMALL_MAX_TILES", str(small_tiles))     # final pass: 64 x 32 / 64 x 64 tiles
+    monkeypatch.setenv("MEAO_DEBUG_DS_SMALL_MAX_TILES", str(small_tiles))        # downsample pass: 128 x 8 / 128 x 32 tiles
     s = H.settings(oracle, w, h, **variant)
     frames = [synth.make("S2", w, h, seed=70 + f) for f in range(batch)]
     frames[0] = H.hostile_frame(w, h, 78, density=0.01)
