@@ -45,41 +45,11 @@
 #include <algorithm>
 #include <type_traits>
 
-// Build-time switches for A/B runs (tests/build_variants.py builds variants next to the product
-// library; measured outcomes in profiles/README.md).
-#ifndef MEAO_UPS_HOIST
-#define MEAO_UPS_HOIST 1        // hi-res depth / AO loads of the bilateral phase issued at the top of the tile
-#endif
-#ifndef MEAO_REN_SWPIPE
-#define MEAO_REN_SWPIPE 1       // render texel loop with hand-pipelined LDS reads (accumulate_terms_pipelined); 0 = compiler-scheduled
-#endif
-#ifndef MEAO_REN_SWPIPE_DEPTH
-#define MEAO_REN_SWPIPE_DEPTH 1 // sample pairs in flight ahead of the one being evaluated (1 or 2)
-#endif
-#ifndef MEAO_REN_VGPR_CONSTS
-#define MEAO_REN_VGPR_CONSTS 1  // pipelined render loop: -frontDepth and the reject fade-off as VGPR instead of SGPR operands (an SGPR source halves the VALU rate)
-#endif
-#ifndef MEAO_UPS_VGPR_CONSTS
-#define MEAO_UPS_VGPR_CONSTS 0  // bilateral phase: tolerance, noise strength and the 3 / 9 of the weights as VGPR operands
-#endif
-#ifndef MEAO_FUSE_SPLIT_DS
-#define MEAO_FUSE_SPLIT_DS 2    // fused last kernel: the carried downsample tile's loads are issued inside the upsample tile
-#endif                          // (1 = after its prefetch, 2 = before its bilateral phase) and consumed after it; 0 = tile first
-#ifndef MEAO_UPS_LOADS_ORDER
-#define MEAO_UPS_LOADS_ORDER 1  // interior upsample tiles: low-res window loads first, hoisted hi-res loads behind them, all
-#endif                          // straight-line (vmcnt retires in order: the window wait then no longer includes the hi-res loads)
-#ifndef MEAO_DS_LEAN
-#define MEAO_DS_LEAN 0          // downsample tile: 32-bit byte offsets from uniform bases (saddr addressing), arguments pinned in
-#endif                          // SGPRs, the four f16 conversions of a row as two v_cvt_pkrtz_f16_f32
-#ifndef MEAO_SETPRIO
-#define MEAO_SETPRIO 1          // waves raise their issue priority while they load a tile's window (render fill / upsample prefetch)
-#endif
-#ifndef MEAO_UPS_ALIGNED_FILL
-#define MEAO_UPS_ALIGNED_FILL 0 // interior upsample tiles: the window goes to LDS as aligned 16-byte stores (one element from the next lane by DPP)
-#endif
-#ifndef MEAO_REN_FASTPATH
-#define MEAO_REN_FASTPATH 0     // wave-uniform "all distances >= 0" path in the render kernel (bit-exact; slower, see test_samples)
-#endif
+// Every design decision below that replaced an alternative was A/B-measured on one box; the arms that
+// lost (or changed nothing) were removed in round 3 -- their logs stay in profiles/ (r02_ab_*.jsonl) and
+// profiles/README.md lists them.  Experimental arms of the current round live behind the MEAO_X_* switches
+// of this block only (tests/build_variants.py builds variants next to the product library;
+// tests/test_variants_gpu.py runs a parity smoke through every variant library it finds).
 
 namespace meao {
 namespace {
@@ -332,9 +302,7 @@ __device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, in
         if (y < H) {
             const size_t at = static_cast<size_t>(y) * W + x0;
             if (F32_ONLY || a.depth_format == MEAO_DEPTH_F32) {
-                const float *row = MEAO_DS_LEAN ? at_byte_offset(static_cast<const float *>(depth),
-                                                                 (static_cast<uint32_t>(y) * static_cast<uint32_t>(W) + static_cast<uint32_t>(x0)) * 4u)
-                                                : static_cast<const float *>(depth) + at;
+                const float *row = static_cast<const float *>(depth) + at;
                 if constexpr (VEC) {
                     const float4v q = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(row));
                     v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
@@ -391,15 +359,7 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
     const int x0 = tile_x * kDsTileW + (threadIdx.x % kDsLanesPerRow) * 4;
     const int yb = tile_y * (PASSES * kDsRowsPerPass) + (threadIdx.x / kDsLanesPerRow);
     if (x0 >= W) return;
-#if MEAO_DS_LEAN
-    // level widths and Z-buffer parameters once, in SGPRs (left to itself the compiler re-issues the s_load of
-    // every one of them inside each store branch, with an s_waitcnt lgkmcnt(0) behind it)
-    uint32_t w1 = a.w[1], w2 = a.w[2], w3 = a.w[3], w4 = a.w[4];
-    float zp0 = a.zp0, zp1 = a.zp1;
-    asm volatile("" : "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(zp0), "+s"(zp1));
-#else
     const float zp0 = a.zp0, zp1 = a.zp1;
-#endif
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
         const int y = yb + k * kDsRowsPerPass;
@@ -424,35 +384,6 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
             for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], zp0, zp1, sky_depth);
         }
 
-#if MEAO_DS_LEAN
-        if constexpr (VEC) {
-            const uint32_t ux = x0, uy = y;
-            uint32_t lo, hi;                                              // LinearZ[st] = dist (DS1:46)
-            if constexpr (RTNE) {
-                lo = f32_to_f16_bits<true>(lin[0]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[1])) << 16);
-                hi = f32_to_f16_bits<true>(lin[2]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[3])) << 16);
-            } else {
-                lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[0], lin[1]));
-                hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[2], lin[3]));
-            }
-            typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
-            __builtin_nontemporal_store(uint2v{lo, hi}, reinterpret_cast<uint2v *>(
-                at_byte_offset(linear, (uy * static_cast<uint32_t>(W) + ux) * 2u)));
-            if ((y & 1) == 0) {                                           // DS2x (DS1:64-70)
-                __builtin_nontemporal_store(float2v{lin[0], lin[2]}, reinterpret_cast<float2v *>(
-                    at_byte_offset(low1, ((uy >> 1) * w1 + (ux >> 1)) * 4u)));
-                if ((y & 3) == 0) {                                       // DS4x (DS1:73-77)
-                    *at_byte_offset(low2, ((uy >> 2) * w2 + (ux >> 2)) * 4u) = lin[0];
-                    if ((y & 7) == 0 && (x0 & 7) == 0) {                  // DS8x (DS2:35-40)
-                        *at_byte_offset(low3, ((uy >> 3) * w3 + (ux >> 3)) * 4u) = lin[0];
-                        if ((y & 15) == 0 && (x0 & 15) == 0)              // DS16x (DS2:43-49)
-                            *at_byte_offset(low4, ((uy >> 4) * w4 + (ux >> 4)) * 4u) = lin[0];
-                    }
-                }
-            }
-            continue;
-        }
-#endif
         uint16_t *lrow = linear + static_cast<size_t>(y) * W + x0;    // LinearZ[st] = dist (DS1:46)
         if constexpr (VEC) {
             ushort4v h;
@@ -520,12 +451,6 @@ __device__ __forceinline__ float pair_from_distances(float d1, float d2, float r
     return sat(mad(-p1, p2, acc));
 }
 
-// When d1 >= 0 and d2 >= 0 (no NaN): p1 = p2 = 0, so the pair is saturate(saturate(d1) + saturate(d2)),
-// and that equals saturate(d1 + d2): if both are <= 1 the expressions are identical; if one exceeds 1
-// both sides are 1 (rounding is monotonic, so d1 + d2 >= max(d1, d2)).  One v_add_f32 with clamp.
-__device__ __forceinline__ float pair_all_nonnegative(float d1, float d2) { return sat(d1 + d2); }
-
-
 // TestSamples (REN:77-110) WITHOUT its leading 0.5 / 0.25: that exact power-of-two factor is folded
 // into the term's weight on the host (RenderLevelArgs::weight), since fma(w, k*S, ao) and
 // fma(k*w, S, ao) round the same real number.  (X, Y) are sample offsets in source texels; the LDS
@@ -533,14 +458,11 @@ __device__ __forceinline__ float pair_all_nonnegative(float d1, float d2) { retu
 // P = 4*pitch, Q = 4.  Wide (REN:79-82, x <<= 1): P = 2*pitch, Q = 2.
 // Two horizontally adjacent texels share every LDS address: one 8-byte LDS read per sample.
 //
-// FAST (wave-uniform fast path, bit-exact): the 8 / 16 distances of the term are computed first; if no
-// lane of the wave has a negative one (v_min3 chain, one ballot), every pair of the term is
-// pair_all_nonnegative -- 1 instruction instead of 6.  `try_fast` carries the outcome to the next term
-// of the same texel: neighbouring terms sample the same neighbourhood, so after a miss the remaining
-// terms skip the test (a frame of slopes costs one failed test per texel, not seven).
-template <int X, int Y, int P, int Q, bool FAST>
+// (A wave-uniform "all distances >= 0 => pair = saturate(d1 + d2)" fast path was built, is bit-exact and was
+// measured slower on both headline workloads -- DESIGN.md 5.2, profiles/r02_render_fastpath_hitrates.txt; removed.)
+template <int X, int Y, int P, int Q>
 __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv_depth, float inv_thickness,
-                                                float front_depth, float reject, bool &try_fast)
+                                                float front_depth, float reject)
 {
     constexpr int N = (Y == 0 || X == Y) ? 2 : 4;
     constexpr int off[4] = {Y == 0 ? X * Q : (X == Y ? X * P - X * Q : Y * P + X * Q),
@@ -557,28 +479,9 @@ __device__ __forceinline__ float2v test_samples(const float *centre, float2v inv
         d2[i] = float2v{mad(s2.x, inv_range.x, neg_front), mad(s2.y, inv_range.y, neg_front)};
     }
     float2v r[N];
-    bool fast = false;
-    if constexpr (FAST) {
-        if (try_fast) {
-            // minimum of the distances (v_min3_f32 chain; the inputs are NaN-free here).  Not an OR of
-            // the sign bits: ROCm 7.2's clang drops operands from or(bitcast(...)) < 0 (seen, reproduced).
-            float lowest = __builtin_fminf(__builtin_fminf(d1[0].x, d1[0].y), __builtin_fminf(d2[0].x, d2[0].y));
 #pragma unroll
-            for (int i = 1; i < N; ++i)
-                lowest = __builtin_fminf(__builtin_fminf(lowest, __builtin_fminf(d1[i].x, d1[i].y)), __builtin_fminf(d2[i].x, d2[i].y));
-            fast = __builtin_amdgcn_ballot_w64(lowest < 0.0f) == 0;   // wave-uniform
-            try_fast = fast;
-        }
-    }
-    if (fast) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            r[i] = float2v{pair_all_nonnegative(d1[i].x, d2[i].x), pair_all_nonnegative(d1[i].y, d2[i].y)};
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            r[i] = float2v{pair_from_distances(d1[i].x, d2[i].x, reject), pair_from_distances(d1[i].y, d2[i].y, reject)};
-    }
+    for (int i = 0; i < N; ++i)
+        r[i] = float2v{pair_from_distances(d1[i].x, d2[i].x, reject), pair_from_distances(d1[i].y, d2[i].y, reject)};
     if constexpr (N == 2) return r[0] + r[1];
     else return ((r[0] + r[1]) + r[2]) + r[3];
 }
@@ -610,14 +513,13 @@ struct TermConstants {
     }
 };
 
-template <bool EXH, int P, int Q, bool FAST>
+template <bool EXH, int P, int Q>
 __device__ __forceinline__ float2v accumulate_terms(const TermConstants<EXH> &L, const float *centre, float2v inv_depth)
 {
     const float reject = L.reject_fadeoff;
     float2v ao = splat(0.0f);
-    bool try_fast = true;
 #define MEAO_TERM(N, X, Y) \
-    ao = fma2(splat(L.weight[N]), test_samples<X, Y, P, Q, FAST>(centre, inv_depth, L.inv_thickness[N], L.front_depth[N], reject, try_fast), ao)
+    ao = fma2(splat(L.weight[N]), test_samples<X, Y, P, Q>(centre, inv_depth, L.inv_thickness[N], L.front_depth[N], reject), ao)
     if constexpr (EXH) {
         MEAO_TERM(0, 1, 0); MEAO_TERM(1, 2, 0); MEAO_TERM(2, 3, 0); MEAO_TERM(3, 4, 0);
         MEAO_TERM(4, 1, 1); MEAO_TERM(5, 2, 2); MEAO_TERM(6, 3, 3); MEAO_TERM(7, 1, 2);
@@ -630,7 +532,7 @@ __device__ __forceinline__ float2v accumulate_terms(const TermConstants<EXH> &L,
     return fma2(splat(L.intensity), ao - splat(1.0f), splat(1.0f));   // lerp(1, ao, gIntensity) REN:176
 }
 
-// ---- the same sum with the LDS reads pipelined by hand (MEAO_REN_SWPIPE) ----------------------
+// ---- the same sum with the LDS reads pipelined by hand (checker set) --------------------------
 // clang issues the ds_read's of a term right before their first use (s_waitcnt a few instructions
 // later): every wave exposes the LDS latency 12+ times per texel pair.  Here the 18 sample pairs of
 // the checker set are one flat sequence; the two 8-byte reads of pair k + DEPTH are issued before pair k
@@ -712,7 +614,7 @@ __device__ __forceinline__ void pipelined_checker_step(const TermConstants<false
         if constexpr (i == 0) {
             inv_range = splat(L.inv_thickness[t]) * inv_depth;
             neg_front = -L.front_depth[t];
-            if constexpr (MEAO_REN_VGPR_CONSTS) asm volatile("" : "+v"(neg_front));
+            asm volatile("" : "+v"(neg_front));      // VGPR operand: an SGPR source halves the VALU issue rate (tools/ubench_issue.hip)
         }
         const float2v d1 = float2v{mad(s.s1.x, inv_range.x, neg_front), mad(s.s1.y, inv_range.y, neg_front)};
         const float2v d2 = float2v{mad(s.s2.x, inv_range.x, neg_front), mad(s.s2.y, inv_range.y, neg_front)};
@@ -737,7 +639,7 @@ __device__ __forceinline__ float2v accumulate_terms_pipelined(const TermConstant
         if (k == 1) issue_checker_pair<1, P, Q>(base, ring[1]);
     }
     float reject = L.reject_fadeoff, neg_front = 0.0f;
-    if constexpr (MEAO_REN_VGPR_CONSTS) asm volatile("" : "+v"(reject));
+    asm volatile("" : "+v"(reject));
     pipelined_checker_step<0, P, Q, DEPTH>(L, base, inv_depth, reject, ring, inv_range, neg_front, term_sum, ao);
     return fma2(splat(L.intensity), ao - splat(1.0f), splat(1.0f));   // lerp(1, ao, gIntensity) REN:176
 }
@@ -782,7 +684,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     const int lw = L.lw, lh = L.lh;
     const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, frame);
 
-    if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);
     // ---- stage the (64+32) x (32+32) window.  Window texel (vx,vy) (level coordinates, may
     // be outside the level) belongs to slice (vx&3, vy&3), slice texel (vx>>2, vy>>2); the
     // reference clamps the slice texel per slice (REN:118 Gather + clamp sampler) and finds
@@ -831,7 +733,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
         }
     }
     __syncthreads();
-    if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
 
     // ---- each lane: a texel pair (X, X+1) in each of the TILE_H / 8 iterations
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
@@ -851,12 +753,9 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
             const float *centre = &tile[(ly + kRenApron) * kRenLdsW + 2 * txl + kRenApron];
             const float2v c = *reinterpret_cast<const float2v *>(centre);
             const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-            // the fast path assumes NaN-free distances: the body hostile frames (and RTNE storage, inf samples) run has it off
-            float2v out;
-            if constexpr (MEAO_REN_SWPIPE && !EXH)
-                out = accumulate_terms_pipelined<4 * kRenLdsW, 4, MEAO_REN_SWPIPE_DEPTH>(terms, centre, inv_depth);
-            else
-                out = accumulate_terms<EXH, 4 * kRenLdsW, 4, MEAO_REN_FASTPATH && DIV == DIV_EXACT_RCP>(terms, centre, inv_depth);
+            float2v out;     // one pair in flight ahead of the one evaluated; a second one changed nothing (r02 A/B)
+            if constexpr (!EXH) out = accumulate_terms_pipelined<4 * kRenLdsW, 4, 1>(terms, centre, inv_depth);
+            else out = accumulate_terms<EXH, 4 * kRenLdsW, 4>(terms, centre, inv_depth);
 
             typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
             const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
@@ -946,7 +845,7 @@ __device__ __forceinline__ void render_wide_tile(const RenderArgs &a, float *til
         const float *centre = &tile[(ly + kWideApron) * kWideLdsW + 2 * txl + kWideApron];
         const float2v c = *reinterpret_cast<const float2v *>(centre);
         const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-        const float2v out = accumulate_terms<EXH, 2 * kWideLdsW, 2, false>(terms, centre, inv_depth);
+        const float2v out = accumulate_terms<EXH, 2 * kWideLdsW, 2>(terms, centre, inv_depth);
 
         typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
         const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
@@ -984,14 +883,11 @@ struct UpsTile {
     static constexpr int kRawPitch = 40;
     static constexpr int kBlurW = kLowW + 2, kBlurH = kLowH + 2;     // blurred texels: 34 x 18|34
     static constexpr int kBlurPitch = 36;
-#ifndef MEAO_UPS_LONG_RUNS
-#define MEAO_UPS_LONG_RUNS 1   // A/B: -2.2 % on the full-resolution pass (220 -> 215 us per 16 frames)
-#endif
     // Run lengths are chosen so that each blur phase is ONE round over the 256 lanes (the phases are
     // latency-bound: a second, partly filled round costs a full LDS round trip): 64-row tiles use
     // 6 x 38 = 228 horizontal runs of 6 and 7 x 34 = 238 vertical runs of 5 (runs of 4 / 4: 342 and 306
     // items, two rounds each); 32-row tiles 9 x 22 = 198 runs of 4 and 6 x 34 = 204 runs of 3.
-    static constexpr bool kLong = MEAO_UPS_LONG_RUNS && TILE_H == 64;
+    static constexpr bool kLong = TILE_H == 64;          // A/B: -2.2 % on the full-resolution pass (220 -> 215 us per 16 frames)
     static constexpr int kHRun = kLong ? 6 : 4, kHSegs = (kBlurW + kHRun - 1) / kHRun;
     static constexpr int kVRun = kLong ? 5 : ((kBlurH % 3 == 0) ? 3 : 4);
     static constexpr int kVSegs = (kBlurH + kVRun - 1) / kVRun;
@@ -1041,16 +937,12 @@ __device__ __forceinline__ void blur_run(const BlurConsts &k, const float (&a)[N
 }
 
 // BilateralUpsample (UPS:177-183); taps already in weight order 9,3,1,3.
-// The uniform operands of the bilateral phase.  With MEAO_UPS_VGPR_CONSTS they are pinned in VGPRs: an
-// SGPR (or literal) source costs the VALU ~0.2 cycles per instruction (tools/ubench_issue.hip, "constants
-// in SGPRs"), and 9 of the 41 instructions per upsampled texel read one.
+// The uniform operands of the bilateral phase (SGPRs / literals; pinning them in VGPRs changed nothing here:
+// this phase waits on latency, not on VALU issue, profiles/r02_ab_v14*_ups_vgpr_consts.jsonl).
 struct BilateralConsts {
     float tolerance, noise, three, nine;
     __device__ __forceinline__ BilateralConsts(float upsample_tolerance, float noise_filter_strength)
-        : tolerance(upsample_tolerance), noise(noise_filter_strength), three(3.0f), nine(9.0f)
-    {
-        if constexpr (MEAO_UPS_VGPR_CONSTS) asm volatile("" : "+v"(tolerance), "+v"(noise), "+v"(three), "+v"(nine));
-    }
+        : tolerance(upsample_tolerance), noise(noise_filter_strength), three(3.0f), nine(9.0f) {}
 };
 
 template <int DIV>
@@ -1136,8 +1028,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
     const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
 
-    if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(3);
-#if MEAO_UPS_HOIST
+    __builtin_amdgcn_s_setprio(3);
     // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
     // are issued first, so that their latency hides behind the prefetch and blur phases.
     constexpr int kPasses = kTileH / 32;
@@ -1172,14 +1063,12 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             }
     };
     // interior tile, 16-byte loads everywhere, no second AO input: window loads first (see below)
-    const bool window_first = MEAO_UPS_LOADS_ORDER && !NESTED && hoist_ok && !lo_ao2 && ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
+    const bool window_first = !NESTED && hoist_ok && !lo_ao2 && ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
     if (hoist_ok && !window_first) issue_hoisted(std::false_type());
-#endif
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
     // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
     const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
-#if MEAO_UPS_HOIST && MEAO_UPS_LOADS_ORDER
     if (window_first) {
         // The window comes from L2 (written by the previous pass), the hi-res operands of the final pass from
         // HBM; vmcnt retires loads in issue order, so with the hi-res loads in front the window wait lasts an
@@ -1209,49 +1098,8 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 asm volatile("" : : "v"(__builtin_bit_cast(bits_t, wa[round])));
             }
             const int i = threadIdx.x + round * kThreads;
-#if MEAO_UPS_ALIGNED_FILL
-            if constexpr (!NESTED) {
-                // A lane holds window columns 4k-1 .. 4k+2 (its 16-byte load starts one texel left of the
-                // window): four scalar stores per array at a lane stride of 4 floats are 4-way bank conflicts,
-                // 43 % of this kernel's LDS cycles.  Each lane takes column 4k+3 from the next lane (DPP
-                // wave_shl:1, all lanes active) and stores the aligned quad 4k .. 4k+3 with one ds_write_b128;
-                // at the end of a window row that fourth column is row padding.  The wave's last lane has no
-                // neighbour (stores three), its first lane also stores its own column 4k-1.
-                const float dv[4] = {wd[round].x, wd[round].y, wd[round].z, wd[round].w};
-                const float av[4] = {AO::decode(wa[round].x), AO::decode(wa[round].y), AO::decode(wa[round].z), AO::decode(wa[round].w)};
-                float iv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) iv[e] = rcp_strict<DIV>(dv[e]);                    // UPS:67
-                auto from_next_lane = [](float x) {
-                    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
-                };
-                const float d_n = from_next_lane(dv[0]), i_n = from_next_lane(iv[0]), a_n = from_next_lane(av[0]);
-                if (i < kItems) {
-                    const int r = i / 10, k = i % 10, c0 = 4 * k;
-                    const int lane = threadIdx.x & 63;
-                    float *pi = &s_inv[r * T::kRawPitch + c0], *pa = &s_ao[r * T::kRawPitch + c0];
-                    if (lane != 63) {
-                        *reinterpret_cast<float4v *>(pi) = float4v{iv[1], iv[2], iv[3], i_n};
-                        *reinterpret_cast<float4v *>(pa) = float4v{av[1], av[2], av[3], a_n};
-                    } else {
-                        *reinterpret_cast<float2v *>(pi) = float2v{iv[1], iv[2]}; pi[2] = iv[3];
-                        *reinterpret_cast<float2v *>(pa) = float2v{av[1], av[2]}; pa[2] = av[3];
-                    }
-                    // LoResDB keeps columns kDep0 .. kDep0 + kDepW - 1 (even bounds): pairs are kept or dropped whole
-                    if (dep_kept(r, c0)) *reinterpret_cast<float2v *>(&dep_at(r, c0)) = float2v{dv[1], dv[2]};
-                    if (dep_kept(r, c0 + 2)) {
-                        if (lane != 63) *reinterpret_cast<float2v *>(&dep_at(r, c0 + 2)) = float2v{dv[3], d_n};
-                        else dep_at(r, c0 + 2) = dv[3];
-                    }
-                    if (lane == 0 && k > 0) {               // column 4k-1: the previous lane belongs to another wave
-                        s_inv[r * T::kRawPitch + c0 - 1] = iv[0];
-                        s_ao[r * T::kRawPitch + c0 - 1] = av[0];
-                        if (dep_kept(r, c0 - 1)) dep_at(r, c0 - 1) = dv[0];
-                    }
-                }
-                continue;
-            }
-#endif
+            // (storing the window as aligned 16-byte quads -- fourth column from the next lane by DPP -- removes the 4-way
+            // bank conflicts of these scalar stores and changes nothing: profiles/r02_ab_v23_aligned_fill.jsonl)
             if (i < kItems) {
                 const int r = i / 10, k = i % 10;
                 const float dv[4] = {wd[round].x, wd[round].y, wd[round].z, wd[round].w};
@@ -1271,9 +1119,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 }
             }
         }
-    } else
-#endif
-    if (interior_x) {
+    } else if (interior_x) {
         // no horizontal clamping inside this tile: one aligned 16-byte depth load (+ 4 AO texels)
         // per lane covers the 40-texel row segment [LX0-4, LX0+35]
         for (int i = threadIdx.x; i < 10 * T::kRawH; i += kThreads) {
@@ -1318,7 +1164,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         }
     }
     __syncthreads();
-    if constexpr (MEAO_SETPRIO) __builtin_amdgcn_s_setprio(0);       // (kept through the blur phases: +10 % on the pass)
+    __builtin_amdgcn_s_setprio(0);       // (kept through the blur phases: +10 % on the pass)
     hook.after_prefetch();
 
     // ---- BlurHorizontally: runs of 4 outputs; output (r, c) is centred on raw column c+2.
@@ -1370,7 +1216,6 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         for (int n = 0; n < T::kVRun; ++n) s_vb[(r0 + n) * T::kBlurPitch + c] = o[n];
     }
     __syncthreads();
-#if MEAO_UPS_HOIST
     if constexpr (Hook::kBeforeBilateral && FINAL) {
         // vmcnt retires in order: a load issued here would sit behind nothing only if the hoisted operands
         // are waited for first -- naming them in an asm makes the compiler put that wait here
@@ -1381,7 +1226,6 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         hook.before_bilateral();
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
 
     // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
@@ -1392,11 +1236,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const int tx = threadIdx.x & 15;
     const int hx0 = HX0 + 4 * tx;
     if (hx0 >= hw) return;
-#if MEAO_UPS_HOIST
 #pragma unroll       // the hoisted operands live in registers: static indices
-#else
-#pragma unroll 1
-#endif
     for (int pass = 0; pass < kTileH / 32; ++pass) {
         const int ty = (threadIdx.x >> 4) + 16 * pass;
         const int hy0 = HY0 + 2 * ty;
@@ -1422,11 +1262,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             if constexpr (FINAL) {
                 const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
                 if (vec_ok) {
-#if MEAO_UPS_HOIST
                     const ushort4v q = hoist_hd16[pass][f];
-#else
-                    const ushort4v q = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(p));   // read once
-#endif
                     hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
                     hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
                 } else {
@@ -1437,13 +1273,8 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
                 const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
                 if (vec_ok) {
-#if MEAO_UPS_HOIST
                     const float4v d4 = hoist_hd32[pass][f];
                     const typename AO::type4 a4 = hoist_ha[pass][f];
-#else
-                    const float4v d4 = *reinterpret_cast<const float4v *>(p);
-                    const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(q);
-#endif
                     hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
                     ha[0] = AO::decode(a4.x); ha[1] = AO::decode(a4.y);
                     ha[2] = AO::decode(a4.z); ha[3] = AO::decode(a4.w);
@@ -1711,10 +1542,11 @@ __global__ __launch_bounds__(kThreads) void upsample_three_level_kernel(const Up
     upsample_three_level_tile<AOFMT, RTNE, DIV>(outer, mid, inner, smem, tile, frame);
 }
 
-// Hook of the fused last kernel (MEAO_FUSE_SPLIT_DS): puts the four 16-byte depth loads of the carried
-// downsample tile in flight inside the upsample tile; 1 = after its prefetch, 2 = before its bilateral phase.
+// Hook of the fused last kernel: puts the four 16-byte depth loads of the carried downsample tile in flight
+// inside the upsample tile, before its bilateral phase (A/B against "tile first" and "after the prefetch":
+// profiles/r02_ab_v15p..v17p_split_ds*.jsonl).
 struct IssueCarriedLoads {
-    static constexpr bool kBeforeBilateral = MEAO_FUSE_SPLIT_DS == 2;
+    static constexpr bool kBeforeBilateral = true;
     const DownsampleArgs &d;
     float (&v)[kDsTileH / kDsRowsPerPass][4];
     bool mine;
@@ -1743,7 +1575,6 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsamp
                 else downsample_tile<RTNE, false, DIV>(d, t, f);
             }
     };
-#if MEAO_FUSE_SPLIT_DS
     // One downsample tile per workgroup (the usual case: both grids tile the same frame) with 16-byte f32
     // loads: its four loads per lane go out after the upsample tile's prefetch wait -- issued earlier they
     // would sit in front of that wait (vmcnt counts in order) -- and are consumed after the bilateral phase.
@@ -1760,10 +1591,6 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsamp
     const IssueCarriedLoads issue = {d, v, mine};
     upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z, issue);
     if (mine) downsample_tile_finish<RTNE, true, DIV>(d, blockIdx.x, blockIdx.z, v);
-#else
-    carried_downsample();
-    upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1942,13 +1769,8 @@ __global__ __launch_bounds__(kThreads) void composite_kernel(const CompositeArgs
 // the composite is pure streaming (17 bytes per texel, as many bytes as the whole AO path) and render
 // is VALU-bound with HBM nearly idle, so every render workgroup first streams its share of the
 // composite texel pairs and then renders its tile.
-#ifndef MEAO_COMPOSITE_IN_LOOP
-#define MEAO_COMPOSITE_IN_LOOP 1   // carried composite (multiply mode): two pixel pairs per lane in flight under every texel-loop iteration
-#endif
-#ifndef MEAO_COMPOSITE_PER_ITERATION
-#define MEAO_COMPOSITE_PER_ITERATION 2
-#endif
-constexpr int kCompositePerIteration = MEAO_COMPOSITE_PER_ITERATION;          // pixel pairs per lane in flight under one iteration
+// carried composite (multiply mode): two pixel pairs per lane in flight under every texel-loop iteration (three: 0.830 vs 0.834 ms, not kept)
+constexpr int kCompositePerIteration = 2;
 constexpr int kCompositePairsInLoop = kCompositePerIteration * (kRenTileH / 8);
 
 // Pass 2 of Blit.shader (dst * src.a) for pixel pairs of ONE frame, as the hook of the render texel loop:
@@ -2013,7 +1835,7 @@ __global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_with_composit
     __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(false) + 2 * kRenApron)];
     const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
     // In-loop form: one composite frame per render frame, multiply mode, frames below 2^28 pairs (32-bit byte offsets)
-    const bool in_loop = MEAO_COMPOSITE_IN_LOOP && c.mode == MEAO_COMPOSITE_MULTIPLY && c.frames == static_cast<int32_t>(gridDim.y) &&
+    const bool in_loop = c.mode == MEAO_COMPOSITE_MULTIPLY && c.frames == static_cast<int32_t>(gridDim.y) &&
                          c.pixels < (int64_t(1) << 29);
     CarriedComposite<AOFMT> carried;
     carried.active = in_loop;

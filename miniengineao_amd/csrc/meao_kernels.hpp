@@ -40,10 +40,8 @@ constexpr int ren_tile_w(bool exhaustive) { return exhaustive ? 64 : 128; }
 constexpr int kRenTileH = 32;
 constexpr int kRenTileHSmall = 8;               // calls with fewer 128 x 32 tiles than CUs: four times the workgroups, one texel-loop iteration each
 constexpr int kWideTileW = 64;                                 // Render.main (wide) keeps 64 x 32, 256 threads
-#ifndef MEAO_DS_TILE_W
-#define MEAO_DS_TILE_W 128      // A/B: downsample tile 128 x 32 (default), 256 x 16, 512 x 8 -- always 4096 texels, 256 lanes x 4 row passes
-#endif
-constexpr int kDsTileW = MEAO_DS_TILE_W, kDsTileH = 4096 / kDsTileW;
+// downsample tile 128 x 32 (A/B against 256 x 16 and 512 x 8: profiles/r02_ab_v20_ds_tile_shape.jsonl) -- 4096 texels, 256 lanes x 4 row passes
+constexpr int kDsTileW = 128, kDsTileH = 4096 / kDsTileW;
 constexpr int kDsLanesPerRow = kDsTileW / 4, kDsRowsPerPass = 256 / kDsLanesPerRow;     // a lane covers 4 texels of a row
 constexpr int kRenApron = 16;                   // 4 slice texels * interleave 4
 constexpr int kRenLdsH = kRenTileH + 2 * kRenApron;            // rows of the staged window; columns: tile width + 2 * apron
