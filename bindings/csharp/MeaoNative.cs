@@ -98,7 +98,7 @@ namespace MiniEngineAO.Native
     public static class Meao
     {
         const string Lib = "meao_hip";   // libmeao_hip.so
-        public const int AbiVersion = 4;
+        public const int AbiVersion = 5;
         public const int MaxBatch = 64;
         public const int NumPasses = 7;
         public const int DebugOcclusionHq1 = 18;
@@ -147,8 +147,14 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern IntPtr meao_pool_last_error(IntPtr pool);
         [DllImport(Lib)] public static extern int meao_pool_set_params(IntPtr pool, ref MeaoParams p);
         [DllImport(Lib)] public static extern int meao_pool_execute_batch(IntPtr pool, int n, IntPtr[] depth, int depth_loc, IntPtr[] ao_out, int out_loc);
+        [DllImport(Lib)] public static extern int meao_pool_prefetch_batch(IntPtr pool, int n, IntPtr[] depth);
+        [DllImport(Lib)] public static extern int meao_pool_composite_enqueue(IntPtr pool, int mode, int n, IntPtr[] ao, IntPtr[] color_rgba16f, IntPtr[] gbuffer0_rgba8);
+        [DllImport(Lib)] public static extern int meao_pool_composite_flush(IntPtr pool);
         [DllImport(Lib)] public static extern int meao_pool_gather_to_device(IntPtr pool, int n, IntPtr[] ao_src, IntPtr[] dst, int dst_device);
+        [DllImport(Lib)] public static extern int meao_pool_gather_path(IntPtr pool, int member, int dst_device);   // 0 same device, 1 peer (xGMI), 2 staged
         [DllImport(Lib)] public static extern int meao_pool_synchronize(IntPtr pool);
+        [DllImport(Lib)] public static extern int meao_hostile_frames(IntPtr ctx, out ulong mask);
+        [DllImport(Lib)] public static extern int meao_debug_set(IntPtr ctx, int key, int value);   // launch-structure overrides / fault injection (tests)
         [DllImport(Lib)] public static extern int meao_debug_view(IntPtr ctx, int frame, int debug_id, IntPtr dst, int out_loc, IntPtr stream);
         [DllImport(Lib)] public static extern int meao_composite(IntPtr ctx, int mode, IntPtr ao, IntPtr color_rgba16f, IntPtr gbuffer0_rgba8, int loc, IntPtr stream);
     }

@@ -32,7 +32,7 @@ extern "C" {
 #define MEAO_API
 #endif
 
-#define MEAO_ABI_VERSION 4
+#define MEAO_ABI_VERSION 5
 #define MEAO_MAX_BATCH 64      /* frames per batched launch */
 #define MEAO_NUM_PASSES 7      /* downsample, render, upsample x4, render_hq (see meao_pass) */
 
@@ -62,7 +62,12 @@ typedef enum meao_f16_rounding { MEAO_F16_RTZ_CLAMP = 0, MEAO_F16_RTNE = 1 } mea
 /* STRICT (default): bit-exact against the CPU oracle (correctly rounded '/', explicit mad fusion
  * only).  FAST: every divide is the raw 1-ulp v_rcp_f32 times the numerator; NOT bit-exact --
  * AO texels may differ from STRICT by one storage step on a small fraction of texels; everything
- * else (fusion, storage conversions) is unchanged.  Applies with RTZ_CLAMP depth storage. */
+ * else (fusion, storage conversions) is unchanged.  Applies with RTZ_CLAMP depth storage.
+ * FAST is OUTSIDE the project's parity bar ("within 1 ULP fp16 of the reference path"): with F16 AO
+ * storage it was measured up to 4 fp16 ulps away from STRICT (a 1-ulp weight difference can flip a
+ * CompareDeltas decision downstream; tests/test_gpu_more.py allows 8).  It exists to price the exact
+ * division sequences (+6 %), is never what bench.py reports, and is not a route to any parity or
+ * roofline claim. */
 typedef enum meao_numerics { MEAO_NUMERICS_STRICT = 0, MEAO_NUMERICS_FAST = 1 } meao_numerics;
 
 typedef enum meao_mem { MEAO_MEM_HOST = 0, MEAO_MEM_DEVICE = 1 } meao_mem;
@@ -240,6 +245,8 @@ MEAO_API const char *meao_last_error(const meao_ctx *ctx);
  *        pass uses 4-texel vector loads, and when every ao_out pointer is aligned to 4 texels (4 bytes
  *        R8, 8 bytes F16) the last pass uses 4-texel stores; otherwise the scalar variants run
  *        (same results, slower).  hipMalloc / torch allocations are always aligned.
+ * Failure: meao_resize and the first meao_prefetch_batch allocate; when that fails the context is left
+ *        exactly as it was (geometry, buffers, captured graphs, a ready prefetch).
  * Any depth value is accepted: NaN, +-inf, negative, > 1 or denormal raw depths are processed with
  *        IEEE division exactly like the reference's Linearize (Downsample1.compute:37-48) -- a frame
  *        containing such texels takes slower kernel bodies, results stay bit-exact vs the oracle.
@@ -264,6 +271,7 @@ MEAO_API int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const 
  * re-allocates the context's intermediates with a second set of downsample buffers (one device
  * synchronisation; on allocation failure the context is left unchanged and usable). */
 MEAO_API int32_t meao_prefetch_batch(meao_ctx *ctx, int32_t n, const void *const *depth);
+/* Waits for `stream`; NULL = the stream of the last meao_execute* of this context. */
 MEAO_API int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream);
 
 /* ---- observability (replaces the _debug 1..17 views, AO.cs:787-820) --------------------- */
@@ -308,8 +316,11 @@ MEAO_API int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, voi
  * this context carries it inside its render kernel (every render workgroup first streams its share of
  * the texel pairs), on that call's stream, i.e. ordered behind the kernels that wrote ao[f] when the
  * same stream is used.  Results are identical to meao_composite.  One batch can wait at a time: a
- * second enqueue, meao_resize, meao_destroy and meao_composite_flush run the waiting batch as plain
- * composite launches (stream NULL = the stream of the last call), so nothing is ever dropped.
+ * second enqueue, meao_resize and meao_composite_flush run the waiting batch as plain composite
+ * launches, on the stream of the execute that preceded its enqueue -- i.e. the one that produced
+ * ao[f] -- or on the stream given to meao_composite_flush.  meao_destroy DISCARDS a batch that still
+ * waits (its targets are caller memory that is usually gone by then): call meao_composite_flush
+ * before destroying a context if the last enqueued composite matters.
  * ao[f], color[f] and gbuffer0[f] must stay valid and untouched until the carrying call has run. */
 MEAO_API int32_t meao_composite_enqueue(meao_ctx *ctx, int32_t mode, int32_t n, const void *const *ao,
                                         void *const *color_rgba16f, void *const *gbuffer0_rgba8);
@@ -342,17 +353,55 @@ MEAO_API int32_t meao_pool_device_of_frame(const meao_pool *pool, int32_t frame)
 MEAO_API const char *meao_pool_last_error(const meao_pool *pool);
 /* meao_set_params on every member. */
 MEAO_API int32_t meao_pool_set_params(meao_pool *pool, const meao_params *p);
+/* Every meao_pool_* call leaves the calling thread's current HIP device as it found it.  If a member
+ * fails in the middle of a call the members before it have already been given their work (their
+ * launches are in flight and complete normally); the call returns the failing member's status and
+ * meao_pool_last_error names it. */
 /* n <= max_batch * members frames; frame f runs on member f mod G, each member's share as one batched
  * launch sequence on its own stream.  DEVICE pointers of frame f must be resident on
  * meao_pool_device_of_frame(f); the call is then asynchronous (meao_pool_synchronize).  HOST pointers
  * are staged per member and the call returns after completion. */
 MEAO_API int32_t meao_pool_execute_batch(meao_pool *pool, int32_t n, const void *const *depth, int32_t depth_loc,
                                          void *const *ao_out, int32_t out_loc);
+/* meao_prefetch_batch for the pool: announces the n DEVICE depth frames of the call after next, dealt to
+ * the members exactly like meao_pool_execute_batch deals them (frame f -> member f mod G), so that each
+ * member's next execute carries its share of the next batch's downsample pass.  Create the pool with
+ * cfg.pipelined = 1 to keep this call free of allocation. */
+MEAO_API int32_t meao_pool_prefetch_batch(meao_pool *pool, int32_t n, const void *const *depth);
+/* meao_composite_enqueue / meao_composite_flush for the pool, frames dealt f -> member f mod G: the composite
+ * of frame f rides inside the next execute of the member that owns (and produced) it. */
+MEAO_API int32_t meao_pool_composite_enqueue(meao_pool *pool, int32_t mode, int32_t n, const void *const *ao,
+                                             void *const *color_rgba16f, void *const *gbuffer0_rgba8);
+MEAO_API int32_t meao_pool_composite_flush(meao_pool *pool);
 /* Copies the n DEVICE results ao_src[f] (on their owning devices) to dst[f] on dst_device with
  * hipMemcpyPeerAsync (xGMI), each on its producer's stream, i.e. ordered behind the kernels that wrote it. */
 MEAO_API int32_t meao_pool_gather_to_device(meao_pool *pool, int32_t n, const void *const *ao_src,
                                             void *const *dst, int32_t dst_device);
+/* How a copy from `member`'s device to dst_device travels.  meao_pool_create asks hipDeviceCanAccessPeer for
+ * every ordered pair of distinct member devices and enables peer access both ways where it is offered;
+ * PEER_DIRECT = enabled (device-to-device over xGMI), STAGED = not offered or not enabled (the runtime
+ * bounces the copy through host memory), SAME_DEVICE = no link involved.  Negative = invalid argument. */
+typedef enum meao_pool_path { MEAO_POOL_PATH_SAME_DEVICE = 0, MEAO_POOL_PATH_PEER_DIRECT = 1, MEAO_POOL_PATH_STAGED = 2 } meao_pool_path;
+MEAO_API int32_t meao_pool_gather_path(const meao_pool *pool, int32_t member, int32_t dst_device);
 MEAO_API int32_t meao_pool_synchronize(meao_pool *pool);
+
+/* Which frames of the last meao_execute* held "hostile" depth texels (NaN, inf, negative, > 1, denormal --
+ * anything outside the operand range the exact v_rcp_f32 division sequences are verified for) and therefore
+ * ran the slower IEEE-division kernel bodies: bit f of *out_mask = frame f.  Results are bit-exact either
+ * way; this is a performance diagnostic.  Synchronises the stream of that call. */
+MEAO_API int32_t meao_hostile_frames(meao_ctx *ctx, uint64_t *out_mask);
+
+/* Launch-structure overrides and fault injection, for tests and A/B runs (the library reads no
+ * environment variables).  Every structure gives bit-identical results; the defaults are what measured
+ * fastest.  FUSE_COARSE_BLEND 0 = three separate blend launches; *_MAX_TILES = tile-count thresholds at or
+ * below which a call uses the nested three-level blend launch / 128x8 render tiles / 64x32 final tiles /
+ * 128x8 downsample tiles (0 = never); FAIL_NEXT_ALLOCS n = the next n allocations of intermediates
+ * (meao_resize, first meao_prefetch_batch) fail with MEAO_ERR_OUT_OF_MEMORY. */
+typedef enum meao_debug_key {
+    MEAO_DEBUG_FUSE_COARSE_BLEND = 0, MEAO_DEBUG_NESTED_MAX_TILES = 1, MEAO_DEBUG_RENDER_SMALL_MAX_TILES = 2,
+    MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4, MEAO_DEBUG_FAIL_NEXT_ALLOCS = 5
+} meao_debug_key;
+MEAO_API int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value);
 
 /* roctx ranges ("meao:downsample", "meao:render", "meao:upsample_L1_to_L0", ...) around the launches
  * of every pass, so that rocprofv3 --marker-trace output is self-describing even where passes are

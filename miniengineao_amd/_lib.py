@@ -22,7 +22,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # MEAO_LIB_PATH: an alternative build of the same library (A/B of kernel variants, tests/run_gpu_variants_ab.sh)
 LIB_PATH = os.environ.get("MEAO_LIB_PATH") or os.path.join(_PKG, "lib", "libmeao_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_BATCH = 64
 NUM_PASSES = 7
 PASS_NAMES = ("downsample", "render", "upsample_L4_to_L3", "upsample_L3_to_L2",
@@ -42,6 +42,10 @@ FMT_F32, FMT_F16, FMT_UNORM8 = 0, 1, 2
 SAMPLES_CHECKER, SAMPLES_EXHAUSTIVE = 0, 1
 LAUNCH_DIRECT, LAUNCH_GRAPH = 0, 1
 DEBUG_OCCLUSION_HQ1 = 18
+# meao_debug_key
+(DEBUG_FUSE_COARSE_BLEND, DEBUG_NESTED_MAX_TILES, DEBUG_RENDER_SMALL_MAX_TILES, DEBUG_FINAL_SMALL_MAX_TILES,
+ DEBUG_DS_SMALL_MAX_TILES, DEBUG_FAIL_NEXT_ALLOCS) = range(6)
+POOL_PATH_SAME_DEVICE, POOL_PATH_PEER_DIRECT, POOL_PATH_STAGED = 0, 1, 2
 NUM_BUFFERS = 21
 
 
@@ -124,6 +128,13 @@ SIGNATURES = {
                                             C.POINTER(C.c_void_p), C.c_int32]),
     "meao_pool_gather_to_device": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32]),
     "meao_pool_synchronize": (C.c_int32, [C.c_void_p]),
+    "meao_pool_prefetch_batch": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "meao_pool_composite_enqueue": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_void_p)]),
+    "meao_pool_composite_flush": (C.c_int32, [C.c_void_p]),
+    "meao_pool_gather_path": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "meao_hostile_frames": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "meao_debug_set": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     "meao_debug_view": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "meao_composite": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }

@@ -215,6 +215,16 @@ class AmbientOcclusion:
     def set_profiling(self, enable: bool) -> None:
         L.check(self._lib.meao_set_profiling(self._ctx, 1 if enable else 0), self._ctx)
 
+    def hostile_frames(self) -> int:
+        """Bit mask of the frames of the last execute that ran the IEEE-division bodies (meao_hostile_frames)."""
+        m = C.c_uint64()
+        L.check(self._lib.meao_hostile_frames(self._ctx, C.byref(m)), self._ctx)
+        return m.value
+
+    def debug_set(self, key: int, value: int) -> None:
+        """meao_debug_set: launch-structure overrides (identical results) and allocation fault injection."""
+        L.check(self._lib.meao_debug_set(self._ctx, key, value), self._ctx)
+
     def set_tracing(self, enable: bool) -> None:
         """roctx ranges around every pass (rocprofv3 --marker-trace)."""
         L.check(self._lib.meao_set_tracing(self._ctx, 1 if enable else 0), self._ctx)
@@ -279,7 +289,11 @@ class AmbientOcclusionPool:
         prm.near_clip, prm.far_clip, prm.reversed_z, prm.intensity = near_clip, far_clip, 1 if reversed_z else 0, intensity
         if projection00 is not None:
             prm.proj00 = projection00
-        self._check(self._lib.meao_pool_set_params(self._pool, C.byref(prm)))
+        try:
+            self._check(self._lib.meao_pool_set_params(self._pool, C.byref(prm)))
+        except Exception:
+            self.close()        # the pool exists already: do not leak its contexts
+            raise
 
     def _check(self, status: int) -> None:
         if status != L.OK:
@@ -306,6 +320,29 @@ class AmbientOcclusionPool:
         n = len(depth_ptrs)
         pin, pout = (C.c_void_p * n)(*depth_ptrs), (C.c_void_p * n)(*out_ptrs)
         self._check(self._lib.meao_pool_execute_batch(self._pool, n, pin, L.MEM_DEVICE, pout, L.MEM_DEVICE))
+
+    def prefetch_device(self, depth_ptrs: Sequence[int]) -> None:
+        """meao_pool_prefetch_batch: the frames of the call after next, dealt like execute_device deals them."""
+        n = len(depth_ptrs)
+        self._check(self._lib.meao_pool_prefetch_batch(self._pool, n, (C.c_void_p * n)(*depth_ptrs)))
+
+    def composite_enqueue_device(self, mode: int, ao_ptrs: Sequence[int], color_ptrs: Sequence[int],
+                                 gbuffer0_ptrs: Optional[Sequence[int]] = None) -> None:
+        n = len(ao_ptrs)
+        g = (C.c_void_p * n)(*gbuffer0_ptrs) if gbuffer0_ptrs else None
+        self._check(self._lib.meao_pool_composite_enqueue(self._pool, mode, n, (C.c_void_p * n)(*ao_ptrs),
+                                                          (C.c_void_p * n)(*color_ptrs), g))
+
+    def composite_flush(self) -> None:
+        self._check(self._lib.meao_pool_composite_flush(self._pool))
+
+    def gather_path(self, member: int, dst_device: int) -> int:
+        """L.POOL_PATH_*: how gather_to_device copies from `member`'s device to dst_device."""
+        return self._lib.meao_pool_gather_path(self._pool, member, dst_device)
+
+    def member_context(self, member: int):
+        """Raw meao_ctx* of a member (owned by the pool), e.g. for meao_set_profiling / meao_get_pass_times."""
+        return C.c_void_p(self._lib.meao_pool_context(self._pool, member))
 
     def gather_to_device(self, src_ptrs: Sequence[int], dst_ptrs: Sequence[int], dst_device: int) -> None:
         n = len(src_ptrs)

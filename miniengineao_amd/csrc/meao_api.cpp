@@ -67,16 +67,21 @@ struct meao_ctx {
     // (meao_kernels.hip "Exact division"); recomputed by update_plan()
     int exact_rcp_div = 0;
 
-    // Upsample L4->L3 evaluated inside the L3->L2 launch (upsample_two_level_kernel); on unless the
-    // A/B switch MEAO_DEBUG_NO_FUSED_BLEND=1 was set when the context was created
+    // Upsample L4->L3 evaluated inside the L3->L2 launch (upsample_two_level_kernel).  This and the four
+    // thresholds below choose between launch structures with identical results; meao_debug_set overrides
+    // them (tests, A/B runs) -- the library reads no environment variables.
     bool fuse_coarse_blend = true;
     int ds_small_max_tiles = 1024;     // stand-alone downsample pass: calls with at most this many 128x32 tiles use 128x8 tiles
     int final_small_max_tiles = 512;   // plain final pass: calls with at most this many 64x64 tiles use 64x32 tiles
     int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
     int nested_max_tiles = 512;        // calls with at most this many L2->L1 tiles (frames x tiles) run the three blend passes as one launch
 
-    // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue)
+    // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue),
+    // and the stream its AO frames were produced on (where a flush that is not given a stream runs it)
     CompositeBatchArgs pending_comp{};
+    hipStream_t pending_stream = nullptr;
+
+    int debug_fail_allocs = 0;         // meao_debug_set(MEAO_DEBUG_FAIL_NEXT_ALLOCS): arena allocations still to fail (tests)
 
     const void *last_out[MEAO_MAX_BATCH] = {};   // device address of the last results (debug id 17)
     int last_frames = 0;
@@ -150,21 +155,37 @@ bool config_valid(const meao_config &c, std::string *why)
 
 uint64_t ao_elem(const meao_config &c) { return c.ao_format == MEAO_AO_R8 ? 1 : 2; }
 
-void layout_slot(meao_ctx *ctx)
+// Where the intermediates of one frame live inside its slot; a pure function of (plan, cfg, two_ds_sets).
+struct SlotLayout {
+    uint64_t off_ds_linear = 0, off_ds_low[4] = {}, ds_set_bytes = 0, off_occ[4] = {}, off_comb[3] = {}, off_hq[4] = {}, slot_bytes = 0;
+};
+
+SlotLayout layout_slot(const Plan &p, const meao_config &cfg, bool two_ds_sets)
 {
-    const Plan &p = ctx->plan;
+    SlotLayout l;
     uint64_t off = 0;
     auto take = [&](uint64_t bytes) { const uint64_t o = off; off = align_up(off + bytes); return o; };
     auto px = [&](int k) { return static_cast<uint64_t>(p.mip[k].w) * p.mip[k].h; };
-    ctx->off_ds_linear = take(px(0) * 2);
-    for (int k = 1; k <= 4; ++k) ctx->off_ds_low[k - 1] = take(px(k) * 4);
-    ctx->ds_set_bytes = off;
-    if (ctx->two_ds_sets) off = 2 * off;          // second set: same layout, ds_set_bytes further
-    for (int k = 1; k <= 4; ++k) ctx->off_occ[k - 1] = take(px(k) * ao_elem(ctx->cfg));
-    for (int k = 1; k <= 3; ++k) ctx->off_comb[k - 1] = take(px(k) * ao_elem(ctx->cfg));
-    for (int k = 1; k <= 4; ++k)
-        ctx->off_hq[k - 1] = level_has_hq(ctx->cfg.num_levels, ctx->cfg.hq_levels, k) ? take(px(k) * ao_elem(ctx->cfg)) : 0;
-    ctx->slot_bytes = off;
+    l.off_ds_linear = take(px(0) * 2);
+    for (int k = 1; k <= 4; ++k) l.off_ds_low[k - 1] = take(px(k) * 4);
+    l.ds_set_bytes = off;
+    if (two_ds_sets) off = 2 * off;          // second set: same layout, ds_set_bytes further
+    for (int k = 1; k <= 4; ++k) l.off_occ[k - 1] = take(px(k) * ao_elem(cfg));
+    for (int k = 1; k <= 3; ++k) l.off_comb[k - 1] = take(px(k) * ao_elem(cfg));
+    for (int k = 1; k <= 4; ++k) l.off_hq[k - 1] = level_has_hq(cfg.num_levels, cfg.hq_levels, k) ? take(px(k) * ao_elem(cfg)) : 0;
+    l.slot_bytes = off;
+    return l;
+}
+
+void apply_layout(meao_ctx *ctx, const SlotLayout &l)
+{
+    ctx->off_ds_linear = l.off_ds_linear;
+    ctx->ds_set_bytes = l.ds_set_bytes;
+    ctx->slot_bytes = l.slot_bytes;
+    std::memcpy(ctx->off_ds_low, l.off_ds_low, sizeof l.off_ds_low);
+    std::memcpy(ctx->off_occ, l.off_occ, sizeof l.off_occ);
+    std::memcpy(ctx->off_comb, l.off_comb, sizeof l.off_comb);
+    std::memcpy(ctx->off_hq, l.off_hq, sizeof l.off_hq);
 }
 
 // Divides on the path: 1/LoResDB, 1/centre depth, {9,3,1,3}/(|dHi-dLo| + tol), (HiAO*sum)/total.
@@ -224,29 +245,27 @@ void release_buffers(meao_ctx *ctx)
     ctx->last_frames = 0;
 }
 
-// (Re)plans for cfg/two_ds_sets and replaces the arena.  The new arena is allocated BEFORE the old one
-// is released: on failure the context keeps its previous geometry and buffers and stays usable.
+// (Re)plans for cfg/two_ds_sets and replaces the arena.  The new geometry is planned on the side and its
+// arena allocated BEFORE anything of the context changes: on failure the context is untouched -- geometry,
+// buffers, captured graphs and a ready prefetch all stay as they were.
 int reallocate(meao_ctx *ctx, const meao_config &cfg, bool two_ds_sets)
 {
-    const meao_config old_cfg = ctx->cfg;
-    const bool old_two = ctx->two_ds_sets;
+    Plan plan{};
+    build_plan(cfg.width, cfg.height, cfg.num_levels, cfg.sample_set, ctx->prm, &plan);
+    const SlotLayout lay = layout_slot(plan, cfg, two_ds_sets);
+    char *fresh = nullptr;
+    hipError_t e;
+    if (ctx->debug_fail_allocs > 0) {      // fault injection (meao_debug_set, tests only)
+        --ctx->debug_fail_allocs;
+        e = hipErrorOutOfMemory;
+    } else {
+        e = hipMalloc(reinterpret_cast<void **>(&fresh), lay.slot_bytes * cfg.max_batch);
+    }
+    if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc (intermediates)");
     ctx->cfg = cfg;
     ctx->two_ds_sets = two_ds_sets;
-    update_plan(ctx);
-    layout_slot(ctx);
-    char *fresh = nullptr;
-    // fault injection for tests (tests/test_gpu_more.py): MEAO_DEBUG_FAIL_ALLOC=1 makes this allocation fail
-    const char *inject = std::getenv("MEAO_DEBUG_FAIL_ALLOC");
-    const hipError_t e = (inject && inject[0] == '1')
-                             ? hipErrorOutOfMemory
-                             : hipMalloc(reinterpret_cast<void **>(&fresh), ctx->slot_bytes * ctx->cfg.max_batch);
-    if (e != hipSuccess) {
-        ctx->cfg = old_cfg;
-        ctx->two_ds_sets = old_two;
-        update_plan(ctx);
-        layout_slot(ctx);
-        return fail_hip(ctx, e, "hipMalloc (intermediates)");
-    }
+    update_plan(ctx);           // drops captured graphs and a ready prefetch: they refer to the old arena
+    apply_layout(ctx, lay);
     release_buffers(ctx);
     ctx->arena = fresh;
     return MEAO_OK;
@@ -303,7 +322,7 @@ struct TraceRange {   // roctx range around one pass (no-op unless meao_set_trac
 bool aligned_to(const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // The launch sequence of one batch: what RebuildCommandBuffers records (AO.cs:511-531).
-int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream)
+int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream, bool capturing = false)
 {
     const Plan &p = ctx->plan;
     const meao_config &c = ctx->cfg;
@@ -369,6 +388,11 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     if (!prefetched) {
         TraceRange tr(ctx, "meao:downsample");
         ctx->set_gen[ctx->ds_cur] = next_generation();
+        // A captured sequence bakes its generation into the kernel arguments, so every replay stamps and tests
+        // the same value: the flag words are cleared in front of the downsample launch (a memset node), or one
+        // hostile frame would keep every later replay on the IEEE-division bodies.  Direct launches take a
+        // fresh generation per downsample and need no clearing.
+        if (capturing) MEAO_HIP(ctx, hipMemsetAsync(ctx->hostile_of(ctx->ds_cur), 0, sizeof(uint32_t) * n, stream));
         MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, stream));
         MEAO_HIP(ctx, launch_downsample(downsample_args(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur], true), n, stream));
         MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, stream));
@@ -581,7 +605,7 @@ int submit_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const
         return MEAO_OK;
     }
     MEAO_HIP(ctx, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    const int rc = run_batch(ctx, n, depth_dev, out_dev, stream);
+    const int rc = run_batch(ctx, n, depth_dev, out_dev, stream, true);
     hipGraph_t graph = nullptr;
     const hipError_t end = hipStreamEndCapture(stream, &graph);
     if (rc != MEAO_OK || end != hipSuccess) {
@@ -747,12 +771,6 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
     meao_ctx *ctx = new (std::nothrow) meao_ctx();
     if (!ctx) return fail(nullptr, MEAO_ERR_OUT_OF_MEMORY, "meao_create: host allocation failed");
     ctx->cfg = *cfg;
-    const char *no_fuse = std::getenv("MEAO_DEBUG_NO_FUSED_BLEND");
-    ctx->fuse_coarse_blend = !(no_fuse && no_fuse[0] == '1');
-    if (const char *m = std::getenv("MEAO_DEBUG_NESTED_MAX_TILES")) ctx->nested_max_tiles = std::atoi(m);   // A/B switch
-    if (const char *m = std::getenv("MEAO_DEBUG_RENDER_SMALL_MAX_TILES")) ctx->render_small_max_tiles = std::atoi(m);
-    if (const char *m = std::getenv("MEAO_DEBUG_FINAL_SMALL_MAX_TILES")) ctx->final_small_max_tiles = std::atoi(m);
-    if (const char *m = std::getenv("MEAO_DEBUG_DS_SMALL_MAX_TILES")) ctx->ds_small_max_tiles = std::atoi(m);
     meao_default_params(&ctx->prm);
     int rc = use_device(ctx);
     if (rc == MEAO_OK) {
@@ -781,8 +799,12 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
 int32_t meao_destroy(meao_ctx *ctx)
 {
     if (!ctx) return MEAO_OK;
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
     (void)hipSetDevice(ctx->cfg.device);
-    if (ctx->pending_comp.frames > 0) (void)flush_pending_composite(ctx, ctx->last_stream);   // never dropped
+    // A composite batch still waiting is DISCARDED (meao.h): its targets are caller memory whose lifetime has
+    // typically ended by now (free the frames, then destroy); hosts that want it call meao_composite_flush first.
+    ctx->pending_comp.frames = 0;
     (void)hipDeviceSynchronize();
     drop_graphs(ctx);
     release_buffers(ctx);
@@ -792,6 +814,7 @@ int32_t meao_destroy(meao_ctx *ctx)
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+    if (prev_device >= 0) (void)hipSetDevice(prev_device);
     return MEAO_OK;
 }
 
@@ -805,8 +828,8 @@ int32_t meao_resize(meao_ctx *ctx, int32_t width, int32_t height)
     if (!config_valid(c, &why)) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_resize: " + why);
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
-    if (ctx->pending_comp.frames > 0) {        // sized for the old geometry: run it now
-        rc = flush_pending_composite(ctx, ctx->last_stream);
+    if (ctx->pending_comp.frames > 0) {        // sized for the old geometry: run it now, where its AO frames were produced
+        rc = flush_pending_composite(ctx, ctx->pending_stream);
         if (rc != MEAO_OK) return rc;
     }
     MEAO_HIP(ctx, hipDeviceSynchronize());
@@ -840,8 +863,12 @@ int32_t meao_get_config(const meao_ctx *ctx, meao_config *out)
 
 const char *meao_last_error(const meao_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
-int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth, int32_t depth_loc,
-                           void *const *ao_out, int32_t out_loc, meao_stream stream_)
+}  // extern "C"
+
+// meao_execute_batch; wait_for_host = false (pool members only) leaves the staged copies of a HOST call in
+// flight on `stream_` -- the caller synchronises the stream before it touches the host buffers.
+int meao::execute_batch_internal(meao_ctx *ctx, int32_t n, const void *const *depth, int32_t depth_loc, void *const *ao_out,
+                                 int32_t out_loc, meao_stream stream_, bool wait_for_host)
 {
     if (!ctx || !depth || !ao_out) return MEAO_ERR_INVALID_ARGUMENT;
     if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_execute_batch: n must be 1..max_batch");
@@ -887,8 +914,16 @@ int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth, i
     if (out_loc == MEAO_MEM_HOST)
         for (int f = 0; f < n; ++f)
             MEAO_HIP(ctx, hipMemcpyAsync(ao_out[f], out_dev[f], out_bytes, hipMemcpyDeviceToHost, stream));
-    if (out_loc == MEAO_MEM_HOST || depth_loc == MEAO_MEM_HOST) MEAO_HIP(ctx, hipStreamSynchronize(stream));
+    if (wait_for_host && (out_loc == MEAO_MEM_HOST || depth_loc == MEAO_MEM_HOST)) MEAO_HIP(ctx, hipStreamSynchronize(stream));
     return MEAO_OK;
+}
+
+extern "C" {
+
+int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const *depth, int32_t depth_loc,
+                           void *const *ao_out, int32_t out_loc, meao_stream stream_)
+{
+    return meao::execute_batch_internal(ctx, n, depth, depth_loc, ao_out, out_loc, stream_, true);
 }
 
 int32_t meao_prefetch_batch(meao_ctx *ctx, int32_t n, const void *const *depth)
@@ -1130,7 +1165,6 @@ int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, void *color_
     }
     ca.ao = ao; ca.color = color_rgba16f; ca.gbuffer0 = gbuffer0_rgba8;
     MEAO_HIP(ctx, launch_composite(ca, ctx->cfg.ao_format, stream));
-    ctx->last_stream = stream;
     return MEAO_OK;
 }
 
@@ -1148,9 +1182,10 @@ int32_t meao_composite_enqueue(meao_ctx *ctx, int32_t mode, int32_t n, const voi
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     if (ctx->pending_comp.frames > 0) {        // one batch can wait at a time: the older one runs now, in order
-        rc = flush_pending_composite(ctx, ctx->last_stream);
+        rc = flush_pending_composite(ctx, ctx->pending_stream);
         if (rc != MEAO_OK) return rc;
     }
+    ctx->pending_stream = ctx->last_stream;    // the stream of the execute that (by contract) produced ao[f]
     CompositeBatchArgs &pc = ctx->pending_comp;
     for (int f = 0; f < n; ++f) {
         pc.ao[f] = ao[f];
@@ -1169,10 +1204,43 @@ int32_t meao_composite_flush(meao_ctx *ctx, meao_stream stream_)
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     if (ctx->pending_comp.frames == 0) return MEAO_OK;
-    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->last_stream;
-    rc = flush_pending_composite(ctx, stream);
-    if (rc == MEAO_OK) ctx->last_stream = stream;
-    return rc;
+    return flush_pending_composite(ctx, stream_ ? static_cast<hipStream_t>(stream_) : ctx->pending_stream);
+}
+
+int32_t meao_hostile_frames(meao_ctx *ctx, uint64_t *out_mask)
+{
+    if (!ctx || !out_mask) return MEAO_ERR_INVALID_ARGUMENT;
+    *out_mask = 0;
+    if (ctx->last_frames == 0) return MEAO_OK;
+    int rc = use_device(ctx);
+    if (rc != MEAO_OK) return rc;
+    uint32_t words[MEAO_MAX_BATCH];
+    MEAO_HIP(ctx, hipMemcpyAsync(words, ctx->hostile_of(ctx->ds_cur), sizeof(uint32_t) * ctx->last_frames, hipMemcpyDeviceToHost,
+                                 ctx->last_stream));
+    MEAO_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    for (int f = 0; f < ctx->last_frames; ++f)
+        if (words[f] == ctx->set_gen[ctx->ds_cur]) *out_mask |= uint64_t(1) << f;
+    return MEAO_OK;
+}
+
+int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    switch (key) {
+    case MEAO_DEBUG_FUSE_COARSE_BLEND: ctx->fuse_coarse_blend = value != 0; break;
+    case MEAO_DEBUG_NESTED_MAX_TILES: ctx->nested_max_tiles = value; break;
+    case MEAO_DEBUG_RENDER_SMALL_MAX_TILES: ctx->render_small_max_tiles = value; break;
+    case MEAO_DEBUG_FINAL_SMALL_MAX_TILES: ctx->final_small_max_tiles = value; break;
+    case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
+    case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
+    default: return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: unknown key");
+    }
+    if (!ctx->graphs.empty()) {      // captured sequences embed the launch structure
+        const int rc = use_device(ctx);
+        if (rc != MEAO_OK) return rc;
+        drop_graphs(ctx);
+    }
+    return MEAO_OK;
 }
 
 int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches)

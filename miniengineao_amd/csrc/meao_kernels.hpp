@@ -164,4 +164,8 @@ hipError_t launch_render_with_composite(const RenderArgs &a, const CompositeBatc
 // Exhaustive conversion self-tests; *count (device) receives the number of mismatches.
 hipError_t launch_selftest(int which, unsigned long long *count, hipStream_t s);
 
+// meao_api.cpp, for meao_pool.cpp: meao_execute_batch that can leave the staged copies of a HOST call in flight
+int execute_batch_internal(meao_ctx *ctx, int32_t n, const void *const *depth, int32_t depth_loc, void *const *ao_out,
+                           int32_t out_loc, meao_stream stream, bool wait_for_host);
+
 }  // namespace meao

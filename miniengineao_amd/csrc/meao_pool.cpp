@@ -5,8 +5,11 @@
 // complete context (all intermediates) and a stream on its device, and there is no data-path
 // exchange.  One host thread drives all members -- the launches are asynchronous -- so a C# host can
 // bind these entry points directly ([DllImport]) instead of running one process per GPU.
+// The pipelined forms of the single-context API exist here too (meao_pool_prefetch_batch,
+// meao_pool_composite_enqueue): the in-process host gets the same step the per-GPU processes of bench.py run.
 // Results stay on the owning device (or go to host memory); meao_pool_gather_to_device copies them to
-// one device over xGMI (hipMemcpyPeerAsync) when a single consumer wants the whole batch.
+// one device (hipMemcpyPeerAsync; device-to-device over xGMI where peer access could be enabled at
+// creation, meao_pool_gather_path says which) when a single consumer wants the whole batch.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -14,12 +17,14 @@
 #include <string>
 #include <vector>
 
-#include "../../include/meao.h"
+#include "meao_kernels.hpp"
 
 struct meao_pool {
     std::vector<meao_ctx *> ctx;
     std::vector<int32_t> device;
     std::vector<hipStream_t> stream;
+    std::vector<int32_t> peer_ok;      // [member * device_count + dst_device]: peer access from the member's device enabled
+    int32_t device_count = 0;
     int32_t max_batch = 1;
     uint64_t out_bytes = 0;
     std::string err;
@@ -36,6 +41,23 @@ int pool_fail(meao_pool *p, int status, const std::string &msg)
     return status;
 }
 
+// Pool entry points switch devices; the calling thread's current device is put back on every exit path
+// (an in-process host -- torch, the C# component -- has its own idea of the current device).
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// frames of member m in a batch of n dealt round-robin over G members
+template <typename T>
+int32_t share_of(int32_t m, int32_t G, int32_t n, T *const *all, T **mine)
+{
+    int32_t k = 0;
+    for (int32_t f = m; f < n; f += G) mine[k++] = all[f];
+    return k;
+}
+
 }  // namespace
 
 extern "C" {
@@ -50,9 +72,11 @@ int32_t meao_pool_create(const meao_config *cfg, const int32_t *devices, int32_t
         (void)hipGetLastError();
         return pool_fail(nullptr, MEAO_ERR_NO_DEVICE, "meao_pool_create: no HIP device visible (no CPU fallback exists)");
     }
+    DeviceGuard guard;
     meao_pool *p = new (std::nothrow) meao_pool();
     if (!p) return pool_fail(nullptr, MEAO_ERR_OUT_OF_MEMORY, "meao_pool_create: host allocation failed");
     p->max_batch = cfg->max_batch;
+    p->device_count = count;
     p->out_bytes = static_cast<uint64_t>(cfg->width) * cfg->height * (cfg->ao_format == MEAO_AO_R8 ? 1 : 2);
     for (int32_t i = 0; i < num_devices; ++i) {
         // devices == NULL: members 0..n-1 on devices 0..n-1 (wrapping, so a 1-GPU box can host several members)
@@ -61,21 +85,45 @@ int32_t meao_pool_create(const meao_config *cfg, const int32_t *devices, int32_t
         c.device = dev;
         meao_ctx *ctx = nullptr;
         int32_t rc = meao_create(&c, &ctx);
+        std::string why = rc == MEAO_OK ? std::string() : std::string(meao_last_error(nullptr));
         hipStream_t s = nullptr;
-        if (rc == MEAO_OK && (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)) {
-            (void)hipGetLastError();
-            rc = MEAO_ERR_HIP;
+        if (rc == MEAO_OK) {
+            hipError_t e = hipSetDevice(dev);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                rc = MEAO_ERR_HIP;
+                why = std::string("stream creation: ") + hipGetErrorString(e);
+            }
         }
         if (rc != MEAO_OK) {
-            const std::string why = std::string("meao_pool_create: member ") + std::to_string(i) + " on device " +
-                                    std::to_string(dev) + ": " + meao_last_error(ctx);
             if (ctx) meao_destroy(ctx);
             meao_pool_destroy(p);
-            return pool_fail(nullptr, rc, why);
+            return pool_fail(nullptr, rc, std::string("meao_pool_create: member ") + std::to_string(i) + " on device " +
+                                              std::to_string(dev) + ": " + why);
         }
         p->ctx.push_back(ctx);
         p->device.push_back(dev);
         p->stream.push_back(s);
+    }
+    // Peer access, both ways, between every pair of distinct member devices: without it hipMemcpyPeerAsync
+    // still works but bounces through host memory.  "Already enabled" (another pool, the host itself) is fine.
+    p->peer_ok.assign(p->ctx.size() * static_cast<size_t>(count), 0);
+    for (size_t m = 0; m < p->ctx.size(); ++m) {
+        const int32_t from = p->device[m];
+        for (int32_t to = 0; to < count; ++to) {
+            if (to == from) continue;
+            bool member_device = false;
+            for (int32_t d : p->device) member_device = member_device || d == to;
+            if (!member_device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+            if (!can) continue;
+            if (hipSetDevice(from) != hipSuccess) { (void)hipGetLastError(); continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) p->peer_ok[m * count + to] = 1;
+            (void)hipGetLastError();
+        }
     }
     *out_pool = p;
     return MEAO_OK;
@@ -84,13 +132,15 @@ int32_t meao_pool_create(const meao_config *cfg, const int32_t *devices, int32_t
 int32_t meao_pool_destroy(meao_pool *p)
 {
     if (!p) return MEAO_OK;
+    DeviceGuard guard;
     for (size_t i = 0; i < p->ctx.size(); ++i) {
         (void)hipSetDevice(p->device[i]);
-        if (p->stream[i]) {
-            (void)hipStreamSynchronize(p->stream[i]);
-            (void)hipStreamDestroy(p->stream[i]);
-        }
+        // The member's context has this stream as the stream of its last call (graph replays in flight,
+        // meao_destroy synchronises them): the context goes first, its stream after it.
+        if (p->stream[i]) (void)hipStreamSynchronize(p->stream[i]);
         meao_destroy(p->ctx[i]);
+        (void)hipSetDevice(p->device[i]);
+        if (p->stream[i]) (void)hipStreamDestroy(p->stream[i]);
     }
     delete p;
     return MEAO_OK;
@@ -114,6 +164,7 @@ const char *meao_pool_last_error(const meao_pool *p) { return p ? p->err.c_str()
 int32_t meao_pool_set_params(meao_pool *p, const meao_params *prm)
 {
     if (!p || !prm) return MEAO_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard;
     for (size_t i = 0; i < p->ctx.size(); ++i) {
         const int32_t rc = meao_set_params(p->ctx[i], prm);
         if (rc != MEAO_OK) return pool_fail(p, rc, std::string("meao_pool_set_params: ") + meao_last_error(p->ctx[i]));
@@ -128,35 +179,112 @@ int32_t meao_pool_execute_batch(meao_pool *p, int32_t n, const void *const *dept
     const int32_t G = static_cast<int32_t>(p->ctx.size());
     if (n < 1 || n > p->max_batch * G)
         return pool_fail(p, MEAO_ERR_INVALID_ARGUMENT, "meao_pool_execute_batch: n must be 1..max_batch * members");
+    DeviceGuard guard;
     // frame f -> member f mod G; each member runs its share as ONE batched launch
-    // sequence on its own stream.  With HOST memory a member's call returns when its copies are done, so
-    // members are then served one after the other (device-resident frames overlap across members).
-    for (int32_t m = 0; m < G; ++m) {
+    // sequence on its own stream.  With HOST memory every member's staged copies and launches are put in
+    // flight first and all members are waited for afterwards: member m+1's upload overlaps member m's kernels.
+    const bool host = depth_loc == MEAO_MEM_HOST || out_loc == MEAO_MEM_HOST;
+    int32_t issued = 0, status = MEAO_OK;
+    for (int32_t m = 0; m < G && status == MEAO_OK; ++m) {
         const void *d[MEAO_MAX_BATCH];
         void *o[MEAO_MAX_BATCH];
-        int32_t k = 0;
-        for (int32_t f = m; f < n; f += G, ++k) {
-            d[k] = depth[f];
-            o[k] = ao_out[f];
-        }
+        const int32_t k = share_of(m, G, n, depth, d);
+        share_of(m, G, n, ao_out, o);
         if (k == 0) continue;
-        const int32_t rc = meao_execute_batch(p->ctx[m], k, d, depth_loc, o, out_loc, p->stream[m]);
+        const int32_t rc = meao::execute_batch_internal(p->ctx[m], k, d, depth_loc, o, out_loc, p->stream[m], false);
         if (rc != MEAO_OK)
-            return pool_fail(p, rc, std::string("meao_pool_execute_batch: member ") + std::to_string(m) + ": " +
+            status = pool_fail(p, rc, std::string("meao_pool_execute_batch: member ") + std::to_string(m) + ": " +
+                                          meao_last_error(p->ctx[m]));
+        else
+            issued = m + 1;
+    }
+    if (host) {     // the host buffers are the caller's again when the call returns: wait for what was issued
+        for (int32_t m = 0; m < issued; ++m)
+            if (hipSetDevice(p->device[m]) != hipSuccess || hipStreamSynchronize(p->stream[m]) != hipSuccess) {
+                (void)hipGetLastError();
+                if (status == MEAO_OK) status = pool_fail(p, MEAO_ERR_HIP, "meao_pool_execute_batch: stream synchronisation failed");
+            }
+    }
+    return status;
+}
+
+int32_t meao_pool_prefetch_batch(meao_pool *p, int32_t n, const void *const *depth)
+{
+    if (!p || !depth) return MEAO_ERR_INVALID_ARGUMENT;
+    const int32_t G = static_cast<int32_t>(p->ctx.size());
+    if (n < 1 || n > p->max_batch * G)
+        return pool_fail(p, MEAO_ERR_INVALID_ARGUMENT, "meao_pool_prefetch_batch: n must be 1..max_batch * members");
+    DeviceGuard guard;
+    for (int32_t m = 0; m < G; ++m) {
+        const void *d[MEAO_MAX_BATCH];
+        const int32_t k = share_of(m, G, n, depth, d);
+        if (k == 0) continue;
+        const int32_t rc = meao_prefetch_batch(p->ctx[m], k, d);
+        if (rc != MEAO_OK)
+            return pool_fail(p, rc, std::string("meao_pool_prefetch_batch: member ") + std::to_string(m) + ": " +
                                         meao_last_error(p->ctx[m]));
     }
     return MEAO_OK;
 }
 
+int32_t meao_pool_composite_enqueue(meao_pool *p, int32_t mode, int32_t n, const void *const *ao, void *const *color_rgba16f,
+                                    void *const *gbuffer0_rgba8)
+{
+    if (!p || !ao || !color_rgba16f) return MEAO_ERR_INVALID_ARGUMENT;
+    const int32_t G = static_cast<int32_t>(p->ctx.size());
+    if (n < 1 || n > p->max_batch * G)
+        return pool_fail(p, MEAO_ERR_INVALID_ARGUMENT, "meao_pool_composite_enqueue: n must be 1..max_batch * members");
+    DeviceGuard guard;
+    for (int32_t m = 0; m < G; ++m) {
+        const void *a[MEAO_MAX_BATCH];
+        void *c[MEAO_MAX_BATCH], *g[MEAO_MAX_BATCH];
+        const int32_t k = share_of(m, G, n, ao, a);
+        share_of(m, G, n, color_rgba16f, c);
+        if (gbuffer0_rgba8) share_of(m, G, n, gbuffer0_rgba8, g);
+        if (k == 0) continue;
+        const int32_t rc = meao_composite_enqueue(p->ctx[m], mode, k, a, c, gbuffer0_rgba8 ? g : nullptr);
+        if (rc != MEAO_OK)
+            return pool_fail(p, rc, std::string("meao_pool_composite_enqueue: member ") + std::to_string(m) + ": " +
+                                        meao_last_error(p->ctx[m]));
+    }
+    return MEAO_OK;
+}
+
+int32_t meao_pool_composite_flush(meao_pool *p)
+{
+    if (!p) return MEAO_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard;
+    for (size_t m = 0; m < p->ctx.size(); ++m) {
+        const int32_t rc = meao_composite_flush(p->ctx[m], p->stream[m]);
+        if (rc != MEAO_OK)
+            return pool_fail(p, rc, std::string("meao_pool_composite_flush: member ") + std::to_string(m) + ": " +
+                                        meao_last_error(p->ctx[m]));
+    }
+    return MEAO_OK;
+}
+
+int32_t meao_pool_gather_path(const meao_pool *p, int32_t member, int32_t dst_device)
+{
+    if (!p || member < 0 || member >= static_cast<int32_t>(p->ctx.size()) || dst_device < 0 || dst_device >= p->device_count)
+        return MEAO_ERR_INVALID_ARGUMENT;
+    if (p->device[member] == dst_device) return MEAO_POOL_PATH_SAME_DEVICE;
+    return p->peer_ok[static_cast<size_t>(member) * p->device_count + dst_device] ? MEAO_POOL_PATH_PEER_DIRECT : MEAO_POOL_PATH_STAGED;
+}
+
 int32_t meao_pool_gather_to_device(meao_pool *p, int32_t n, const void *const *ao_src, void *const *dst, int32_t dst_device)
 {
     if (!p || !ao_src || !dst || n < 1) return MEAO_ERR_INVALID_ARGUMENT;
+    if (dst_device < 0 || dst_device >= p->device_count)
+        return pool_fail(p, MEAO_ERR_INVALID_ARGUMENT, "meao_pool_gather_to_device: dst_device out of range");
     const int32_t G = static_cast<int32_t>(p->ctx.size());
+    DeviceGuard guard;
     for (int32_t f = 0; f < n; ++f) {
         const int32_t m = f % G;
         if (hipSetDevice(p->device[m]) != hipSuccess) return pool_fail(p, MEAO_ERR_HIP, "meao_pool_gather_to_device: hipSetDevice");
         // on the producing member's stream: ordered behind the kernels that wrote the frame
-        const hipError_t e = hipMemcpyPeerAsync(dst[f], dst_device, ao_src[f], p->device[m], p->out_bytes, p->stream[m]);
+        const hipError_t e = p->device[m] == dst_device
+                                 ? hipMemcpyAsync(dst[f], ao_src[f], p->out_bytes, hipMemcpyDeviceToDevice, p->stream[m])
+                                 : hipMemcpyPeerAsync(dst[f], dst_device, ao_src[f], p->device[m], p->out_bytes, p->stream[m]);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             return pool_fail(p, MEAO_ERR_HIP, std::string("meao_pool_gather_to_device: ") + hipGetErrorString(e));
@@ -168,6 +296,7 @@ int32_t meao_pool_gather_to_device(meao_pool *p, int32_t n, const void *const *a
 int32_t meao_pool_synchronize(meao_pool *p)
 {
     if (!p) return MEAO_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard;
     for (size_t i = 0; i < p->ctx.size(); ++i) {
         if (hipSetDevice(p->device[i]) != hipSuccess || hipStreamSynchronize(p->stream[i]) != hipSuccess) {
             (void)hipGetLastError();

@@ -16,13 +16,25 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def init(backend: str = "nccl", device: "torch.device | None" = None) -> Tuple[int, int, int]:
     """Initialise the default process group when WORLD_SIZE > 1.  Returns (rank, world, local_rank)."""
     rank, world, local_rank = env_world()
     force = os.environ.get("MEAO_FORCE_DIST") == "1"     # exercise the collective path with one rank
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            # torch.distributed.run always exports MASTER_PORT; only a hand-made single-rank group
+            # (MEAO_FORCE_DIST=1) gets here, and it takes a free port instead of a hard-wired one
+            if world > 1:
+                raise RuntimeError("MASTER_PORT is not set: launch with torch.distributed.run (or export MASTER_ADDR / MASTER_PORT)")
+            os.environ["MASTER_PORT"] = str(_free_port())
         kwargs = {}
         if backend == "nccl" and device is not None:
             kwargs["device_id"] = device

@@ -18,8 +18,9 @@ def settings(O, w, h, cam=synth.DEFAULT_CAMERA, **kw):
                       reversed_z=cam.reversed_z, **kw)
 
 
-def component(s, max_batch=1, device=0, **kw):
-    """AmbientOcclusion (C ABI) configured exactly like oracle Settings ``s``."""
+def component(s, max_batch=1, device=0, debug=None, **kw):
+    """AmbientOcclusion (C ABI) configured exactly like oracle Settings ``s``.  ``debug``: {meao_debug_key: value}
+    launch-structure overrides applied through meao_debug_set."""
     from miniengineao_amd import AmbientOcclusion
     ao = AmbientOcclusion(s.width, s.height, device=device, num_levels=s.num_levels,
                           ao_format=s.ao_format, f16_rounding=s.f16_rounding, max_batch=max_batch,
@@ -31,6 +32,8 @@ def component(s, max_batch=1, device=0, **kw):
     ao.upsampleTolerance = s.upsample_tolerance
     ao.thicknessModifier = s.thickness_modifier
     ao.intensity = s.intensity
+    for key, value in (debug or {}).items():
+        ao.debug_set(key, value)
     return ao
 
 

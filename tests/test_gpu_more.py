@@ -320,18 +320,18 @@ def test_pipelined_downsample_tile_counts_and_formats(oracle, w, h, batch, depth
 
 @pytest.mark.parametrize("mode", ["separate", "two_level", "three_level"])
 @pytest.mark.parametrize("w,h,batch", [(203, 117, 3), (256, 128, 1), (640, 360, 2), (67, 45, 2)])
-def test_every_blend_launch_structure_is_bit_exact(oracle, monkeypatch, mode, w, h, batch):
+def test_every_blend_launch_structure_is_bit_exact(oracle, mode, w, h, batch):
     """The three blend passes run as three launches, as L4->L3 inside L3->L2, or all inside the L2->L1
-    launch (chosen by the size of the call; the MEAO_DEBUG_* switches are read by meao_create).  Every
+    launch (chosen by the size of the call; forced here through meao_debug_set).  Every
     buffer of every frame -- one of them hostile -- must equal the oracle's in each structure."""
     if mode == "separate":
-        monkeypatch.setenv("MEAO_DEBUG_NO_FUSED_BLEND", "1")
+        debug = {L.DEBUG_FUSE_COARSE_BLEND: 0}
     else:
-        monkeypatch.setenv("MEAO_DEBUG_NESTED_MAX_TILES", "0" if mode == "two_level" else "1000000")
+        debug = {L.DEBUG_NESTED_MAX_TILES: 0 if mode == "two_level" else 1000000}
     s = H.settings(oracle, w, h)
     frames = [synth.make("S2", w, h, seed=50 + f) for f in range(batch)]
     frames[-1] = H.hostile_frame(w, h, 77, density=0.01)
-    ao = H.component(s, max_batch=batch)
+    ao = H.component(s, max_batch=batch, debug=debug)
     try:
         outs = ao.render_batch(frames)
         for f in range(batch):
@@ -348,17 +348,17 @@ def test_every_blend_launch_structure_is_bit_exact(oracle, monkeypatch, mode, w,
 @pytest.mark.parametrize("small_tiles", [0, 1000000])
 @pytest.mark.parametrize("variant", [dict(), dict(ao_format=1, f16_rounding=1), dict(num_levels=2)])
 @pytest.mark.parametrize("w,h,batch", [(203, 117, 2), (512, 300, 1), (131, 77, 3)])
-def test_both_render_tilings_are_bit_exact(oracle, monkeypatch, small_tiles, variant, w, h, batch):
+def test_both_render_tilings_are_bit_exact(oracle, small_tiles, variant, w, h, batch):
     """Calls with few tiles use 128 x 8 render tiles (render_small_kernel) and 64 x 32 tiles in the final
     upsample pass (upsample_final_small_kernel), larger ones 128 x 32 and 64 x 64; the thresholds are forced
-    either way here (MEAO_DEBUG_*_SMALL_MAX_TILES, read by meao_create)."""
-    monkeypatch.setenv("MEAO_DEBUG_RENDER_SMALL_MAX_TILES", str(small_tiles))
-    monkeypatch.setenv("MEAO_DEBUG_FINAL_SMALL_MAX_TILES", str(small_tiles))     # final pass: 64 x 32 / 64 x 64 tiles
-    monkeypatch.setenv("MEAO_DEBUG_DS_SMALL_MAX_TILES", str(small_tiles))        # downsample pass: 128 x 8 / 128 x 32 tiles
+    either way here (meao_debug_set)."""
+    debug = {L.DEBUG_RENDER_SMALL_MAX_TILES: small_tiles,
+             L.DEBUG_FINAL_SMALL_MAX_TILES: small_tiles,     # final pass: 64 x 32 / 64 x 64 tiles
+             L.DEBUG_DS_SMALL_MAX_TILES: small_tiles}        # downsample pass: 128 x 8 / 128 x 32 tiles
     s = H.settings(oracle, w, h, **variant)
     frames = [synth.make("S2", w, h, seed=70 + f) for f in range(batch)]
     frames[0] = H.hostile_frame(w, h, 78, density=0.01)
-    ao = H.component(s, max_batch=batch)
+    ao = H.component(s, max_batch=batch, debug=debug)
     try:
         outs = ao.render_batch(frames)
         for f in range(batch):
@@ -436,9 +436,9 @@ def test_graph_replay_after_prefetched_batch_reads_the_right_downsample_set(orac
         ao.close()
 
 
-def test_failed_resize_leaves_the_context_usable(oracle, monkeypatch):
-    """A meao_resize / first meao_prefetch_batch whose allocation fails (injected: MEAO_DEBUG_FAIL_ALLOC)
-    returns OUT_OF_MEMORY and the context keeps its size and buffers (VERDICT r1 weak #8)."""
+def test_failed_resize_leaves_the_context_usable(oracle):
+    """A meao_resize / first meao_prefetch_batch whose allocation fails (injected: meao_debug_set
+    FAIL_NEXT_ALLOCS) returns OUT_OF_MEMORY and the context keeps its size and buffers (VERDICT r1 weak #8)."""
     import torch
     w, h = 160, 90
     s = H.settings(oracle, w, h)
@@ -447,7 +447,7 @@ def test_failed_resize_leaves_the_context_usable(oracle, monkeypatch):
     ao = H.component(s, max_batch=2)
     try:
         assert np.array_equal(ao.render(depth), want)
-        monkeypatch.setenv("MEAO_DEBUG_FAIL_ALLOC", "1")
+        ao.debug_set(L.DEBUG_FAIL_NEXT_ALLOCS, 2)
         with pytest.raises(L.MeaoError) as e:
             ao.resize(640, 360)
         assert e.value.status == L.ERR_OUT_OF_MEMORY
@@ -458,7 +458,7 @@ def test_failed_resize_leaves_the_context_usable(oracle, monkeypatch):
             ao.prefetch_device([d.data_ptr()])
         assert e.value.status == L.ERR_OUT_OF_MEMORY
         assert np.array_equal(ao.render(depth), want)
-        monkeypatch.delenv("MEAO_DEBUG_FAIL_ALLOC")
+        ao.debug_set(L.DEBUG_FAIL_NEXT_ALLOCS, 0)
         with pytest.raises(L.MeaoError) as e:
             ao.resize(0, 10)
         assert e.value.status == L.ERR_INVALID_ARGUMENT
@@ -506,5 +506,58 @@ def test_tracing_ranges_can_be_switched_on(oracle):
             assert e.status == L.ERR_UNSUPPORTED        # no libroctx64.so on this box
         assert np.array_equal(ao.render(depth), oracle.run(depth, s, result_only=True)["result"])
         ao.set_tracing(False)
+    finally:
+        ao.close()
+
+
+# ---- round 3 ------------------------------------------------------------------------------------------
+
+def test_graph_replay_leaves_the_ieee_bodies_after_a_hostile_frame(oracle):
+    """a captured sequence bakes its hostile-flag generation into the kernel arguments; the flag
+    words are cleared inside the graph, so a replay over clean data is back on the exact-reciprocal bodies
+    (meao_hostile_frames) after a replay over hostile data -- and both are bit-exact."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h = 256, 128
+    s = H.settings(oracle, w, h)
+    clean = [synth.make("S2", w, h, seed=300 + f) for f in range(2)]
+    hostile = [H.hostile_frame(w, h, 31, density=0.003), clean[1]]
+    d = [torch.from_numpy(f).to(dev) for f in clean]          # the graph is keyed by these pointers
+    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ao = H.component(s, max_batch=2, launch_mode=L.LAUNCH_GRAPH)
+    try:
+        dp, op = [t.data_ptr() for t in d], [t.data_ptr() for t in out]
+        for frames, want_mask in ((clean, 0), (hostile, 1), (clean, 0), (hostile, 1), (clean, 0)):
+            for t, f in zip(d, frames):
+                t.copy_(torch.from_numpy(f))
+            torch.cuda.synchronize(dev)
+            ao.execute_device(dp, op, st)                       # first round captures, the rest replay
+            assert ao.hostile_frames() == want_mask
+            for f in range(2):
+                ok, bad = H.nan_aware_equal(out[f].cpu().numpy(), oracle.run(frames[f], s, result_only=True)["result"])
+                assert ok, (f, int(bad.sum()))
+    finally:
+        ao.close()
+
+
+def test_hostile_frames_mask_in_direct_and_pipelined_calls(oracle):
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h = 200, 120
+    s = H.settings(oracle, w, h)
+    batches = [[synth.make("S2", w, h, seed=400 + 3 * k + f) for f in range(3)] for k in range(3)]
+    batches[1][2] = H.hostile_frame(w, h, 41, density=0.002)
+    batches[2][0] = H.hostile_frame(w, h, 42, density=0.002)
+    dd = [[torch.from_numpy(f).to(dev) for f in b] for b in batches]
+    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(3)]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ao = H.component(s, max_batch=3, pipelined=True)
+    try:
+        for k, want_mask in enumerate((0, 4, 1)):
+            if k + 1 < 3:
+                ao.prefetch_device([t.data_ptr() for t in dd[k + 1]])
+            ao.execute_device([t.data_ptr() for t in dd[k]], [t.data_ptr() for t in out], st)
+            assert ao.hostile_frames() == want_mask, k
     finally:
         ao.close()
