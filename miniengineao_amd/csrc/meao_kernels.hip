@@ -50,9 +50,43 @@
 // profiles/README.md lists them.  Experimental arms of the current round live behind the MEAO_X_* switches
 // of this block only (tests/build_variants.py builds variants next to the product library;
 // tests/test_variants_gpu.py runs a parity smoke through every variant library it finds).
+#ifndef MEAO_X_PHASE_CLOCKS
+#define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py)
+#endif
+
+#if MEAO_X_PHASE_CLOCKS
+// [phase] summed 100 MHz ticks and [16 + phase] wave counts, per upsample-tile phase; read and cleared by meao_x_phase_clocks
+__device__ unsigned long long g_phase_clocks[32];
+extern "C" __attribute__((visibility("default"))) int meao_x_phase_clocks(unsigned long long *out32)
+{
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase_clocks), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    static const unsigned long long zero[32] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clocks), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 
 namespace meao {
 namespace {
+
+// Phase stamps of a tile (diagnostic builds only; compiles to nothing otherwise): lane 0 of every wave adds the
+// time since its previous stamp to the phase's accumulator.
+struct PhaseClock {
+#if MEAO_X_PHASE_CLOCKS
+    unsigned long long last;
+    __device__ __forceinline__ PhaseClock() : last(__builtin_amdgcn_s_memrealtime()) {}
+    __device__ __forceinline__ void mark(int phase)
+    {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g_phase_clocks[phase], now - last);
+            atomicAdd(&g_phase_clocks[16 + phase], 1ull);
+        }
+        last = now;
+    }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -1028,6 +1062,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
     const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
 
+    PhaseClock clk;
     __builtin_amdgcn_s_setprio(3);
     // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
     // are issued first, so that their latency hides behind the prefetch and blur phases.
@@ -1163,7 +1198,9 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             }
         }
     }
+    clk.mark(0);         // 0: window loaded, converted, stored to LDS
     __syncthreads();
+    clk.mark(1);         // 1: barrier
     __builtin_amdgcn_s_setprio(0);       // (kept through the blur phases: +10 % on the pass)
     hook.after_prefetch();
 
@@ -1197,7 +1234,9 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 *reinterpret_cast<float2v *>(&s_hb[r * T::kBlurPitch + c0 + n]) = float2v{o[n], o[n + 1]};
         }
     }
+    clk.mark(2);         // 2: H-blur
     __syncthreads();
+    clk.mark(3);         // 3: barrier
 
     // ---- BlurVertically: runs of T::kVRun outputs; output (r, c) is centred on H-blurred row
     // r+2; depths come from the same virtual column (DepthCache[... + 2], UPS:141-146).  Rows
@@ -1215,7 +1254,9 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
 #pragma unroll
         for (int n = 0; n < T::kVRun; ++n) s_vb[(r0 + n) * T::kBlurPitch + c] = o[n];
     }
+    clk.mark(4);         // 4: V-blur
     __syncthreads();
+    clk.mark(5);         // 5: barrier
     if constexpr (Hook::kBeforeBilateral && FINAL) {
         // vmcnt retires in order: a load issued here would sit behind nothing only if the hoisted operands
         // are waited for first -- naming them in an asm makes the compiler put that wait here
@@ -1315,6 +1356,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                     if (hx0 + e < hw) o[e] = res[e];
             }
         }
+        clk.mark(6 + pass);  // 6, 7: bilateral pass 0 / 1 (64-row tiles) incl. its stores being issued
     }
 }
 

@@ -33,7 +33,6 @@ def main():
             for f in ("meao_kernels.hip", "meao_kernels.hpp"):
                 open(os.path.join(tmp, f), "w").write(subprocess.run(
                     ["git", "show", f"{ref}:miniengineao_amd/csrc/{f}"], cwd=ROOT, check=True, capture_output=True, text=True).stdout)
-            os.makedirs(os.path.join(tmp, "..", "..", "include"), exist_ok=True)
             src = open(os.path.join(tmp, "meao_kernels.hpp")).read().replace('"../../include/meao.h"', '"meao.h"')
             open(os.path.join(tmp, "meao_kernels.hpp"), "w").write(src)
         a, b = asm_of(old_dir, flags), asm_of(csrc, flags)
@@ -41,8 +40,9 @@ def main():
     print(f"{len(set(a) & set(b)) - len(changed)} kernels identical, {len(changed)} changed, "
           f"{len(set(a) - set(b))} only in {ref}, {len(set(b) - set(a))} only in the working tree")
     names = subprocess.run(["c++filt"], input="\n".join(changed), capture_output=True, text=True).stdout.splitlines()
+    strip = re.compile(r"^void |meao::\(anonymous namespace\)::")
     for k, n in zip(changed, names):
-        print(f"  {len(a[k]):6d} -> {len(b[k]):6d} instructions  {re.sub(r'^void |meao::\(anonymous namespace\)::', '', n)[:110]}")
+        print("  %6d -> %6d instructions  %s" % (len(a[k]), len(b[k]), strip.sub("", n)[:110]))
     return 0
 
 if __name__ == "__main__":

@@ -68,10 +68,11 @@ def compile_device(extra_flags=(), want_asm=True):
 
 def table(rows) -> str:
     cols = [("VGPRs", "VGPR"), ("AGPRs", "AGPR"), ("TotalSGPRs", "SGPR"), ("LDS Size [bytes/block]", "LDS B"),
-            ("ScratchSize [bytes/lane]", "scratch"), ("VGPRs Spill", "vspill"), ("Occupancy [waves/SIMD]", "waves/SIMD")]
-    lines = ["%-5s %-5s %-5s %-7s %-8s %-7s %-11s kernel" % tuple(c[1] for c in cols)]
+            ("ScratchSize [bytes/lane]", "scratch"), ("VGPRs Spill", "vspill"), ("SGPRs Spill", "sspill"),
+            ("Occupancy [waves/SIMD]", "waves/SIMD")]
+    lines = ["%-5s %-5s %-5s %-7s %-8s %-7s %-7s %-11s kernel" % tuple(c[1] for c in cols)]
     for r in sorted(rows, key=lambda r: r["name"]):
-        lines.append("%-5s %-5s %-5s %-7s %-8s %-7s %-11s %s" % (*[r.get(c[0], "?") for c in cols], r["name"]))
+        lines.append("%-5s %-5s %-5s %-7s %-8s %-7s %-7s %-11s %s" % (*[r.get(c[0], "?") for c in cols], r["name"]))
     return "\n".join(lines)
 
 

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -312,6 +313,128 @@ __global__ __launch_bounds__(256) void k_fma_with_lds(float *out, Stamp *stamps,
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+
+// ---- round 3: does the transcendental (quarter-rate) pipe overlap with full-rate VALU work? ------------
+// 1 v_rcp_f32 per 7 v_fma_f32 inside every wave (the bilateral phase of the upsample kernels: 5 rcp of ~44)
+__global__ __launch_bounds__(256) void k_rcp_1_in_8(float *out, Stamp *stamps, int iters, float b, float c)
+{
+    float a[16];
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i + 1.0f;
+    PROLOGUE
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            asm volatile("v_rcp_f32 %0, %0" : "+v"(a[g]));
+#pragma unroll
+            for (int i = 0; i < 7; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4 + ((g * 7 + i) % 12)]) : "v"(b), "v"(c));
+        }
+    }
+    EPILOGUE
+    float s = 0; for (int i = 0; i < 16; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// 1 : 3 (a denser transcendental mix)
+__global__ __launch_bounds__(256) void k_rcp_1_in_4(float *out, Stamp *stamps, int iters, float b, float c)
+{
+    float a[16];
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i + 1.0f;
+    PROLOGUE
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            asm volatile("v_rcp_f32 %0, %0" : "+v"(a[g & 3]));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4 + ((g * 3 + i) % 12)]) : "v"(b), "v"(c));
+        }
+    }
+    EPILOGUE
+    float s = 0; for (int i = 0; i < 16; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// workgroups alternate: even ones run only v_rcp_f32, odd ones only v_fma_f32 (every SIMD then holds waves of both
+// kinds).  Reported per instruction over BOTH kinds: 5.3 = no overlap ((8.2 + 2.4) / 2), 4.1 = the rcp waves alone
+// bound it (perfect overlap), in between = partial.
+__global__ __launch_bounds__(256) void k_rcp_waves_next_to_fma_waves(float *out, Stamp *stamps, int iters, float b, float c)
+{
+    float a[16];
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i + 1.0f;
+    PROLOGUE
+    if (blockIdx.x & 1) {
+        for (int it = 0; it < iters; ++it) {
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+        }
+    }
+    EPILOGUE
+    float s = 0; for (int i = 0; i < 16; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// The bilateral phase of the upsample kernels as the compiler emits it, per hi-res texel: four weights
+// K / (|hd - d| + tol) as v_sub, v_add |.|, v_rcp, v_mul, 2 v_fma (K = 1: 3 after the rcp), the two sums, the exact
+// quotient (v_rcp + 2 v_fma + v_mul + 2 v_fma), the UNORM8 encode; two independent texels per round: 84 instructions.
+__global__ __launch_bounds__(256) void k_bilateral_mix(float *out, Stamp *stamps, int iters, float b, float c)
+{
+    float hd[2], d[8], ao[8], res[2];
+    for (int i = 0; i < 8; ++i) { d[i] = threadIdx.x * 0.001f + i; ao[i] = 0.5f + 0.01f * i; }
+    hd[0] = b; hd[1] = c; res[0] = res[1] = 0.0f;
+    const float tol = 1e-12f, nine = 9.0f, three = 3.0f, one = 1.0f;
+    PROLOGUE
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x, r, q, e;
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(x) : "v"(hd[t]), "v"(d[4 * t + k]));
+                asm volatile("v_add_f32 %0, |%1|, %2" : "=v"(x) : "v"(x), "v"(tol));
+                asm volatile("v_rcp_f32 %0, %1" : "=v"(r) : "v"(x));
+                if (k == 2) {
+                    asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(x), "v"(r), "v"(one));
+                    asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(w[k]) : "v"(e), "v"(r));
+                } else {
+                    const float K = k == 0 ? nine : three;
+                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(K), "v"(r));
+                    asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(x), "v"(q), "v"(K));
+                    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(w[k]) : "v"(e), "v"(r), "v"(q));
+                }
+            }
+            float total, sum, r, e, q;
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(total) : "v"(w[0]), "v"(w[1]));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(w[2]));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(w[3]));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(one));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(sum) : "v"(ao[4 * t]), "v"(w[0]));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 1]), "v"(w[1]));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 2]), "v"(w[2]));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 3]), "v"(w[3]));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(one));
+            asm volatile("v_rcp_f32 %0, %1" : "=v"(r) : "v"(total));
+            asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(total), "v"(r), "v"(one));
+            asm volatile("v_fma_f32 %0, %1, %0, %0" : "+v"(r) : "v"(e));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(sum), "v"(r));
+            asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(total), "v"(q), "v"(sum));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(q) : "v"(e), "v"(r));
+            asm volatile("v_mul_f32_e64 %0, %0, %1 clamp" : "+v"(q) : "v"(one));
+            asm volatile("v_mul_f32 %0, 0x437f0000, %0" : "+v"(q));
+            asm volatile("v_add_f32 %0, %0, 0.5" : "+v"(q));
+            asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(q));
+            res[t] = q;
+            d[4 * t] = q;        // loop-carried: the next round's first tap depends on this one (no hoisting)
+        }
+    }
+    EPILOGUE
+    out[blockIdx.x * 256 + threadIdx.x] = res[0] + res[1];
+}
+
 typedef void (*kfn)(float *, Stamp *, int, float, float);
 
 struct Row { const char *name; kfn fn; int per_iter; };
@@ -359,10 +482,16 @@ int main(int argc, char **argv)
         {"render pair mix, packed (10 instr / 2 texels)", k_render_mix_pk, 40},
         {"v_fma_f32 / v_med3_f32 alternating", k_fma_med3_alternating, 32},
         {"8 x v_fma_f32 per ds_read_b64 (VALU instr only)", k_fma_with_lds, 32},
+        {"1 v_rcp_f32 : 7 v_fma_f32 in every wave", k_rcp_1_in_8, 32},
+        {"1 v_rcp_f32 : 3 v_fma_f32 in every wave", k_rcp_1_in_4, 32},
+        {"v_rcp waves next to v_fma waves (both counted)", k_rcp_waves_next_to_fma_waves, 32},
+        {"bilateral-phase mix (2 texels: 84 instr, 10 rcp)", k_bilateral_mix, 84},
     };
+    const char *filter = argc > 2 ? argv[2] : nullptr;    // only rows whose name contains this
     std::printf("%-48s %5s %10s %10s %9s %10s\n", "instruction", "w/SIMD", "cyc/instr", "clock MHz", "ms/launch", "cyc(wall)");
     for (const Row &r : rows) {
-        for (int k : {1, 2, 4, 8}) {
+        if (filter && !std::strstr(r.name, filter)) continue;
+        for (int k : {1, 2, 4, 7, 8}) {
             const int blocks = cus * k;
             // calibrate iterations for ~target_ms per launch
             int iters = 2048;
