@@ -399,7 +399,9 @@ MEAO_API int32_t meao_hostile_frames(meao_ctx *ctx, uint64_t *out_mask);
  * (meao_resize, first meao_prefetch_batch) fail with MEAO_ERR_OUT_OF_MEMORY. */
 typedef enum meao_debug_key {
     MEAO_DEBUG_FUSE_COARSE_BLEND = 0, MEAO_DEBUG_NESTED_MAX_TILES = 1, MEAO_DEBUG_RENDER_SMALL_MAX_TILES = 2,
-    MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4, MEAO_DEBUG_FAIL_NEXT_ALLOCS = 5
+    MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4, MEAO_DEBUG_FAIL_NEXT_ALLOCS = 5,
+    MEAO_DEBUG_DS_SHARE_IN_BLEND = 6   /* percent (0..100) of the next batch's downsample tiles (meao_prefetch_batch) carried by
+                                        * the L2 -> L1 blend launch instead of the last kernel */
 } meao_debug_key;
 MEAO_API int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value);
 

@@ -75,6 +75,7 @@ struct meao_ctx {
     int final_small_max_tiles = 512;   // plain final pass: calls with at most this many 64x64 tiles use 64x32 tiles
     int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
     int nested_max_tiles = 512;        // calls with at most this many L2->L1 tiles (frames x tiles) run the three blend passes as one launch
+    int ds_share_in_blend = 0;         // percent of the carried (next batch's) downsample tiles that ride in the L2->L1 blend launch instead of the last kernel
 
     // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue),
     // and the stream its AO frames were produced on (where a flush that is not given a stream runs it)
@@ -374,6 +375,8 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         }
         ds.hostile = ctx->hostile_of(set);
         ds.generation = generation;
+        ds.tile_begin = 0;
+        ds.tile_end = ds.tiles_x * ds.tiles_y;
         return ds;
     };
     auto next_generation = [&]() { if (++ctx->gen_counter == 0) ++ctx->gen_counter; return ctx->gen_counter; };   // never 0
@@ -545,9 +548,31 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             if (rc != MEAO_OK) return rc;
         }
     }
+    // Part of the announced next batch's downsample pass can ride in the L2 -> L1 blend launch (latency-bound, HBM and
+    // issue slots idle) instead of the last kernel: tiles [0, carried_in_blend) of every frame
+    int carried_in_blend = 0;
+    uint32_t next_gen = 0;
     if (c.num_levels >= 2 && !blend_done) {
-        const int rc = launch_blend(1, stream);
-        if (rc != MEAO_OK) return rc;
+        const UpsampleArgs up1 = upsample_args(1);
+        if (ctx->next_n > 0 && ctx->ds_share_in_blend > 0 && ctx->next_n <= n) {
+            next_gen = next_generation();
+            DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, 1 - ctx->ds_cur, next_gen);
+            const int blend_tiles = up1.tiles_x * up1.tiles_y, ds_tiles = ds.tiles_x * ds.tiles_y;
+            const int share = std::min(blend_tiles, static_cast<int>(static_cast<int64_t>(ds_tiles) * ctx->ds_share_in_blend / 100));
+            const int final_tiles = ((p.mip[0].w + kUpsTileW - 1) / kUpsTileW) * ((p.mip[0].h + ups_tile_h(true) - 1) / ups_tile_h(true));
+            if (share > 0 && ds.vec_ok && c.depth_format == MEAO_DEPTH_F32 && ds_tiles <= final_tiles) {   // the last kernel takes the rest in its split form
+                ds.tile_end = share;
+                TraceRange tr(ctx, "meao:upsample_L2_to_L1+part_of_downsample_next");
+                MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_1, stream));
+                MEAO_HIP(ctx, launch_upsample_blend_with_downsample(up1, ds, c.ao_format, n, stream));
+                MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_1, stream));
+                carried_in_blend = share;
+            }
+        }
+        if (carried_in_blend == 0) {
+            const int rc = launch_blend(1, stream);
+            if (rc != MEAO_OK) return rc;
+        }
     }
     {   // Upsample.main: the result
         TraceRange tr(ctx, kUpsRange[0]);
@@ -556,9 +581,10 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         if (ctx->next_n > 0) {
             // carry the downsample of the announced next batch in this (VALU-bound) kernel
             const int other = 1 - ctx->ds_cur;
-            ctx->set_gen[other] = next_generation();
-            MEAO_HIP(ctx, launch_upsample_final_with_downsample(
-                              up, downsample_args(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other]), c.ao_format, n, stream));
+            ctx->set_gen[other] = carried_in_blend > 0 ? next_gen : next_generation();     // one generation for both carrying launches
+            DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other]);
+            ds.tile_begin = carried_in_blend;
+            MEAO_HIP(ctx, launch_upsample_final_with_downsample(up, ds, c.ao_format, n, stream));
             ctx->ready_n = ctx->next_n;
             ctx->ready_set = other;
             ctx->ready_stream = stream;
@@ -1233,6 +1259,7 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_FINAL_SMALL_MAX_TILES: ctx->final_small_max_tiles = value; break;
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
+    case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
     default: return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: unknown key");
     }
     if (!ctx->graphs.empty()) {      // captured sequences embed the launch structure

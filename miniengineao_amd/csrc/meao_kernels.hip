@@ -50,17 +50,24 @@
 // profiles/README.md lists them.  Experimental arms of the current round live behind the MEAO_X_* switches
 // of this block only (tests/build_variants.py builds variants next to the product library;
 // tests/test_variants_gpu.py runs a parity smoke through every variant library it finds).
+#ifndef MEAO_X_UPS_PERSISTENT
+#define MEAO_X_UPS_PERSISTENT 0 // full-resolution upsample (plain and fused): 1 = persistent workgroups (7 per CU) looping over (frame, tile);
+#endif                          // 2 = the same with the next tile's loads issued in front of the current tile's bilateral phase (plain pass only)
+#ifndef MEAO_X_UPS_RCP_GROUP
+#define MEAO_X_UPS_RCP_GROUP 0  // bilateral phase, exact-division bodies: 4 / 8 / 16 = the v_rcp_f32 of 1 / 2 / 4 texels issued back to back
+#endif                          // (the transcendental pipe pays ~3 cycles per isolated v_rcp_f32: tools/ubench_issue.hip "bilateral mix")
 #ifndef MEAO_X_PHASE_CLOCKS
 #define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py)
 #endif
 
 #if MEAO_X_PHASE_CLOCKS
-// [phase] summed 100 MHz ticks and [16 + phase] wave counts, per upsample-tile phase; read and cleared by meao_x_phase_clocks
-__device__ unsigned long long g_phase_clocks[32];
-extern "C" __attribute__((visibility("default"))) int meao_x_phase_clocks(unsigned long long *out32)
+// [phase] summed 100 MHz ticks and [32 + phase] wave counts, per upsample-tile phase (0..7 full-resolution pass,
+// 8..15 blend passes); read and cleared by meao_x_phase_clocks
+__device__ unsigned long long g_phase_clocks[64];
+extern "C" __attribute__((visibility("default"))) int meao_x_phase_clocks(unsigned long long *out64)
 {
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase_clocks), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-    static const unsigned long long zero[32] = {};
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_clocks), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    static const unsigned long long zero[64] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clocks), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -72,18 +79,26 @@ namespace {
 // time since its previous stamp to the phase's accumulator.
 struct PhaseClock {
 #if MEAO_X_PHASE_CLOCKS
+    // one workgroup in 32 is sampled; the others never read the clock (the read needs an s_waitcnt lgkmcnt(0))
     unsigned long long last;
-    __device__ __forceinline__ PhaseClock() : last(__builtin_amdgcn_s_memrealtime()) {}
+    int base;
+    bool on;
+    __device__ __forceinline__ explicit PhaseClock(int base_) : last(0), base(base_), on((blockIdx.x & 31) == 0)
+    {
+        if (on) last = __builtin_amdgcn_s_memrealtime();
+    }
     __device__ __forceinline__ void mark(int phase)
     {
+        if (!on) return;
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&g_phase_clocks[phase], now - last);
-            atomicAdd(&g_phase_clocks[16 + phase], 1ull);
+            atomicAdd(&g_phase_clocks[base + phase], now - last);
+            atomicAdd(&g_phase_clocks[32 + base + phase], 1ull);
         }
         last = now;
     }
 #else
+    __device__ __forceinline__ explicit PhaseClock(int) {}
     __device__ __forceinline__ void mark(int) {}
 #endif
 };
@@ -102,6 +117,16 @@ constexpr int kThreads = 256;
 // scalar / packed helpers
 
 __device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// threadIdx.x behind an optimisation barrier: inside the tile loop of a persistent kernel every lane-dependent index
+// (LDS addresses, run numbers, texel coordinates) is loop-invariant, and the compiler would hoist all of them out of
+// the loop into long-lived registers (38 spilled VGPRs in the first persistent upsample kernel).
+__device__ __forceinline__ int thread_index_opaque()
+{
+    int t = static_cast<int>(threadIdx.x);
+    asm volatile("" : "+v"(t));
+    return t;
+}
 __device__ __forceinline__ float sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
@@ -999,6 +1024,59 @@ __device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao,
     return div_strict<DIV>(hi_ao * sum, total);
 }
 
+// BilateralUpsample for N texels at once with the 4N weight reciprocals issued back to back (and then the N
+// reciprocals of the final quotients): same operations per texel, in the same order, as bilateral_upsample<DIV_EXACT_RCP>.
+template <int N>
+__device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_depth)[N], const float (&hi_ao)[N], const float (&d)[N][4],
+                                                           const float (&a)[N][4], const BilateralConsts &k, float (&out)[N])
+{
+    float x[N][4], r[N][4], w[N][4];
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[t][i] = __builtin_fabsf(hi_depth[t] - d[t][i]) + k.tolerance;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_rcp_f32 %0, %1" : "=v"(r[t][i]) : "v"(x[t][i]));
+    __builtin_amdgcn_sched_barrier(0);
+    float total[N], sum[N], rr[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i == 2) {                                              // 1 / x: one Newton step (rcp_strict)
+                const float e = mad(-x[t][i], r[t][i], 1.0f);
+                w[t][i] = mad(e, r[t][i], r[t][i]);
+            } else {                                                   // {9, 3} / x (div_const)
+                const float kv = i == 0 ? k.nine : k.three;
+                const float q = kv * r[t][i];
+                const float e = mad(-x[t][i], q, kv);
+                w[t][i] = mad(e, r[t][i], q);
+            }
+        }
+        total[t] = (((w[t][0] + w[t][1]) + w[t][2]) + w[t][3]) + k.noise;
+        float sm = a[t][0] * w[t][0];
+        sm = mad(a[t][1], w[t][1], sm);
+        sm = mad(a[t][2], w[t][2], sm);
+        sm = mad(a[t][3], w[t][3], sm);
+        sum[t] = hi_ao[t] * (sm + k.noise);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < N; ++t) asm volatile("v_rcp_f32 %0, %1" : "=v"(rr[t]) : "v"(total[t]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < N; ++t) {                                      // div_strict(sum, total)
+        const float e0 = mad(-total[t], rr[t], 1.0f);
+        const float rc = mad(e0, rr[t], rr[t]);
+        const float q = sum[t] * rc;
+        const float e = mad(-total[t], q, sum[t]);
+        out[t] = mad(e, rc, q);
+    }
+}
+
 // One tile of Upsample.main (FINAL) / main_blendout; every thread of the workgroup must call it
 // (barriers inside; lanes outside the image leave after the last one).
 template <bool FINAL, int TILE_H = ups_tile_h(FINAL)>
@@ -1012,6 +1090,91 @@ struct UpsLds {
     static constexpr int kFloats = kInvN + kHbN + kDepN + kAoN;
 };
 
+// The global loads of an interior tile (no horizontal clamping, 16-byte loads everywhere, no second AO input): its low-res
+// window as 16-byte row quads [LX0 - 4 + 4k, +4) -- depth and AO -- and the hi-res operands of the bilateral phase
+// (f16 depth in the full-resolution pass, f32 depth + AO in the blend passes).  Issued at the top of the tile, or -- in the
+// persistent kernels -- a whole tile ahead, in front of the previous tile's bilateral phase.
+template <int AOFMT, bool FINAL, int TILE_H>
+struct UpsLoads {
+    typedef AoTexel<AOFMT> AO;
+    static constexpr int kItems = 10 * UpsTile<TILE_H>::kRawH, kRounds = (kItems + kThreads - 1) / kThreads, kPasses = TILE_H / 32;
+    float4v wd[kRounds];
+    typename AO::type4 wa[kRounds];
+    ushort4v hd16[kPasses][2];
+    float4v hd32[kPasses][2];
+    typename AO::type4 ha[kPasses][2];
+};
+
+template <bool FINAL, int TILE_H>
+__device__ __forceinline__ bool ups_tile_is_interior(const UpsampleArgs &a, int tile)
+{
+    const int LX0 = ((tile % a.tiles_x) * kUpsTileW) >> 1;
+    return a.vec_ok != 0 && !a.lo_ao2 && (a.lw & 3) == 0 && LX0 >= 4 && LX0 + 35 < a.lw;
+}
+
+// Hi-res operands.  CLAMPED: every lane loads (out-of-frame lanes re-read the frame's last row / quad and never use it),
+// so that the code is branch-free and the compiler's s_waitcnt counts stay exact.
+template <int AOFMT, bool FINAL, int TILE_H, bool CLAMPED>
+__device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
+{
+    const int tid = thread_index_opaque();
+    typedef AoTexel<AOFMT> AO;
+    typedef typename AO::type ao_t;
+    const int HX0 = (tile % a.tiles_x) * kUpsTileW, HY0 = (tile / a.tiles_x) * TILE_H;
+    const int hw = a.hw, hh = a.hh;
+    const int htx = tid & 15;
+    const int hhx0 = CLAMPED ? min(HX0 + 4 * htx, hw - 4) : HX0 + 4 * htx;
+#pragma unroll
+    for (int pass = 0; pass < TILE_H / 32; ++pass)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int hy_raw = HY0 + 2 * ((tid >> 4) + 16 * pass) + f;
+            const int hy = CLAMPED ? min(hy_raw, hh - 1) : hy_raw;
+            if (CLAMPED || (hhx0 < hw && hy < hh)) {
+                const size_t hrow = static_cast<size_t>(hy) * hw + hhx0;
+                if constexpr (FINAL) {
+                    L.hd16[pass][f] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(
+                        frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow));
+                } else {
+                    L.hd32[pass][f] = *reinterpret_cast<const float4v *>(
+                        frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow);
+                    L.ha[pass][f] = *reinterpret_cast<const typename AO::type4 *>(
+                        frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow);
+                }
+            }
+        }
+}
+
+// All loads of an interior tile: window first, hi-res operands behind them.  The window comes from L2 (written by the
+// previous pass), the hi-res operands of the final pass from HBM; vmcnt retires loads in issue order, so with the hi-res
+// loads in front the window wait would last an HBM latency.
+template <int AOFMT, bool FINAL, int TILE_H, bool WINDOW_ONLY = false>
+__device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
+{
+    const int tid = thread_index_opaque();
+    typedef UpsLoads<AOFMT, FINAL, TILE_H> Loads;
+    typedef typename Loads::AO AO;
+    typedef typename AO::type ao_t;
+    const int LX0 = ((tile % a.tiles_x) * kUpsTileW) >> 1, LY0 = ((tile / a.tiles_x) * TILE_H) >> 1;
+    const int lw = a.lw, lh = a.lh;
+    const float *__restrict__ lo_depth = frame_ptr(a.lo_depth, a.frame_stride, frame);
+    const ao_t *__restrict__ lo_ao = frame_ptr(static_cast<const ao_t *>(a.lo_ao), a.frame_stride, frame);
+#pragma unroll
+    for (int round = 0; round < Loads::kRounds; ++round) {
+        const int i = min(tid + round * kThreads, Loads::kItems - 1);
+        const int r = i / 10, k = i % 10;
+        const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
+        const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
+        L.wd[round] = *reinterpret_cast<const float4v *>(lo_depth + idx);
+        L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
+    }
+    if constexpr (!WINDOW_ONLY) {
+        __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
+        ups_issue_hoisted<AOFMT, FINAL, TILE_H, true>(a, tile, frame, L);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // NESTED: the LoResAO1 taps (s_ao) were already produced in LDS by blend_window_into_lds (the
 // previous pass of the chain evaluated inside this workgroup) instead of being read from global memory.
 // Places inside an upsample tile where every thread of the workgroup can put unrelated global loads in flight:
@@ -1023,9 +1186,14 @@ struct NoHook {
     __device__ __forceinline__ void before_bilateral() const {}
 };
 
-template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
-__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
+// PRELOADED (persistent kernels): `pre` holds the window loads of this -- interior -- tile, issued a tile ago
+// (ups_issue_interior_loads<.., WINDOW_ONLY>); its hi-res operands are loaded here, at the top of the tile, as always.
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL),
+          bool PRELOADED = false>
+__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook(),
+                                              const UpsLoads<AOFMT, FINAL, TILE_H> *pre = nullptr)
 {
+    const int tid = thread_index_opaque();
     typedef AoTexel<AOFMT> AO;
     typedef typename AO::type ao_t;
     constexpr int kTileH = TILE_H;
@@ -1062,67 +1230,35 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
     const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
 
-    PhaseClock clk;
+    PhaseClock clk(FINAL ? 0 : 8);
     __builtin_amdgcn_s_setprio(3);
     // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
     // are issued first, so that their latency hides behind the prefetch and blur phases.
     constexpr int kPasses = kTileH / 32;
-    ushort4v hoist_hd16[kPasses][2];
-    float4v hoist_hd32[kPasses][2];
-    typename AO::type4 hoist_ha[kPasses][2];
+    typedef UpsLoads<AOFMT, FINAL, TILE_H> Loads;
+    Loads L;
+    if constexpr (PRELOADED) {
+#pragma unroll
+        for (int round = 0; round < Loads::kRounds; ++round) { L.wd[round] = pre->wd[round]; L.wa[round] = pre->wa[round]; }
+        ups_issue_hoisted<AOFMT, FINAL, TILE_H, true>(a, tile, frame, L);
+    }
+    auto &hoist_hd16 = L.hd16;
+    auto &hoist_hd32 = L.hd32;
+    auto &hoist_ha = L.ha;
     const bool hoist_ok = a.vec_ok != 0;
-    // CLAMPED: every lane loads (out-of-frame lanes re-read the frame's last row / quad and never use it), so
-    // that the code is branch-free and the compiler's s_waitcnt counts stay exact
-    auto issue_hoisted = [&](auto clamped) {
-        constexpr bool CLAMPED = decltype(clamped)::value;
-        const int htx = threadIdx.x & 15;
-        const int hhx0 = CLAMPED ? min(HX0 + 4 * htx, hw - 4) : HX0 + 4 * htx;
-#pragma unroll
-        for (int pass = 0; pass < kPasses; ++pass)
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const int hy_raw = HY0 + 2 * ((threadIdx.x >> 4) + 16 * pass) + f;
-                const int hy = CLAMPED ? min(hy_raw, hh - 1) : hy_raw;
-                if (CLAMPED || (hhx0 < hw && hy < hh)) {
-                    const size_t hrow = static_cast<size_t>(hy) * hw + hhx0;
-                    if constexpr (FINAL) {
-                        hoist_hd16[pass][f] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(
-                            frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow));
-                    } else {
-                        hoist_hd32[pass][f] = *reinterpret_cast<const float4v *>(
-                            frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow);
-                        hoist_ha[pass][f] = *reinterpret_cast<const typename AO::type4 *>(
-                            frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow);
-                    }
-                }
-            }
-    };
-    // interior tile, 16-byte loads everywhere, no second AO input: window loads first (see below)
-    const bool window_first = !NESTED && hoist_ok && !lo_ao2 && ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
-    if (hoist_ok && !window_first) issue_hoisted(std::false_type());
+    // interior tile, 16-byte loads everywhere, no second AO input: window loads first (ups_issue_interior_loads)
+    const bool window_first = PRELOADED || (!NESTED && ups_tile_is_interior<FINAL, TILE_H>(a, tile));
+    if constexpr (!PRELOADED)
+        if (hoist_ok && !window_first) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false>(a, tile, frame, L);
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
     // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
     const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
     if (window_first) {
-        // The window comes from L2 (written by the previous pass), the hi-res operands of the final pass from
-        // HBM; vmcnt retires loads in issue order, so with the hi-res loads in front the window wait lasts an
-        // HBM latency.  Here: all window loads of the lane, then the hi-res loads, then the window is consumed.
-        constexpr int kItems = 10 * T::kRawH, kRounds = (kItems + kThreads - 1) / kThreads;
-        float4v wd[kRounds];
-        typename AO::type4 wa[kRounds];
-#pragma unroll
-        for (int round = 0; round < kRounds; ++round) {
-            const int i = min(static_cast<int>(threadIdx.x) + round * kThreads, kItems - 1);
-            const int r = i / 10, k = i % 10;
-            const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
-            const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
-            wd[round] = *reinterpret_cast<const float4v *>(lo_depth + idx);
-            if constexpr (!NESTED) wa[round] = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
-        }
-        __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
-        issue_hoisted(std::true_type());
-        __builtin_amdgcn_sched_barrier(0);
+        constexpr int kItems = Loads::kItems, kRounds = Loads::kRounds;
+        if constexpr (!PRELOADED && !NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H>(a, tile, frame, L);
+        auto &wd = L.wd;
+        auto &wa = L.wa;
 #pragma unroll
         for (int round = 0; round < kRounds; ++round) {
             // an unconditional use: the compiler would otherwise sink the loads of the partial last round into
@@ -1132,7 +1268,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type bits_t;
                 asm volatile("" : : "v"(__builtin_bit_cast(bits_t, wa[round])));
             }
-            const int i = threadIdx.x + round * kThreads;
+            const int i = tid + round * kThreads;
             // (storing the window as aligned 16-byte quads -- fourth column from the next lane by DPP -- removes the 4-way
             // bank conflicts of these scalar stores and changes nothing: profiles/r02_ab_v23_aligned_fill.jsonl)
             if (i < kItems) {
@@ -1157,7 +1293,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     } else if (interior_x) {
         // no horizontal clamping inside this tile: one aligned 16-byte depth load (+ 4 AO texels)
         // per lane covers the 40-texel row segment [LX0-4, LX0+35]
-        for (int i = threadIdx.x; i < 10 * T::kRawH; i += kThreads) {
+        for (int i = tid; i < 10 * T::kRawH; i += kThreads) {
             const int r = i / 10, k = i % 10;
             const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
             const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
@@ -1184,7 +1320,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             }
         }
     } else {
-        for (int i = threadIdx.x; i < T::kRawW * T::kRawH; i += kThreads) {
+        for (int i = tid; i < T::kRawW * T::kRawH; i += kThreads) {
             const int r = i / T::kRawW, c = i % T::kRawW;
             const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
             const size_t idx = static_cast<size_t>(cy) * lw + cx;
@@ -1206,7 +1342,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
 
     // ---- BlurHorizontally: runs of 4 outputs; output (r, c) is centred on raw column c+2.
     // (Columns 34, 35 of the last run are scratch: they read the row padding.)
-    for (int i = threadIdx.x; i < T::kHSegs * T::kRawH; i += kThreads) {
+    for (int i = tid; i < T::kHSegs * T::kRawH; i += kThreads) {
         const int r = i / T::kHSegs, c0 = (i % T::kHSegs) * T::kHRun;
         float av[T::kHRun + 4], zv[T::kHRun + 4], o[T::kHRun];
         if constexpr (T::kHRun == 4) {
@@ -1242,7 +1378,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     // r+2; depths come from the same virtual column (DepthCache[... + 2], UPS:141-146).  Rows
     // >= T::kBlurH of the last run are scratch: they read rows past the window (never used).
     // s_vb aliases s_ao, which nothing reads after the barrier above.
-    for (int i = threadIdx.x; i < T::kVSegs * T::kBlurW; i += kThreads) {
+    for (int i = tid; i < T::kVSegs * T::kBlurW; i += kThreads) {
         const int c = i % T::kBlurW, r0 = (i / T::kBlurW) * T::kVRun;
         float av[T::kVRun + 4], zv[T::kVRun + 4], o[T::kVRun];
 #pragma unroll
@@ -1257,12 +1393,19 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     clk.mark(4);         // 4: V-blur
     __syncthreads();
     clk.mark(5);         // 5: barrier
-    if constexpr (Hook::kBeforeBilateral && FINAL) {
+    if constexpr (Hook::kBeforeBilateral) {
         // vmcnt retires in order: a load issued here would sit behind nothing only if the hoisted operands
         // are waited for first -- naming them in an asm makes the compiler put that wait here
 #pragma unroll
-        for (int pass = 0; pass < kPasses; ++pass)
-            asm volatile("" : : "v"(hoist_hd16[pass][0]), "v"(hoist_hd16[pass][1]));
+        for (int pass = 0; pass < kPasses; ++pass) {
+            if constexpr (FINAL) {
+                asm volatile("" : : "v"(hoist_hd16[pass][0]), "v"(hoist_hd16[pass][1]));
+            } else {
+                typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type bits_t;
+                asm volatile("" : : "v"(hoist_hd32[pass][0]), "v"(hoist_hd32[pass][1]),
+                             "v"(__builtin_bit_cast(bits_t, hoist_ha[pass][0])), "v"(__builtin_bit_cast(bits_t, hoist_ha[pass][1])));
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         hook.before_bilateral();
         __builtin_amdgcn_sched_barrier(0);
@@ -1274,12 +1417,12 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const bool vec_ok = a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
     // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
     constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
-    const int tx = threadIdx.x & 15;
+    const int tx = tid & 15;
     const int hx0 = HX0 + 4 * tx;
     if (hx0 >= hw) return;
 #pragma unroll       // the hoisted operands live in registers: static indices
     for (int pass = 0; pass < kTileH / 32; ++pass) {
-        const int ty = (threadIdx.x >> 4) + 16 * pass;
+        const int ty = (tid >> 4) + 16 * pass;
         const int hy0 = HY0 + 2 * ty;
         if (hy0 >= hh) return;
 
@@ -1328,6 +1471,30 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 }
             }
             ao_t res[4];
+            if constexpr (MEAO_X_UPS_RCP_GROUP >= 4 && DIV == DIV_EXACT_RCP) {
+                constexpr int kGroup = MEAO_X_UPS_RCP_GROUP >= 4 ? MEAO_X_UPS_RCP_GROUP / 4 : 1;   // texels whose reciprocals are issued together
+                static_assert(kGroup == 1 || kGroup == 2 || kGroup == 4, "MEAO_X_UPS_RCP_GROUP is 4, 8 or 16");
+#pragma unroll
+                for (int e0 = 0; e0 < 4; e0 += kGroup) {
+                    float gd[kGroup][4], ga[kGroup][4], ghd[kGroup], gha[kGroup], gout[kGroup];
+#pragma unroll
+                    for (int t = 0; t < kGroup; ++t) {
+                        const int e = e0 + t;
+                        const int cc = ((e + 1) >> 1) + 1, rr = f + 1;
+                        const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int g = (comp + i) & 3;
+                            gd[t][i] = dl[rr + gy[g]][cc + gx[g]];
+                            ga[t][i] = vb[rr + gy[g]][cc + gx[g]];
+                        }
+                        ghd[t] = hd[e]; gha[t] = ha[e];
+                    }
+                    bilateral_upsample_grouped<kGroup>(ghd, gha, gd, ga, bilateral_k, gout);
+#pragma unroll
+                    for (int t = 0; t < kGroup; ++t) res[e0 + t] = AO::template encode<RTNE>(gout[t]);
+                }
+            } else
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 // hi texel (4tx+e, 2ty+f) is written by dispatch thread D = ((hx+1)>>1, (hy+1)>>1)
@@ -1592,7 +1759,8 @@ struct IssueCarriedLoads {
     const DownsampleArgs &d;
     float (&v)[kDsTileH / kDsRowsPerPass][4];
     bool mine;
-    __device__ __forceinline__ void issue() const { if (mine) downsample_tile_load<true, true>(d, blockIdx.x, blockIdx.z, v); }
+    int tile, frame;
+    __device__ __forceinline__ void issue() const { if (mine) downsample_tile_load<true, true>(d, tile, frame, v); }
     __device__ __forceinline__ void after_prefetch() const { if constexpr (!kBeforeBilateral) issue(); }
     __device__ __forceinline__ void before_bilateral() const { if constexpr (kBeforeBilateral) issue(); }
 };
@@ -1623,16 +1791,125 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsamp
     const int ds_tiles = d.tiles_x * d.tiles_y;
     const bool split = d.vec_ok != 0 && d.depth_format == MEAO_DEPTH_F32 && gridDim.x >= static_cast<unsigned>(ds_tiles) &&
                        gridDim.z >= static_cast<unsigned>(d.frames);
-    if (!split) {
+    if (!split) {       // (the host only moves tiles into a blend pass when the split form applies: tile_begin = 0 here)
         carried_downsample();
         upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
         return;
     }
-    const bool mine = blockIdx.x < static_cast<unsigned>(ds_tiles) && blockIdx.z < static_cast<unsigned>(d.frames);
+    // (tiles below d.tile_begin were carried by an earlier launch of this call: a blend pass, MEAO_DEBUG_DS_SHARE_IN_BLEND)
+    const bool mine = blockIdx.x >= static_cast<unsigned>(d.tile_begin) && blockIdx.x < static_cast<unsigned>(ds_tiles) &&
+                      blockIdx.z < static_cast<unsigned>(d.frames);
     float v[kDsTileH / kDsRowsPerPass][4];
-    const IssueCarriedLoads issue = {d, v, mine};
+    const IssueCarriedLoads issue = {d, v, mine, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.z)};
     upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z, issue);
     if (mine) downsample_tile_finish<RTNE, true, DIV>(d, blockIdx.x, blockIdx.z, v);
+}
+
+// Upsample.main_blendout L2 -> L1 carrying the first d.tile_end downsample tiles (per frame) of the NEXT batch: the
+// blend passes wait on latency with issue slots and HBM idle, the fused last kernel is short of both
+// (MEAO_DEBUG_DS_SHARE_IN_BLEND; the last kernel then starts at d.tile_begin = this launch's tile_end).
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(kThreads) void upsample_blend_with_next_downsample_kernel(const UpsampleArgs a, const DownsampleArgs d)
+{
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<false>::kFloats];
+    const bool mine = blockIdx.x < static_cast<unsigned>(d.tile_end) && blockIdx.z < static_cast<unsigned>(d.frames);
+    float v[kDsTileH / kDsRowsPerPass][4];
+    const IssueCarriedLoads issue = {d, v, mine, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.z)};
+    upsample_tile_checked<AOFMT, RTNE, false, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z, issue);
+    if (mine) downsample_tile_finish<RTNE, true, DIV>(d, blockIdx.x, blockIdx.z, v);
+}
+
+// ---- experiment (MEAO_X_UPS_PERSISTENT): the full-resolution pass as persistent workgroups ------------------
+// gridDim.x = 7 workgroups per CU (a multiple of 8, so a workgroup's ids id, id + gridDim.x, ... stay on its XCD);
+// xcd_contiguous over the whole batch gives every XCD a contiguous range of (frame, tile) pairs.
+// Hook of the persistent kernels: the loads of the workgroup's NEXT (interior) tile go out in front of this tile's
+// bilateral phase -- a whole phase before they are needed, and in front of this tile's stores (vmcnt retires in order:
+// loads issued behind the stores would wait for the stores' round trip to HBM).
+template <int AOFMT, bool FINAL, int TILE_H>
+struct IssueNextTileLoads {
+    static constexpr bool kBeforeBilateral = true;
+    const UpsampleArgs &a;
+    UpsLoads<AOFMT, FINAL, TILE_H> &next;
+    bool active;
+    int tile, frame;
+    __device__ __forceinline__ void after_prefetch() const {}
+    __device__ __forceinline__ void before_bilateral() const
+    {
+        if (active) ups_issue_interior_loads<AOFMT, FINAL, TILE_H, true>(a, tile, frame, next);
+    }
+};
+
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(kThreads, 7) void upsample_final_persistent_kernel(const UpsampleArgs a, int frames)
+{
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<true>::kFloats];
+    const int per_frame = a.tiles_x * a.tiles_y, total = per_frame * frames;
+#if MEAO_X_UPS_PERSISTENT == 2
+    constexpr int kTileH = ups_tile_h(true);
+    typedef UpsLoads<AOFMT, true, kTileH> Loads;
+    // frames whose downsample pass saw hostile depth take the IEEE-division bodies (no prefetching across them)
+    uint64_t hostile_mask = 0;
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        const int lane = threadIdx.x & 63;
+        hostile_mask = __builtin_amdgcn_ballot_w64(lane < frames && __builtin_nontemporal_load(a.hostile + lane) == a.generation);
+    }
+    auto interior = [&](int tile, int frame) {
+        return ups_tile_is_interior<true, kTileH>(a, tile) && !(hostile_mask >> frame & 1u);
+    };
+    Loads cur, nxt;
+    int id = blockIdx.x;
+    if (id >= total) return;
+    int g = xcd_contiguous(id, total), frame = g / per_frame, tile = g - frame * per_frame;
+    bool fast = interior(tile, frame);
+    if (fast) ups_issue_interior_loads<AOFMT, true, kTileH, true>(a, tile, frame, cur);
+    for (;;) {
+        const int nid = id + gridDim.x;
+        int ntile = 0, nframe = 0;
+        bool nfast = false;
+        if (nid < total) {
+            const int ng = xcd_contiguous(nid, total);
+            nframe = ng / per_frame;
+            ntile = ng - nframe * per_frame;
+            nfast = interior(ntile, nframe);
+        }
+        if (fast) {
+            const IssueNextTileLoads<AOFMT, true, kTileH> hook = {a, nxt, nfast, ntile, nframe};
+            upsample_tile<AOFMT, RTNE, true, DIV, false, IssueNextTileLoads<AOFMT, true, kTileH>, kTileH, true>(a, smem, tile, frame, hook, &cur);
+        } else {
+            if (hostile_mask >> frame & 1u) upsample_tile<AOFMT, RTNE, true, DIV_IEEE>(a, smem, tile, frame);
+            else upsample_tile<AOFMT, RTNE, true, DIV>(a, smem, tile, frame);
+            if (nfast) ups_issue_interior_loads<AOFMT, true, kTileH, true>(a, ntile, nframe, nxt);
+        }
+        if (nid >= total) break;
+        cur = nxt;
+        id = nid; tile = ntile; frame = nframe; fast = nfast;
+        __syncthreads();       // the next tile's fill overwrites what slower waves still read
+    }
+#else
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+        const int g = xcd_contiguous(id, total), frame = g / per_frame, tile = g - frame * per_frame;
+        upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, tile, frame);
+        __syncthreads();       // the next tile's fill overwrites what slower waves still read
+    }
+#endif
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsample_persistent_kernel(const UpsampleArgs a,
+                                                                                                  const DownsampleArgs d, int frames)
+{
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<true>::kFloats];
+    const int per_frame = a.tiles_x * a.tiles_y, total = per_frame * frames;
+    const int ds_tiles = d.tiles_x * d.tiles_y;       // the launcher guarantees ds_tiles <= per_frame, d.frames <= frames, 16-byte f32 loads
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+        const int g = xcd_contiguous(id, total), frame = g / per_frame, tile = g - frame * per_frame;
+        const bool mine = tile >= d.tile_begin && tile < ds_tiles && frame < d.frames;
+        float v[kDsTileH / kDsRowsPerPass][4];
+        const IssueCarriedLoads issue = {d, v, mine, tile, frame};
+        upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, tile, frame, issue);
+        if (mine) downsample_tile_finish<RTNE, true, DIV>(d, tile, frame, v);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2054,9 +2331,30 @@ hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hi
     return launch_render_any<true>(a, ao_format, frames, s);
 }
 
+// workgroups of a persistent launch: 7 per CU (what the 22.8 KB of LDS per workgroup allow), a multiple of 8
+static int persistent_grid(int total)
+{
+    static int cus[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev >= 64 ? 0 : dev;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    const int want = cus[dev] * 7 / 8 * 8;
+    return total < want ? (total + 7) / 8 * 8 : want;
+}
+
 template <int AOFMT, bool RTNE, int DIV>
 static void launch_upsample_t(const UpsampleArgs &a, bool final_pass, dim3 grid, hipStream_t s)
 {
+    if (MEAO_X_UPS_PERSISTENT && final_pass && a.tile_h != kUpsTileHSmall) {
+        const int frames = static_cast<int>(grid.z), total = a.tiles_x * a.tiles_y * frames;
+        upsample_final_persistent_kernel<AOFMT, RTNE, DIV><<<dim3(persistent_grid(total)), dim3(kThreads), 0, s>>>(a, frames);
+        return;
+    }
     if (final_pass && a.tile_h == kUpsTileHSmall) upsample_final_small_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else if (final_pass) upsample_kernel<AOFMT, RTNE, true, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else upsample_kernel<AOFMT, RTNE, false, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
@@ -2131,6 +2429,13 @@ hipError_t launch_upsample_three_level(const UpsampleArgs &outer, const Upsample
 template <int AOFMT, bool RTNE, int DIV>
 static void launch_upsample_fused_t(const UpsampleArgs &a, const DownsampleArgs &d, dim3 grid, hipStream_t s)
 {
+    const int frames = static_cast<int>(grid.z);
+    if (MEAO_X_UPS_PERSISTENT == 1 && d.vec_ok != 0 && d.depth_format == MEAO_DEPTH_F32 && d.tiles_x * d.tiles_y <= a.tiles_x * a.tiles_y &&
+        d.frames <= frames) {
+        const int total = a.tiles_x * a.tiles_y * frames;
+        upsample_final_with_next_downsample_persistent_kernel<AOFMT, RTNE, DIV><<<dim3(persistent_grid(total)), dim3(kThreads), 0, s>>>(a, d, frames);
+        return;
+    }
     upsample_final_with_next_downsample_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a, d);
 }
 
@@ -2148,6 +2453,31 @@ hipError_t launch_upsample_final_with_downsample(const UpsampleArgs &a, const Do
         else if (a.exact_rcp_div == 2) launch_upsample_fused_t<MEAO_AO_F16, false, DIV_FAST>(a, d, grid, s);
         else if (a.exact_rcp_div) launch_upsample_fused_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, d, grid, s);
         else launch_upsample_fused_t<MEAO_AO_F16, false, DIV_IEEE>(a, d, grid, s);
+    }
+    return hipGetLastError();
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+static void launch_upsample_blend_ds_t(const UpsampleArgs &a, const DownsampleArgs &d, dim3 grid, hipStream_t s)
+{
+    upsample_blend_with_next_downsample_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a, d);
+}
+
+hipError_t launch_upsample_blend_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format, int frames, hipStream_t s)
+{
+    const dim3 grid(a.tiles_x * a.tiles_y, 1, frames);
+    if (d.vec_ok == 0 || d.depth_format != MEAO_DEPTH_F32 || d.tile_end > static_cast<int>(grid.x) || d.frames > frames)
+        return hipErrorInvalidValue;      // the caller checks the same conditions before it moves tiles here
+    if (ao_format == MEAO_AO_R8) {
+        if (a.f16_rtne) launch_upsample_blend_ds_t<MEAO_AO_R8, true, DIV_IEEE>(a, d, grid, s);
+        else if (a.exact_rcp_div == 2) launch_upsample_blend_ds_t<MEAO_AO_R8, false, DIV_FAST>(a, d, grid, s);
+        else if (a.exact_rcp_div) launch_upsample_blend_ds_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(a, d, grid, s);
+        else launch_upsample_blend_ds_t<MEAO_AO_R8, false, DIV_IEEE>(a, d, grid, s);
+    } else {
+        if (a.f16_rtne) launch_upsample_blend_ds_t<MEAO_AO_F16, true, DIV_IEEE>(a, d, grid, s);
+        else if (a.exact_rcp_div == 2) launch_upsample_blend_ds_t<MEAO_AO_F16, false, DIV_FAST>(a, d, grid, s);
+        else if (a.exact_rcp_div) launch_upsample_blend_ds_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, d, grid, s);
+        else launch_upsample_blend_ds_t<MEAO_AO_F16, false, DIV_IEEE>(a, d, grid, s);
     }
     return hipGetLastError();
 }

@@ -23,7 +23,8 @@ struct DownsampleArgs {
     int32_t exact_rcp_div;
     int32_t tiles_x, tiles_y;
     int32_t row_passes;       // row passes per tile: kDsTileH / kDsRowsPerPass, or 1 (downsample_small_kernel; stand-alone pass of small calls)
-    int32_t frames;                      // used by the fused kernel only (the plain launch has grid.z = frames)
+    int32_t frames;                      // used by the fused kernels only (the plain launch has grid.z = frames)
+    int32_t tile_begin, tile_end;        // fused kernels: the tiles (per frame) this launch carries are [tile_begin, tile_end)
     int32_t vec_ok;                      // width % 4 == 0 and every depth pointer aligned for 4-texel loads
     // hostile[frame] = generation when a texel of the frame is outside the range the exact
     // v_rcp_f32 sequences are verified for (NaN, inf, negative, tiny); read by the later kernels
@@ -131,6 +132,9 @@ hipError_t launch_upsample_three_level(const UpsampleArgs &outer, const Upsample
 // Upsample.main of this batch + the downsample pass of the next one in a single kernel.
 hipError_t launch_upsample_final_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format,
                                                  int frames, hipStream_t s);
+// Upsample.main_blendout (L2 -> L1) carrying downsample tiles [0, d.tile_end) of the next batch.
+hipError_t launch_upsample_blend_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format, int frames,
+                                                 hipStream_t s);
 hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s);
 // Debug view (PushDebugBlitCommands): src in `src_format` (meao_format), [slices][sh][sw] -> dst AO W x H.
 struct DebugViewArgs {

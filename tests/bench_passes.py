@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=None)
 ap.add_argument("--pipeline", action="store_true")
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--tag", default="")
+ap.add_argument("--ds-share", type=int, default=0, help="MEAO_DEBUG_DS_SHARE_IN_BLEND percent (pipelined only)")
 a = ap.parse_args()
 w, h, kind, cam, intensity, ao_format, _ = WORKLOADS[a.workload]
 B = a.batch or max(1, (3840 * 2160 * 16) // (w * h))
@@ -27,6 +28,8 @@ out = [torch.empty((h, w), dtype=torch.uint8 if ao_format == _lib.AO_R8 else tor
 ao = AmbientOcclusion(w, h, num_levels=4, ao_format=ao_format, max_batch=B, near_clip=cam.near, far_clip=cam.far,
                       projection00=cam.proj00(w, h), reversed_z=cam.reversed_z, pipelined=a.pipeline)
 ao.intensity = intensity
+if a.ds_share:
+    ao.debug_set(_lib.DEBUG_DS_SHARE_IN_BLEND, a.ds_share)
 dp, op = [t.data_ptr() for t in dd], [t.data_ptr() for t in out]
 st = torch.cuda.current_stream(dev).cuda_stream
 def step():
@@ -52,5 +55,5 @@ if a.check:
                    intensity=intensity, ao_format=ao_format)
     want = O.run(frames[0], s, nthreads=os.cpu_count(), result_only=True)["result"]
     res["ok"] = bool(np.array_equal(out[0].cpu().numpy().view(want.dtype), want))
-res["tag"] = a.tag or os.path.basename(os.environ.get("MEAO_LIB_PATH", "product"))
+res["tag"] = (a.tag or os.path.basename(os.environ.get("MEAO_LIB_PATH", "product"))) + (f"+share{a.ds_share}" if a.ds_share else "")
 print(json.dumps(res), flush=True)

@@ -561,3 +561,38 @@ def test_hostile_frames_mask_in_direct_and_pipelined_calls(oracle):
             assert ao.hostile_frames() == want_mask, k
     finally:
         ao.close()
+
+
+@pytest.mark.parametrize("share", [15, 30, 100])
+@pytest.mark.parametrize("w,h,batch", [(512, 256, 2), (1280, 720, 3), (644, 364, 2)])
+def test_carried_downsample_split_between_blend_and_last_kernel(oracle, share, w, h, batch):
+    """MEAO_DEBUG_DS_SHARE_IN_BLEND: part of the next batch's downsample tiles ride in the L2 -> L1 blend launch, the
+    rest in the last kernel; three pipelined steps, every buffer of every frame (one hostile) against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = H.settings(oracle, w, h)
+    seqs = [[synth.make("S2", w, h, seed=900 + 10 * k + f) for f in range(batch)] for k in range(3)]
+    seqs[1][0] = H.hostile_frame(w, h, 55, density=0.002)
+    dd = [[torch.from_numpy(f).to(dev) for f in b] for b in seqs]
+    out = [[torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in b] for b in seqs]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_SHARE_IN_BLEND: share})
+    try:
+        ao.set_profiling(True)
+        for k in range(3):
+            if k + 1 < 3:
+                ao.prefetch_device([t.data_ptr() for t in dd[k + 1]])
+            ao.execute_device([t.data_ptr() for t in dd[k]], [t.data_ptr() for t in out[k]], st)
+            torch.cuda.synchronize(dev)
+            for f in range(batch):
+                want = oracle.run(seqs[k][f], s)
+                ok, bad = H.nan_aware_equal(out[k][f].cpu().numpy(), want["result"])
+                assert ok, (k, f, int(bad.sum()))
+                for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+                    ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
+                    assert ok, (H.NAMES[i], k, f, int(bad.sum()))
+            assert ao.hostile_frames() == (1 if k == 1 else 0)
+        ms, n = ao.pass_times_ms()
+        assert n == 3 and ms[0] > 0        # only the first step ran a stand-alone downsample pass
+    finally:
+        ao.close()

@@ -168,6 +168,10 @@ def test_pool_calls_leave_the_current_device_alone_and_destroy_with_work_in_flig
     cfg.width, cfg.height, cfg.max_batch, cfg.launch_mode = w, h, 2, L.LAUNCH_GRAPH
     pool = C.c_void_p()
     L.check(lib.meao_pool_create(C.byref(cfg), (C.c_int32 * 2)(0, 0), 2, C.byref(pool)))
+    prm = L.Params()
+    lib.meao_default_params(C.byref(prm))
+    prm.near_clip, prm.far_clip, prm.proj00, prm.reversed_z = cam.near, cam.far, cam.proj00(w, h), 1 if cam.reversed_z else 0
+    L.check(lib.meao_pool_set_params(pool, C.byref(prm)))
     dp, op = (C.c_void_p * n)(*[t.data_ptr() for t in dd]), (C.c_void_p * n)(*[t.data_ptr() for t in out])
     for _ in range(3):       # capture, then replays in flight
         L.check(lib.meao_pool_execute_batch(pool, n, dp, L.MEM_DEVICE, op, L.MEM_DEVICE))

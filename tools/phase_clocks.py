@@ -21,7 +21,7 @@ ap.add_argument("--pipeline", action="store_true")
 a = ap.parse_args()
 lib = _lib.load()
 read = lib.meao_x_phase_clocks            # AttributeError: not a -DMEAO_X_PHASE_CLOCKS=1 build
-read.restype, read.argtypes = C.c_int, [C.POINTER(C.c_uint64 * 32)]
+read.restype, read.argtypes = C.c_int, [C.POINTER(C.c_uint64 * 64)]
 w, h, kind, cam, intensity, ao_format, _ = WORKLOADS[a.workload]
 B = default_batch(w, h)
 dev = torch.device("cuda", 0)
@@ -41,7 +41,7 @@ t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.08:
     for _ in range(8): step()
     torch.cuda.synchronize()
-buf = (C.c_uint64 * 32)()
+buf = (C.c_uint64 * 64)()
 assert read(C.byref(buf)) == 0            # clear
 ao.set_profiling(True)
 for _ in range(a.steps): step()
@@ -50,12 +50,14 @@ assert read(C.byref(buf)) == 0
 ms, n = ao.pass_times_ms()
 names = ["0 window load+fill", "1 barrier", "2 H-blur", "3 barrier", "4 V-blur", "5 barrier(+carried loads)", "6 bilateral pass 0", "7 bilateral pass 1"]
 res = {"workload": a.workload, "pipeline": a.pipeline, "pass_us": {nm: round(ms[k] * 1e3, 1) for k, nm in enumerate(_lib.PASS_NAMES) if ms[k] > 0}}
-tot = 0.0
-for p, nm in enumerate(names):
-    cnt = buf[16 + p]
-    if cnt:
-        us = buf[p] / cnt / 100.0
-        tot += us
-        res[nm] = {"us_per_wave": round(us, 3), "waves": int(cnt)}
-res["sum_us_per_wave (all upsample passes pooled)"] = round(tot, 3)
+for base, label in ((0, "full_resolution_pass"), (8, "blend_passes")):
+    tot, tab = 0.0, {}
+    for p, nm in enumerate(names):
+        cnt = buf[32 + base + p]
+        if cnt:
+            us = buf[base + p] / cnt / 100.0
+            tot += us
+            tab[nm] = {"us_per_wave": round(us, 3), "waves": int(cnt)}
+    tab["sum_us_per_wave"] = round(tot, 3)
+    res[label] = tab
 print(json.dumps(res, indent=1))

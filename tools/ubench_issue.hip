@@ -380,59 +380,121 @@ __global__ __launch_bounds__(256) void k_rcp_waves_next_to_fma_waves(float *out,
 // The bilateral phase of the upsample kernels as the compiler emits it, per hi-res texel: four weights
 // K / (|hd - d| + tol) as v_sub, v_add |.|, v_rcp, v_mul, 2 v_fma (K = 1: 3 after the rcp), the two sums, the exact
 // quotient (v_rcp + 2 v_fma + v_mul + 2 v_fma), the UNORM8 encode; two independent texels per round: 84 instructions.
+// MODE 0: every weight finished before the next one starts (source order); 1: the four v_rcp_f32 of a texel issued
+// back to back (does the transcendental pipe like batches?); 2: the four v_rcp of BOTH texels back to back;
+// 3: no correction steps (raw rcp * K, raw rcp * sum: what an approximate-then-verify scheme would issue; 66 instructions)
+template <int MODE>
+__device__ __forceinline__ void bilateral_two_texels(const float (&hd)[2], float (&d)[8], const float (&ao)[8], float (&res)[2])
+{
+    const float tol = 1e-12f, nine = 9.0f, three = 3.0f, one = 1.0f;
+    float x[8], r[8], w[8];
+    auto arg = [&](int t, int k) {
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(x[4 * t + k]) : "v"(hd[t]), "v"(d[4 * t + k]));
+        asm volatile("v_add_f32 %0, |%1|, %2" : "=v"(x[4 * t + k]) : "v"(x[4 * t + k]), "v"(tol));
+    };
+    auto rcp = [&](int t, int k) { asm volatile("v_rcp_f32 %0, %1" : "=v"(r[4 * t + k]) : "v"(x[4 * t + k])); };
+    auto fin = [&](int t, int k) {
+        const int i = 4 * t + k;
+        float q, e;
+        if (MODE == 3) {
+            if (k == 2) { w[i] = r[i]; return; }
+            const float K = k == 0 ? nine : three;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w[i]) : "v"(K), "v"(r[i]));
+            return;
+        }
+        if (k == 2) {
+            asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(x[i]), "v"(r[i]), "v"(one));
+            asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(w[i]) : "v"(e), "v"(r[i]));
+        } else {
+            const float K = k == 0 ? nine : three;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(K), "v"(r[i]));
+            asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(x[i]), "v"(q), "v"(K));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(w[i]) : "v"(e), "v"(r[i]), "v"(q));
+        }
+    };
+    auto tail = [&](int t) {
+        float total, sum, rr, e, q;
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(total) : "v"(w[4 * t]), "v"(w[4 * t + 1]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(w[4 * t + 2]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(w[4 * t + 3]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(one));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(sum) : "v"(ao[4 * t]), "v"(w[4 * t]));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 1]), "v"(w[4 * t + 1]));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 2]), "v"(w[4 * t + 2]));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 3]), "v"(w[4 * t + 3]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(one));
+        asm volatile("v_rcp_f32 %0, %1" : "=v"(rr) : "v"(total));
+        if (MODE == 3) {
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(sum), "v"(rr));
+        } else {
+            asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(total), "v"(rr), "v"(one));
+            asm volatile("v_fma_f32 %0, %1, %0, %0" : "+v"(rr) : "v"(e));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(sum), "v"(rr));
+            asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(total), "v"(q), "v"(sum));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(q) : "v"(e), "v"(rr));
+        }
+        asm volatile("v_mul_f32_e64 %0, %0, %1 clamp" : "+v"(q) : "v"(one));
+        asm volatile("v_mul_f32 %0, 0x437f0000, %0" : "+v"(q));
+        asm volatile("v_add_f32 %0, %0, 0.5" : "+v"(q));
+        asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(q));
+        res[t] = q;
+        d[4 * t] = q;        // loop-carried: the next round's first tap depends on this one (no hoisting)
+    };
+#define EACH_T _Pragma("unroll") for (int t = 0; t < 2; ++t)
+#define EACH_K _Pragma("unroll") for (int k = 0; k < 4; ++k)
+    if (MODE == 0) {                    // texel after texel, weight after weight
+        EACH_T { EACH_K { arg(t, k); rcp(t, k); fin(t, k); } tail(t); }
+    } else if (MODE == 1) {             // per texel: 4 args, 4 rcp back to back, 4 corrections
+        EACH_T { EACH_K arg(t, k); EACH_K rcp(t, k); EACH_K fin(t, k); tail(t); }
+    } else if (MODE == 2 || MODE == 3) {  // both texels: 8 args, 8 rcp back to back, 8 corrections, tails
+        EACH_T EACH_K arg(t, k);
+        EACH_T EACH_K rcp(t, k);
+        EACH_T EACH_K fin(t, k);
+        EACH_T tail(t);
+    }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void k_bilateral_mix(float *out, Stamp *stamps, int iters, float b, float c)
 {
     float hd[2], d[8], ao[8], res[2];
     for (int i = 0; i < 8; ++i) { d[i] = threadIdx.x * 0.001f + i; ao[i] = 0.5f + 0.01f * i; }
     hd[0] = b; hd[1] = c; res[0] = res[1] = 0.0f;
-    const float tol = 1e-12f, nine = 9.0f, three = 3.0f, one = 1.0f;
+    PROLOGUE
+    for (int it = 0; it < iters; ++it) bilateral_two_texels<MODE>(hd, d, ao, res);
+    EPILOGUE
+    out[blockIdx.x * 256 + threadIdx.x] = res[0] + res[1];
+}
+
+// ---- round 3: v_fma_mix_f32 (an f16 source widened inside the FMA: samples could stay f16 in LDS) ------------
+KERNEL_F32(k_fma_mix_lo, "v_fma_mix_f32 %0, %1, %0, %2 op_sel_hi:[1,0,0]")
+KERNEL_F32(k_fma_mix_hi, "v_fma_mix_f32 %0, %1, %0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]")
+
+// the render pair mix with both v_fma_f32 of a pair replaced by v_fma_mix_f32 on the two halves of one packed f16 pair
+__global__ __launch_bounds__(256) void k_render_mix_fma_mix(float *out, Stamp *stamps, int iters, float b, float c)
+{
+    float s[16], ir[4], acc[4];
+    for (int i = 0; i < 16; ++i) s[i] = threadIdx.x * 0.001f + i;
+    for (int i = 0; i < 4; ++i) { ir[i] = b + i * 1e-3f; acc[i] = 0.0f; }
+    const float one = 1.0f;
     PROLOGUE
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float x, r, q, e;
-                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(x) : "v"(hd[t]), "v"(d[4 * t + k]));
-                asm volatile("v_add_f32 %0, |%1|, %2" : "=v"(x) : "v"(x), "v"(tol));
-                asm volatile("v_rcp_f32 %0, %1" : "=v"(r) : "v"(x));
-                if (k == 2) {
-                    asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(x), "v"(r), "v"(one));
-                    asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(w[k]) : "v"(e), "v"(r));
-                } else {
-                    const float K = k == 0 ? nine : three;
-                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(K), "v"(r));
-                    asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(x), "v"(q), "v"(K));
-                    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(w[k]) : "v"(e), "v"(r), "v"(q));
-                }
-            }
-            float total, sum, r, e, q;
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(total) : "v"(w[0]), "v"(w[1]));
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(w[2]));
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(w[3]));
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(total) : "v"(one));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(sum) : "v"(ao[4 * t]), "v"(w[0]));
-            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 1]), "v"(w[1]));
-            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 2]), "v"(w[2]));
-            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sum) : "v"(ao[4 * t + 3]), "v"(w[3]));
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(one));
-            asm volatile("v_rcp_f32 %0, %1" : "=v"(r) : "v"(total));
-            asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(total), "v"(r), "v"(one));
-            asm volatile("v_fma_f32 %0, %1, %0, %0" : "+v"(r) : "v"(e));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(sum), "v"(r));
-            asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(e) : "v"(total), "v"(q), "v"(sum));
-            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(q) : "v"(e), "v"(r));
-            asm volatile("v_mul_f32_e64 %0, %0, %1 clamp" : "+v"(q) : "v"(one));
-            asm volatile("v_mul_f32 %0, 0x437f0000, %0" : "+v"(q));
-            asm volatile("v_add_f32 %0, %0, 0.5" : "+v"(q));
-            asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(q));
-            res[t] = q;
-            d[4 * t] = q;        // loop-carried: the next round's first tap depends on this one (no hoisting)
+        for (int p = 0; p < 4; ++p) {
+            float d1, d2, p1, p2, u1, u2, sum;
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(s[4 * p]), "v"(ir[p]), "v"(c));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d2) : "v"(s[4 * p + 1]), "v"(ir[p]), "v"(c));
+            asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(p1) : "v"(d1), "v"(b));
+            asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(p2) : "v"(d2), "v"(b));
+            asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(u1) : "v"(d1), "v"(p2), "v"(one));
+            asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(u2) : "v"(d2), "v"(p1), "v"(one));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(sum) : "v"(u1), "v"(u2));
+            asm volatile("v_fma_f32 %0, -%1, %2, %3 clamp" : "=v"(acc[p]) : "v"(p1), "v"(p2), "v"(sum));
+            s[4 * p + 2] = acc[p];
         }
     }
     EPILOGUE
-    out[blockIdx.x * 256 + threadIdx.x] = res[0] + res[1];
+    out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3] + s[2] + s[6] + s[10] + s[14];
 }
 
 typedef void (*kfn)(float *, Stamp *, int, float, float);
@@ -485,7 +547,13 @@ int main(int argc, char **argv)
         {"1 v_rcp_f32 : 7 v_fma_f32 in every wave", k_rcp_1_in_8, 32},
         {"1 v_rcp_f32 : 3 v_fma_f32 in every wave", k_rcp_1_in_4, 32},
         {"v_rcp waves next to v_fma waves (both counted)", k_rcp_waves_next_to_fma_waves, 32},
-        {"bilateral-phase mix (2 texels: 84 instr, 10 rcp)", k_bilateral_mix, 84},
+        {"v_fma_mix_f32, f16 source (low half)", k_fma_mix_lo, 32},
+        {"v_fma_mix_f32, f16 source (high half)", k_fma_mix_hi, 32},
+        {"render pair mix with v_fma_mix_f32 (spread)", k_render_mix_fma_mix, 32},
+        {"bilateral-phase mix (2 texels: 84 instr, 10 rcp)", k_bilateral_mix<0>, 84},
+        {"bilateral mix, 4 rcp of a texel back to back", k_bilateral_mix<1>, 84},
+        {"bilateral mix, 8 rcp of both texels back to back", k_bilateral_mix<2>, 84},
+        {"bilateral mix without correction steps (66 instr)", k_bilateral_mix<3>, 66},
     };
     const char *filter = argc > 2 ? argv[2] : nullptr;    // only rows whose name contains this
     std::printf("%-48s %5s %10s %10s %9s %10s\n", "instruction", "w/SIMD", "cyc/instr", "clock MHz", "ms/launch", "cyc(wall)");
