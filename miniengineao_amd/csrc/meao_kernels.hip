@@ -51,14 +51,19 @@
 // of this block only (tests/build_variants.py builds variants next to the product library;
 // tests/test_variants_gpu.py runs a parity smoke through every variant library it finds).
 #ifndef MEAO_X_UPS_PERSISTENT
-#define MEAO_X_UPS_PERSISTENT 0 // full-resolution upsample (plain and fused): 1 = persistent workgroups (7 per CU) looping over (frame, tile);
-#endif                          // 2 = the same with the next tile's loads issued in front of the current tile's bilateral phase (plain pass only)
-#ifndef MEAO_X_UPS_RCP_GROUP
-#define MEAO_X_UPS_RCP_GROUP 0  // bilateral phase, exact-division bodies: 4 / 8 / 16 = the v_rcp_f32 of 1 / 2 / 4 texels issued back to back
-#endif                          // (the transcendental pipe pays ~3 cycles per isolated v_rcp_f32: tools/ubench_issue.hip "bilateral mix")
+#define MEAO_X_UPS_PERSISTENT 0 // full-resolution upsample pass as persistent workgroups (7 per CU) looping over (frame, tile), the next tile's
+#endif                          // window loads issued in front of the current tile's bilateral phase, its stores deferred into the next tile:
+                                // 2 = fixed stride, 3 = the seven workgroups of a CU draw their tiles from one atomic ticket counter.
+                                // Measured (profiles/r03_ab_persistent_*.jsonl, r03_wg_log_*.txt): 246 / 285 us against 201 us for the plain
+                                // launch -- the SIMDs issue oldest-wave-first, which gives the hardware-dispatched launch a free software
+                                // pipeline (the furthest-along tile goes first); persistent waves never age relative to each other.
+#ifndef MEAO_X_UPS_PRIO_SCHEME
+#define MEAO_X_UPS_PRIO_SCHEME 0      // s_setprio per upsample phase {fill, H-blur, V-blur, bilateral}: 0 = {3, 0, 0, 0} (product), 1 = {3, 1, 2, 3}
+#endif                                // (emulates "furthest-along first" for persistent workgroups: 246 -> 220 us; plain launch: 201 -> 205 us)
+constexpr int kUpsPrio[2][4] = {{3, 0, 0, 0}, {3, 1, 2, 3}};
 #ifndef MEAO_X_PHASE_CLOCKS
-#define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py)
-#endif
+#define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py),
+#endif                          // persistent launches log start / end / CU of every workgroup (tools/wg_log.py)
 
 #if MEAO_X_PHASE_CLOCKS
 // [phase] summed 100 MHz ticks and [32 + phase] wave counts, per upsample-tile phase (0..7 full-resolution pass,
@@ -69,6 +74,12 @@ extern "C" __attribute__((visibility("default"))) int meao_x_phase_clocks(unsign
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_clocks), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
     static const unsigned long long zero[64] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clocks), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+// per workgroup of the last persistent launch: start, end (100 MHz), HW_ID, XCC_ID
+__device__ unsigned long long g_wg_log[4096 * 4];
+extern "C" __attribute__((visibility("default"))) int meao_x_wg_log(unsigned long long *out, int workgroups)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_log), sizeof(unsigned long long) * 4 * (workgroups < 4096 ? workgroups : 4096)) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1175,6 +1186,39 @@ __device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, 
     }
 }
 
+// The output texels of a tile, held in registers: a persistent workgroup stores them a phase into its NEXT tile.  On this
+// part stores count in vmcnt like loads and the compiler waits with vmcnt(0) for anything carried around a loop: stores
+// issued at the end of a tile would put their round trip to HBM in front of the next tile's first load wait.
+template <int AOFMT, int TILE_H>
+struct UpsResults {
+    typedef typename std::conditional<sizeof(typename AoTexel<AOFMT>::type4) == 4, uint32_t, uint64_t>::type bits_t;   // four texels
+    bits_t r4[TILE_H / 32][2];
+};
+
+template <int AOFMT, bool FINAL, int TILE_H>
+__device__ __forceinline__ void ups_store_results(const UpsampleArgs &a, int tile, int frame, const UpsResults<AOFMT, TILE_H> &R)
+{
+    typedef AoTexel<AOFMT> AO;
+    typedef typename AO::type ao_t;
+    const int tid = thread_index_opaque();
+    const int HX0 = (tile % a.tiles_x) * kUpsTileW, HY0 = (tile / a.tiles_x) * TILE_H;
+    const int hx0 = HX0 + 4 * (tid & 15);
+    if (hx0 >= a.hw) return;
+    ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame]) : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
+#pragma unroll
+    for (int pass = 0; pass < TILE_H / 32; ++pass)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int hy = HY0 + 2 * ((tid >> 4) + 16 * pass) + f;
+            if (hy < a.hh) {
+                typename AO::type4 *o = reinterpret_cast<typename AO::type4 *>(dst + static_cast<size_t>(hy) * a.hw + hx0);
+                const typename AO::type4 v = __builtin_bit_cast(typename AO::type4, R.r4[pass][f]);
+                if constexpr (FINAL) __builtin_nontemporal_store(v, o);
+                else *o = v;
+            }
+        }
+}
+
 // NESTED: the LoResAO1 taps (s_ao) were already produced in LDS by blend_window_into_lds (the
 // previous pass of the chain evaluated inside this workgroup) instead of being read from global memory.
 // Places inside an upsample tile where every thread of the workgroup can put unrelated global loads in flight:
@@ -1182,16 +1226,19 @@ __device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, 
 // before_bilateral() the hoisted hi-res operands have landed too: nothing in the bilateral phase waits on vmcnt
 struct NoHook {
     static constexpr bool kBeforeBilateral = false;
+    static constexpr bool kGroupReciprocals = true;      // bilateral_upsample_grouped
     __device__ __forceinline__ void after_prefetch() const {}
     __device__ __forceinline__ void before_bilateral() const {}
 };
 
 // PRELOADED (persistent kernels): `pre` holds the window loads of this -- interior -- tile, issued a tile ago
-// (ups_issue_interior_loads<.., WINDOW_ONLY>); its hi-res operands are loaded here, at the top of the tile, as always.
+// (ups_issue_interior_loads<.., WINDOW_ONLY>); its hi-res operands are loaded here, at the top of the tile, as always; its
+// output texels go to `deferred` instead of memory (ups_store_results, called by the next tile's hook).
 template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL),
           bool PRELOADED = false>
 __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook(),
-                                              const UpsLoads<AOFMT, FINAL, TILE_H> *pre = nullptr)
+                                              const UpsLoads<AOFMT, FINAL, TILE_H> *pre = nullptr,
+                                              UpsResults<AOFMT, TILE_H> *deferred = nullptr)
 {
     const int tid = thread_index_opaque();
     typedef AoTexel<AOFMT> AO;
@@ -1231,7 +1278,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
 
     PhaseClock clk(FINAL ? 0 : 8);
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][0]);
     // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
     // are issued first, so that their latency hides behind the prefetch and blur phases.
     constexpr int kPasses = kTileH / 32;
@@ -1259,6 +1306,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         if constexpr (!PRELOADED && !NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H>(a, tile, frame, L);
         auto &wd = L.wd;
         auto &wa = L.wa;
+        if constexpr (PRELOADED) asm volatile("; MEAO_MARK preloaded_fill_begin");
 #pragma unroll
         for (int round = 0; round < kRounds; ++round) {
             // an unconditional use: the compiler would otherwise sink the loads of the partial last round into
@@ -1337,7 +1385,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     clk.mark(0);         // 0: window loaded, converted, stored to LDS
     __syncthreads();
     clk.mark(1);         // 1: barrier
-    __builtin_amdgcn_s_setprio(0);       // (kept through the blur phases: +10 % on the pass)
+    __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][1]);       // (3 kept through the blur phases: +10 % on the pass)
     hook.after_prefetch();
 
     // ---- BlurHorizontally: runs of 4 outputs; output (r, c) is centred on raw column c+2.
@@ -1373,6 +1421,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     clk.mark(2);         // 2: H-blur
     __syncthreads();
     clk.mark(3);         // 3: barrier
+    if constexpr (MEAO_X_UPS_PRIO_SCHEME != 0) __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][2]);
 
     // ---- BlurVertically: runs of T::kVRun outputs; output (r, c) is centred on H-blurred row
     // r+2; depths come from the same virtual column (DepthCache[... + 2], UPS:141-146).  Rows
@@ -1412,6 +1461,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     }
 
     // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
+    if constexpr (kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][3] != 0) __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][3]);
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
                                    : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
     const bool vec_ok = a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
@@ -1471,9 +1521,11 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 }
             }
             ao_t res[4];
-            if constexpr (MEAO_X_UPS_RCP_GROUP >= 4 && DIV == DIV_EXACT_RCP) {
-                constexpr int kGroup = MEAO_X_UPS_RCP_GROUP >= 4 ? MEAO_X_UPS_RCP_GROUP / 4 : 1;   // texels whose reciprocals are issued together
-                static_assert(kGroup == 1 || kGroup == 2 || kGroup == 4, "MEAO_X_UPS_RCP_GROUP is 4, 8 or 16");
+            if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
+                // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than
+                // one that follows another (tools/ubench_issue.hip "bilateral mix": 3.81 -> 3.55 cycles per instruction).  A/B:
+                // L2->L1 65 -> 58.5 us, L1->L0 202.5 -> 199.2 us; two texels per group: the same (profiles/r03_ab_rcp_group*.jsonl).
+                constexpr int kGroup = 1;             // texels whose reciprocals are issued together
 #pragma unroll
                 for (int e0 = 0; e0 < 4; e0 += kGroup) {
                     float gd[kGroup][4], ga[kGroup][4], ghd[kGroup], gha[kGroup], gout[kGroup];
@@ -1515,7 +1567,13 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             if (vec_ok) {
                 typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
                 // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
-                if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
+                if constexpr (PRELOADED) {
+                    // packed NOW and pinned: left alone the compiler carries the four texels around the loop unpacked
+                    typename UpsResults<AOFMT, TILE_H>::bits_t packed = __builtin_bit_cast(typename UpsResults<AOFMT, TILE_H>::bits_t, r4);
+                    asm volatile("" : "+v"(packed));
+                    deferred->r4[pass][f] = packed;
+                }
+                else if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
                 else *reinterpret_cast<typename AO::type4 *>(o) = r4;
             } else {
 #pragma unroll
@@ -1640,8 +1698,17 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
             dk[k] = r_dep[(ly - ry0) * kNestRawW + (lx - rx0)];
         }
         const size_t at = static_cast<size_t>(Y) * hw + X;
-        const float v = bilateral_upsample<DIV>(hoist_d[j], AO::decode(hoist_a[j]), dk[0], dk[1], dk[2], dk[3], ak[0], ak[1],
-                                                ak[2], ak[3], bilateral_k);
+        float v;
+        if constexpr (DIV == DIV_EXACT_RCP) {       // the four weight reciprocals back to back (see upsample_tile)
+            const float ghd[1] = {hoist_d[j]}, gha[1] = {AO::decode(hoist_a[j])};
+            const float gd[1][4] = {{dk[0], dk[1], dk[2], dk[3]}}, ga[1][4] = {{ak[0], ak[1], ak[2], ak[3]}};
+            float gout[1];
+            bilateral_upsample_grouped<1>(ghd, gha, gd, ga, bilateral_k, gout);
+            v = gout[0];
+        } else {
+            v = bilateral_upsample<DIV>(hoist_d[j], AO::decode(hoist_a[j]), dk[0], dk[1], dk[2], dk[3], ak[0], ak[1], ak[2], ak[3],
+                                        bilateral_k);
+        }
         const ao_t q = AO::template encode<RTNE>(v);
         out[wr * out_pitch + wc] = AO::decode(q);
         if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) dst[at] = q;
@@ -1756,6 +1823,7 @@ __global__ __launch_bounds__(kThreads) void upsample_three_level_kernel(const Up
 // profiles/r02_ab_v15p..v17p_split_ds*.jsonl).
 struct IssueCarriedLoads {
     static constexpr bool kBeforeBilateral = true;
+    static constexpr bool kGroupReciprocals = false;     // the kernels that carry a downsample tile are short of registers: A/B +3 %
     const DownsampleArgs &d;
     float (&v)[kDsTileH / kDsRowsPerPass][4];
     bool mine;
@@ -1828,11 +1896,21 @@ __global__ __launch_bounds__(kThreads) void upsample_blend_with_next_downsample_
 template <int AOFMT, bool FINAL, int TILE_H>
 struct IssueNextTileLoads {
     static constexpr bool kBeforeBilateral = true;
+    static constexpr bool kGroupReciprocals = true;
     const UpsampleArgs &a;
     UpsLoads<AOFMT, FINAL, TILE_H> &next;
     bool active;
     int tile, frame;
-    __device__ __forceinline__ void after_prefetch() const {}
+    const UpsResults<AOFMT, TILE_H> &pending;        // the previous tile's output, stored once this tile's window is in LDS
+    bool has_pending;
+    int ptile, pframe;
+    uint32_t *ticket_counter;                         // MEAO_X_UPS_PERSISTENT == 3: thread 0 draws the ticket of the tile after next here ...
+    int &drawn;                                       // ... and reads it a whole tile later (the atomic's round trip stays off the path)
+    __device__ __forceinline__ void after_prefetch() const
+    {
+        if (has_pending) ups_store_results<AOFMT, FINAL, TILE_H>(a, ptile, pframe, pending);
+        if (ticket_counter && threadIdx.x == 0) drawn = static_cast<int>(atomicAdd(ticket_counter, 1u));
+    }
     __device__ __forceinline__ void before_bilateral() const
     {
         if (active) ups_issue_interior_loads<AOFMT, FINAL, TILE_H, true>(a, tile, frame, next);
@@ -1844,7 +1922,9 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_persistent_kernel(
 {
     __shared__ __attribute__((aligned(16))) float smem[UpsLds<true>::kFloats];
     const int per_frame = a.tiles_x * a.tiles_y, total = per_frame * frames;
-#if MEAO_X_UPS_PERSISTENT == 2
+#if MEAO_X_PHASE_CLOCKS
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int kTileH = ups_tile_h(true);
     typedef UpsLoads<AOFMT, true, kTileH> Loads;
     // frames whose downsample pass saw hostile depth take the IEEE-division bodies (no prefetching across them)
@@ -1856,60 +1936,114 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_persistent_kernel(
     auto interior = [&](int tile, int frame) {
         return ups_tile_is_interior<true, kTileH>(a, tile) && !(hostile_mask >> frame & 1u);
     };
+#if MEAO_X_UPS_PERSISTENT == 3
+    // Tickets.  The SIMDs issue oldest-wave-first: with a fixed share per workgroup the seven workgroups of a CU finish
+    // one after the other (100 .. 254 us in a 250 us launch, tools/wg_log.py) and the CU spends the second half of the
+    // launch half empty.  Workgroups are dealt to the CUs round-robin (blockIdx mod the number of CUs: measured), so the
+    // seven workgroups {c, c + groups, ...} share CU c: they draw the tiles c, c + groups, c + 2 groups, ... from one counter
+    // (7 clients per counter: no contention) until the CU's share is gone, whoever gets there first.
+    // Thread 0 draws the ticket of the tile after next behind this tile's first barrier and publishes it in LDS before the
+    // end-of-tile barrier.  The last workgroup to finish zeroes the counters for the next launch.
+    __shared__ int s_ticket;
+    const int groups = gridDim.x / 7, group = blockIdx.x % groups;        // gridDim.x = 7 x CUs (launcher)
+    uint32_t *const counter = a.tickets + group;
+    auto id_of = [&](int ticket) { return ticket < 0 ? total : group + groups * ticket; };     // groups % 8 == 0: the XCD of an id is the group's
+    if (threadIdx.x == 0) s_ticket = static_cast<int>(atomicAdd(counter, 1u));
+    __syncthreads();
+    int id = id_of(__builtin_amdgcn_readfirstlane(s_ticket));        // uniform: keep everything derived from it in SGPRs
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = static_cast<int>(atomicAdd(counter, 1u));
+    __syncthreads();
+    int nid = id_of(__builtin_amdgcn_readfirstlane(s_ticket));
+    __syncthreads();
+#else
+    int id = blockIdx.x, nid = id + gridDim.x;
+#endif
     Loads cur, nxt;
-    int id = blockIdx.x;
-    if (id >= total) return;
-    int g = xcd_contiguous(id, total), frame = g / per_frame, tile = g - frame * per_frame;
-    bool fast = interior(tile, frame);
-    if (fast) ups_issue_interior_loads<AOFMT, true, kTileH, true>(a, tile, frame, cur);
-    for (;;) {
-        const int nid = id + gridDim.x;
+    UpsResults<AOFMT, kTileH> pend, out;      // `out` is written at the end of a tile, `pend` stored (and dead) early in the next one
+    bool fast = false, has_pending = false;
+    int tile = 0, frame = 0, ptile = 0, pframe = 0;
+    // (a frame-major id -> tile map and a staggered start of the seven workgroups of a CU changed nothing:
+    // profiles/r03_ab_persistent_map_stagger.jsonl)
+    auto decode = [&](int i, int &t, int &f) {
+        const int g = xcd_contiguous(i, total);
+        f = g / per_frame;
+        t = g - f * per_frame;
+    };
+    if (id < total) {
+        decode(id, tile, frame);
+        fast = interior(tile, frame);
+        if (fast) ups_issue_interior_loads<AOFMT, true, kTileH, true>(a, tile, frame, cur);
+    }
+    [[maybe_unused]] int wg_tiles = 0;
+    PhaseClock loop_clk(16);        // 16: from the end-of-tile barrier to the call of the next tile; 17: the tile; 18: its end-of-tile barrier
+    while (id < total) {
+#if MEAO_X_UPS_PERSISTENT == 3
+        int drawn = -1;                                                      // -1: nothing drawn (the pool is known to be empty)
+        uint32_t *const draw_from = nid < total ? counter : nullptr;         // stop drawing once a ticket was out of range
+#else
+        int drawn = -1;
+        uint32_t *const draw_from = nullptr;
+#endif
         int ntile = 0, nframe = 0;
         bool nfast = false;
         if (nid < total) {
-            const int ng = xcd_contiguous(nid, total);
-            nframe = ng / per_frame;
-            ntile = ng - nframe * per_frame;
+            decode(nid, ntile, nframe);
             nfast = interior(ntile, nframe);
         }
+        loop_clk.mark(0);
+        ++wg_tiles;
         if (fast) {
-            const IssueNextTileLoads<AOFMT, true, kTileH> hook = {a, nxt, nfast, ntile, nframe};
-            upsample_tile<AOFMT, RTNE, true, DIV, false, IssueNextTileLoads<AOFMT, true, kTileH>, kTileH, true>(a, smem, tile, frame, hook, &cur);
+            const IssueNextTileLoads<AOFMT, true, kTileH> hook = {a, nxt, nfast, ntile, nframe, pend, has_pending, ptile, pframe, draw_from, drawn};
+            upsample_tile<AOFMT, RTNE, true, DIV, false, IssueNextTileLoads<AOFMT, true, kTileH>, kTileH, true>(a, smem, tile, frame, hook, &cur, &out);
+            pend = out;
+            has_pending = true; ptile = tile; pframe = frame;
         } else {
+            if (has_pending) ups_store_results<AOFMT, true, kTileH>(a, ptile, pframe, pend);
+            has_pending = false;
+            if (draw_from && threadIdx.x == 0) drawn = static_cast<int>(atomicAdd(draw_from, 1u));
             if (hostile_mask >> frame & 1u) upsample_tile<AOFMT, RTNE, true, DIV_IEEE>(a, smem, tile, frame);
             else upsample_tile<AOFMT, RTNE, true, DIV>(a, smem, tile, frame);
             if (nfast) ups_issue_interior_loads<AOFMT, true, kTileH, true>(a, ntile, nframe, nxt);
         }
-        if (nid >= total) break;
+#if MEAO_X_UPS_PERSISTENT == 3
+        if (threadIdx.x == 0) s_ticket = drawn;
+#endif
+        loop_clk.mark(1);
+        __syncthreads();       // the next tile's fill overwrites what slower waves still read
+        loop_clk.mark(2);
+#if MEAO_X_UPS_PERSISTENT == 3
+        const int nnid = id_of(__builtin_amdgcn_readfirstlane(s_ticket));
+        __syncthreads();       // ... and thread 0 overwrites s_ticket at the top of the next tile
+#endif
         cur = nxt;
         id = nid; tile = ntile; frame = nframe; fast = nfast;
-        __syncthreads();       // the next tile's fill overwrites what slower waves still read
-    }
+#if MEAO_X_UPS_PERSISTENT == 3
+        nid = nnid;
 #else
-    for (int id = blockIdx.x; id < total; id += gridDim.x) {
-        const int g = xcd_contiguous(id, total), frame = g / per_frame, tile = g - frame * per_frame;
-        upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, tile, frame);
-        __syncthreads();       // the next tile's fill overwrites what slower waves still read
+        nid = id + gridDim.x;
+#endif
+    }
+    if (has_pending) ups_store_results<AOFMT, true, kTileH>(a, ptile, pframe, pend);
+#if MEAO_X_PHASE_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_wg_log[blockIdx.x * 4 + 0] = wg_t0;
+        g_wg_log[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        g_wg_log[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
+        g_wg_log[blockIdx.x * 4 + 3] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 0xFu) |     // HW_REG_XCC_ID
+                                       (static_cast<unsigned long long>(wg_tiles) << 8);
     }
 #endif
-}
-
-template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsample_persistent_kernel(const UpsampleArgs a,
-                                                                                                  const DownsampleArgs d, int frames)
-{
-    __shared__ __attribute__((aligned(16))) float smem[UpsLds<true>::kFloats];
-    const int per_frame = a.tiles_x * a.tiles_y, total = per_frame * frames;
-    const int ds_tiles = d.tiles_x * d.tiles_y;       // the launcher guarantees ds_tiles <= per_frame, d.frames <= frames, 16-byte f32 loads
-    for (int id = blockIdx.x; id < total; id += gridDim.x) {
-        const int g = xcd_contiguous(id, total), frame = g / per_frame, tile = g - frame * per_frame;
-        const bool mine = tile >= d.tile_begin && tile < ds_tiles && frame < d.frames;
-        float v[kDsTileH / kDsRowsPerPass][4];
-        const IssueCarriedLoads issue = {d, v, mine, tile, frame};
-        upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, tile, frame, issue);
-        if (mine) downsample_tile_finish<RTNE, true, DIV>(d, tile, frame, v);
-        __syncthreads();
+#if MEAO_X_UPS_PERSISTENT == 3
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(a.tickets + kTicketWords - 1, 1u) == gridDim.x - 1) {        // every other workgroup has drawn its last ticket
+            for (int k = 0; k < groups; ++k) a.tickets[k] = 0;
+            a.tickets[kTicketWords - 1] = 0;
+            __threadfence();
+        }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2332,7 +2466,7 @@ hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hi
 }
 
 // workgroups of a persistent launch: 7 per CU (what the 22.8 KB of LDS per workgroup allow), a multiple of 8
-static int persistent_grid(int total)
+[[maybe_unused]] static int persistent_grid(int total)
 {
     static int cus[64] = {};
     int dev = 0;
@@ -2350,11 +2484,13 @@ static int persistent_grid(int total)
 template <int AOFMT, bool RTNE, int DIV>
 static void launch_upsample_t(const UpsampleArgs &a, bool final_pass, dim3 grid, hipStream_t s)
 {
-    if (MEAO_X_UPS_PERSISTENT && final_pass && a.tile_h != kUpsTileHSmall) {
+#if MEAO_X_UPS_PERSISTENT
+    if (final_pass && a.tile_h != kUpsTileHSmall) {
         const int frames = static_cast<int>(grid.z), total = a.tiles_x * a.tiles_y * frames;
         upsample_final_persistent_kernel<AOFMT, RTNE, DIV><<<dim3(persistent_grid(total)), dim3(kThreads), 0, s>>>(a, frames);
         return;
     }
+#endif
     if (final_pass && a.tile_h == kUpsTileHSmall) upsample_final_small_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else if (final_pass) upsample_kernel<AOFMT, RTNE, true, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else upsample_kernel<AOFMT, RTNE, false, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
@@ -2429,13 +2565,6 @@ hipError_t launch_upsample_three_level(const UpsampleArgs &outer, const Upsample
 template <int AOFMT, bool RTNE, int DIV>
 static void launch_upsample_fused_t(const UpsampleArgs &a, const DownsampleArgs &d, dim3 grid, hipStream_t s)
 {
-    const int frames = static_cast<int>(grid.z);
-    if (MEAO_X_UPS_PERSISTENT == 1 && d.vec_ok != 0 && d.depth_format == MEAO_DEPTH_F32 && d.tiles_x * d.tiles_y <= a.tiles_x * a.tiles_y &&
-        d.frames <= frames) {
-        const int total = a.tiles_x * a.tiles_y * frames;
-        upsample_final_with_next_downsample_persistent_kernel<AOFMT, RTNE, DIV><<<dim3(persistent_grid(total)), dim3(kThreads), 0, s>>>(a, d, frames);
-        return;
-    }
     upsample_final_with_next_downsample_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a, d);
 }
 
