@@ -71,6 +71,24 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out_pa
     return final
 
 
+# Experimental arms of meao_kernels.hip (MEAO_X_* switches) that are kept in the source: name -> -D flags
+VARIANTS = {
+    "persist2": ["-DMEAO_X_UPS_PERSISTENT=2"],
+    "persist3prio": ["-DMEAO_X_UPS_PERSISTENT=3", "-DMEAO_X_UPS_PRIO_SCHEME=1"],
+    "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],
+}
+
+
+def build_variants(names=None):
+    """Variant libraries miniengineao_amd/lib/variants/libmeao_<name>.so (MEAO_LIB_PATH selects one at run time)."""
+    from concurrent.futures import ThreadPoolExecutor
+    out_dir = os.path.join(LIB_DIR, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    todo = [(n, f) for n, f in VARIANTS.items() if names is None or n in names]
+    with ThreadPoolExecutor(4) as ex:
+        return list(ex.map(lambda nf: build_lib(force=True, extra_flags=nf[1], out_path=os.path.join(out_dir, f"libmeao_{nf[0]}.so")), todo))
+
+
 DEMO_PATH = os.path.join(LIB_DIR, "ao_host_demo")
 
 

@@ -754,6 +754,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     const int lw = L.lw, lh = L.lh;
     const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, frame);
 
+    PhaseClock clk(24);      // 24: window loaded, converted, in LDS; 25: barrier; 26..29: texel-loop iterations
     __builtin_amdgcn_s_setprio(3);
     // ---- stage the (64+32) x (32+32) window.  Window texel (vx,vy) (level coordinates, may
     // be outside the level) belongs to slice (vx&3, vy&3), slice texel (vx>>2, vy>>2); the
@@ -802,7 +803,9 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
             if (kEven || q < kQuads) *reinterpret_cast<float4v *>(&tile[qy * kRenLdsW + qx * 4]) = t;
         }
     }
+    clk.mark(0);
     __syncthreads();
+    clk.mark(1);
     __builtin_amdgcn_s_setprio(0);
 
     // ---- each lane: a texel pair (X, X+1) in each of the TILE_H / 8 iterations
@@ -838,6 +841,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
             }
         }
         hook.end(k);
+        clk.mark(2 + (k & 3));
     }
 }
 
@@ -1833,6 +1837,7 @@ struct IssueCarriedLoads {
     __device__ __forceinline__ void before_bilateral() const { if constexpr (kBeforeBilateral) issue(); }
 };
 
+
 // Upsample.main of this batch carrying the downsample pass of the NEXT batch (meao_prefetch_batch):
 // the final upsample is VALU-bound (five exact divides per texel) and leaves HBM idle, the
 // downsample is pure streaming with ~2 VALU ops per byte -- inside one kernel the streaming hides
@@ -1871,6 +1876,8 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsamp
     const IssueCarriedLoads issue = {d, v, mine, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.z)};
     upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z, issue);
     if (mine) downsample_tile_finish<RTNE, true, DIV>(d, blockIdx.x, blockIdx.z, v);
+    // (loading the carried tile behind the first barrier and finishing it in FRONT of the bilateral phase frees 10 VGPRs there
+    // and is 5 % slower: profiles/r03_ab_fused_ds_finished_before_bilateral.jsonl)
 }
 
 // Upsample.main_blendout L2 -> L1 carrying the first d.tile_end downsample tiles (per frame) of the NEXT batch: the

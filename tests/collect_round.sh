@@ -13,6 +13,8 @@ cp gpurun_out/fuzz_$T.log profiles/${T}_fuzz_gpu.log
 cp gpurun_out/pytest_gpu_$T.log profiles/${T}_pytest_gpu.log
 cp gpurun_out/ubench_issue_$T.txt profiles/${T}_ubench_issue.txt
 cp gpurun_out/ubench_lds_$T.txt profiles/${T}_ubench_lds.txt
+for f in pool2 pool3; do [ -f gpurun_out/bench_${T}_$f.log ] && grep '^{' gpurun_out/bench_${T}_$f.log > profiles/${T}_bench_4k_$f.json; done
+for f in plain pipelined; do [ -f gpurun_out/phase_clocks_${f}_$T.json ] && cp gpurun_out/phase_clocks_${f}_$T.json profiles/${T}_phase_clocks_$f.json; done
 [ -f gpurun_out/ubench_launch_$T.txt ] && cp gpurun_out/ubench_launch_$T.txt profiles/${T}_ubench_launch.txt
 python tests/pmc_summary.py gpurun_out/pmc_$T > profiles/${T}_pmc_summary.txt
 python tests/make_pmc_traffic.py gpurun_out/pmc_$T 4k $N > /dev/null

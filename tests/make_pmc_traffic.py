@@ -67,6 +67,7 @@ def main():
     except OSError:
         full = {}
     full[workload] = table
+    full["_tag"] = os.path.basename(os.path.normpath(root)).replace("pmc_", "")
     full["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tests/run_pmc.sh); see tests/make_pmc_traffic.py"
     json.dump(full, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(table, indent=1))
