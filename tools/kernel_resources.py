@@ -90,7 +90,11 @@ def render_loop_isa(asm: str) -> str:
     waits = [i for i, l in enumerate(body) if re.search(r"s_waitcnt lgkmcnt\(2\)", l)]
     out = []
     # ... that is not the first pair of a term (those also carry the term's v_pk_mul of invThickness * invDepth)
-    pick = next((k for k in range(4, len(waits) - 1) if not any("v_pk_mul" in l for l in body[waits[k]:waits[k + 1]])), None)
+    # and not the last one either (those add the term's sum and weighted accumulation): the segment with the fewest VALU instructions
+    def valu_count(k):
+        return sum(1 for l in body[waits[k]:waits[k + 1]] if l.strip().startswith("v_"))
+    cands = [k for k in range(4, len(waits) - 1) if not any("v_pk_mul" in l for l in body[waits[k]:waits[k + 1]])]
+    pick = min(cands, key=valu_count) if cands else None
     if pick is not None:
         a, b = waits[pick], waits[pick + 1]
         seg = [l.split(";")[0].rstrip() for l in body[a:b] if l.strip() and not l.strip().startswith((";", "."))]
