@@ -191,15 +191,16 @@ __device__ __forceinline__ uint32_t f32_to_unorm8(float x)
     return static_cast<uint32_t>(s);
 }
 
-// UNORM8 -> f32 == (float)n / 255.0f exactly: quotient estimate + one fused remainder step
-// (verified against IEEE division for all 256 inputs by tests and meao_selftest(2)).
+// UNORM8 -> f32 == (float)n / 255.0f exactly, in two operations behind the conversion: fma(n, c, n * c_lo) with c = RN(1/255)
+// and c_lo = RN(1/255 - c), i.e. n times a double-float 1/255 with one rounding at the end -- correctly rounded for every
+// n in 0..255 (checked exhaustively with exact rational arithmetic when the constants were chosen, on the device by
+// meao_selftest(2), and by tests/test_abi.py).  One operation less than quotient estimate + fused remainder step.
 __device__ __forceinline__ float unorm8_to_f32(uint32_t n)
 {
     const float fn = static_cast<float>(n);
-    const float r = 1.0f / 255.0f;       // folded at compile time
-    const float q = fn * r;
-    const float e = mad(-255.0f, q, fn);
-    return mad(e, r, q);
+    constexpr float c = 0x1.010102p-8f;              // RN(1 / 255) = 0x3b808081
+    constexpr float c_lo = -0x1.fdfdfep-33f;         // RN(1 / 255 - c) = -2.3191758e-10
+    return mad(fn, c, fn * c_lo);
 }
 
 // N-bit UNORM -> f32 == (float)n / (2^N - 1) exactly, same construction as unorm8_to_f32
