@@ -172,6 +172,7 @@ namespace MiniEngineAO
         // OnDestroy (AO.cs:357-381)
         public void Dispose()
         {
+            // (a composite still waiting for its ride is discarded by meao_destroy: call FlushComposite first if it matters)
             if (_ctx != IntPtr.Zero) { Meao.meao_destroy(_ctx); _ctx = IntPtr.Zero; }
         }
     }

@@ -68,7 +68,7 @@ public:
     }
     AmbientOcclusion(const AmbientOcclusion &) = delete;
     AmbientOcclusion &operator=(const AmbientOcclusion &) = delete;
-    ~AmbientOcclusion() { meao_destroy(ctx_); }   // OnDestroy (AO.cs:357-381)
+    ~AmbientOcclusion() { meao_destroy(ctx_); }   // OnDestroy (AO.cs:357-381); discards a composite still waiting (FlushComposite first)
 
     int32_t width() const { return cfg_.width; }
     int32_t height() const { return cfg_.height; }
@@ -144,6 +144,14 @@ public:
         return data;
     }
 
+    // Bit f = frame f of the last Render* held NaN / inf / out-of-range depth texels and ran the IEEE-division bodies.
+    uint64_t HostileFrames()
+    {
+        uint64_t mask = 0;
+        check(meao_hostile_frames(ctx_, &mask));
+        return mask;
+    }
+
     meao_ctx *native() { return ctx_; }
 
 private:
@@ -186,6 +194,59 @@ private:
     meao_config cfg_{};
     meao_params applied_{};
     bool applied_valid_ = false;
+};
+
+// One context per device behind meao_pool_*: frame f of a batch runs on member f mod G (the in-process multi-GPU host;
+// SURVEY 8e).  `devices` may repeat an ordinal (several members on one GPU: a throughput mode of its own).
+class AmbientOcclusionPool {
+public:
+    AmbientOcclusionPool(int32_t pixelWidth, int32_t pixelHeight, const std::vector<int32_t> &devices, int32_t maxBatchPerMember = 1,
+                         meao_ao_format aoFormat = MEAO_AO_R8, bool pipelined = false)
+    {
+        meao_config cfg;
+        meao_default_config(&cfg);
+        cfg.width = pixelWidth;
+        cfg.height = pixelHeight;
+        cfg.ao_format = aoFormat;
+        cfg.max_batch = maxBatchPerMember;
+        cfg.pipelined = pipelined ? 1 : 0;
+        const int32_t rc = meao_pool_create(&cfg, devices.data(), static_cast<int32_t>(devices.size()), &pool_);
+        if (rc != MEAO_OK) throw Error(rc, meao_pool_last_error(nullptr));
+    }
+    AmbientOcclusionPool(const AmbientOcclusionPool &) = delete;
+    AmbientOcclusionPool &operator=(const AmbientOcclusionPool &) = delete;
+    ~AmbientOcclusionPool() { meao_pool_destroy(pool_); }
+
+    int32_t Size() const { return meao_pool_size(pool_); }
+    int32_t DeviceOfFrame(int32_t frame) const { return meao_pool_device_of_frame(pool_, frame); }
+    void SetParams(const meao_params &p) { check(meao_pool_set_params(pool_, &p)); }
+    // Frame f resident on DeviceOfFrame(f); asynchronous (Synchronize()).
+    void RenderDeviceBatch(const std::vector<const void *> &deviceDepth, const std::vector<void *> &deviceAo)
+    {
+        check(meao_pool_execute_batch(pool_, static_cast<int32_t>(deviceDepth.size()), deviceDepth.data(), MEAO_MEM_DEVICE,
+                                      deviceAo.data(), MEAO_MEM_DEVICE));
+    }
+    void PrefetchBatch(const std::vector<const void *> &nextDeviceDepth)
+    {
+        check(meao_pool_prefetch_batch(pool_, static_cast<int32_t>(nextDeviceDepth.size()), nextDeviceDepth.data()));
+    }
+    void GatherToDevice(const std::vector<const void *> &deviceAo, const std::vector<void *> &dst, int32_t dstDevice)
+    {
+        check(meao_pool_gather_to_device(pool_, static_cast<int32_t>(deviceAo.size()), deviceAo.data(), dst.data(), dstDevice));
+    }
+    meao_pool_path GatherPath(int32_t member, int32_t dstDevice) const
+    {
+        return static_cast<meao_pool_path>(meao_pool_gather_path(pool_, member, dstDevice));
+    }
+    void Synchronize() { check(meao_pool_synchronize(pool_)); }
+    meao_pool *native() { return pool_; }
+
+private:
+    void check(int32_t rc)
+    {
+        if (rc != MEAO_OK) throw Error(rc, meao_pool_last_error(pool_));
+    }
+    meao_pool *pool_ = nullptr;
 };
 
 }  // namespace MiniEngineAO

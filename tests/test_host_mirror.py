@@ -62,7 +62,10 @@ def test_cpp_header_compiles_and_keeps_the_surface(tmp_path):
                    "void probe(MiniEngineAO::AmbientOcclusion &ao) {\n"
                    "  ao.noiseFilterTolerance = ao.blurTolerance = ao.upsampleTolerance = -2.0f;\n"
                    "  ao.thicknessModifier = 2.0f; ao.intensity = 1.5f; ao.ambientOnly = false;\n"
-                   "  ao.Render(nullptr, nullptr); ao.Resize(8, 8); }\n")
+                   "  ao.Render(nullptr, nullptr); ao.Resize(8, 8); (void)ao.HostileFrames(); }\n"
+                   "void probe_pool(MiniEngineAO::AmbientOcclusionPool &pool) {\n"
+                   "  pool.PrefetchBatch({}); pool.RenderDeviceBatch({}, {}); pool.GatherToDevice({}, {}, 0);\n"
+                   "  (void)pool.GatherPath(0, 0); pool.Synchronize(); (void)pool.Size(); }\n")
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
                     "-I" + os.path.join(ROOT, "include"), str(src)], check=True)
     # the C header must also be valid C
