@@ -75,11 +75,18 @@ extern "C" __attribute__((visibility("default"))) int meao_x_phase_clocks(unsign
     static const unsigned long long zero[64] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clocks), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
+extern "C" __attribute__((visibility("default"))) int meao_x_wg_log_preset(void);
 // per workgroup of the last persistent launch: start, end (100 MHz), HW_ID, XCC_ID
-__device__ unsigned long long g_wg_log[4096 * 4];
+__device__ unsigned long long g_wg_log[16384 * 4];
 extern "C" __attribute__((visibility("default"))) int meao_x_wg_log(unsigned long long *out, int workgroups)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_log), sizeof(unsigned long long) * 4 * (workgroups < 4096 ? workgroups : 4096)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_log), sizeof(unsigned long long) * 4 * (workgroups < 16384 ? workgroups : 16384)) == hipSuccess ? 0 : -1;
+}
+extern "C" int meao_x_wg_log_preset(void)       // render log: min fields to ~0, max field to 0
+{
+    static unsigned long long init[16384 * 4];
+    for (int i = 0; i < 16384; ++i) { init[4 * i] = ~0ull; init[4 * i + 1] = 0; init[4 * i + 2] = ~0ull; init[4 * i + 3] = 0; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_log), init, sizeof init) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -851,6 +858,9 @@ template <int AOFMT, bool RTNE, int DIV, bool EXH>
 __global__ __launch_bounds__(ren_tile_w(EXH) * 4, EXH ? 1 : 8) void render_kernel(const RenderArgs a)
 {
     __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(EXH) + 2 * kRenApron)];
+#if MEAO_X_PHASE_CLOCKS
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();      // every wave: the first one in and the last one out are logged
+#endif
     const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
     if constexpr (DIV == DIV_EXACT_RCP) {
         if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
@@ -859,6 +869,18 @@ __global__ __launch_bounds__(ren_tile_w(EXH) * 4, EXH ? 1 : 8) void render_kerne
         }
     }
     render_tile<AOFMT, RTNE, DIV, EXH>(a, tile, frame, block);
+#if MEAO_X_PHASE_CLOCKS
+    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((threadIdx.x & 63) == 0 && id < 16384) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        atomicMin(&g_wg_log[id * 4 + 0], wg_t0);           // earliest wave start (the host presets ~0)
+        atomicMax(&g_wg_log[id * 4 + 1], t1);              // latest wave end
+        atomicMin(&g_wg_log[id * 4 + 2], t1);              // earliest wave end: the skew inside the workgroup
+        if (threadIdx.x == 0)
+            g_wg_log[id * 4 + 3] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 0xFu) |
+                                   (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11))) << 8);
+    }
+#endif
 }
 
 // One or two small frames per call (fewer 128 x 32 tiles than CUs): 128 x 8 tiles, four times the workgroups,
