@@ -460,6 +460,10 @@ def main() -> int:
     ap.add_argument("--validate-frames", type=int, default=-1,
                     help="frames per rank checked bit-for-bit against the CPU oracle after each timed region "
                          "(-1 = every frame at N=1, 2 per rank at N>1; 0 = checksums only)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend; nccl (= RCCL) is what a multi-GPU node uses.  gloo lets the N > 1 path of this "
+                         "script run on a box with fewer GPUs than ranks (ranks then share devices: rank r on device r mod visible "
+                         "devices) -- a functional check of sharding / fences / gathers / validation, not a scaling number")
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
     args = ap.parse_args()
@@ -477,9 +481,13 @@ def main() -> int:
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
 
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.dist_backend == "nccl":
+        raise SystemExit(f"LOCAL_RANK {local_rank} but {ndev} visible device(s): RCCL needs one GPU per rank (--dist-backend gloo shares devices)")
+    local_rank = local_rank % ndev                               # only ever wraps with --dist-backend gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    mdist.init("nccl", dev)                                      # nccl == RCCL on ROCm
+    mdist.init(args.dist_backend, dev)                           # nccl == RCCL on ROCm
 
     wl = Workload(args.workload, args, dev, local_rank, rank, world, batch=args.batch, in_flight=args.in_flight)
     w, h, B, ao, ao_format, cam, intensity = wl.w, wl.h, wl.B, wl.ao, wl.ao_format, wl.cam, wl.intensity
@@ -667,7 +675,7 @@ def main() -> int:
             "config": {"workload": desc, "width": w, "height": h, "frames_per_step_per_gpu": B,
                        "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
                        "numerics": "FAST (raw rcp, not bit-exact, outside the parity bar)" if args.fast_numerics else "strict (bit-exact vs CPU oracle)",
-                       "sharding": f"frames x{world}", "batches_in_flight": nfl,
+                       "sharding": f"frames x{world}", "batches_in_flight": nfl, "process_group": args.dist_backend if world > 1 else None,
                        "downsample": "pipelined: each step's last kernel carries the next step's downsample pass "
                                      "(meao_prefetch_batch)" if pipelined else "own pass per step"},
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
