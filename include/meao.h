@@ -415,7 +415,9 @@ MEAO_API int32_t meao_set_tracing(meao_ctx *ctx, int32_t enable);
  * inputs whose hardware result differs from the IEEE / bit-level model.
  * which: 0 = f32->f16 RTZ_CLAMP (all 2^32), 1 = f32->f16 RTNE (all 2^32), 2 = unorm8->f32 (256),
  *        3 = f16->f32 (65536), 4 = exact reciprocal vs 1/x (all x, 2^-100<=|x|<=2^100),
- *        5 = exact 3/x and 9/x (same range), 6 = exact a/b on hashed pairs (2^-60<=|a|,|b|<=2^60). */
+ *        (and: the uncorrected v_rcp_f32 within one ulp of it), 5 = exact 3/x and 9/x (same range), 6 = exact a/b on hashed
+ *        pairs (2^-60<=|a|,|b|<=2^60), 7 = the UNORM8 bilateral result that skips the correction steps away from rounding
+ *        boundaries vs the code of the exact chain, 2^32 hashed operand sets. */
 MEAO_API int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches);
 
 #ifdef __cplusplus

@@ -76,6 +76,7 @@ VARIANTS = {
     "persist2": ["-DMEAO_X_UPS_PERSISTENT=2"],
     "persist3prio": ["-DMEAO_X_UPS_PERSISTENT=3", "-DMEAO_X_UPS_PRIO_SCHEME=1"],
     "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],
+    "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],
 }
 
 

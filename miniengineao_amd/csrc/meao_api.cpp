@@ -1274,7 +1274,7 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
 
 int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches)
 {
-    if (!ctx || !out_mismatches || which < 0 || which > 6) return MEAO_ERR_INVALID_ARGUMENT;
+    if (!ctx || !out_mismatches || which < 0 || which > 7) return MEAO_ERR_INVALID_ARGUMENT;
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     if (!ctx->counter) MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->counter), sizeof(unsigned long long)));

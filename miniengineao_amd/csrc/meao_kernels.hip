@@ -66,6 +66,9 @@
 #define MEAO_X_UPS_PRIO_SCHEME 0      // s_setprio per upsample phase {fill, H-blur, V-blur, bilateral}: 0 = {3, 0, 0, 0} (product), 1 = {3, 1, 2, 3}
 #endif                                // (emulates "furthest-along first" for persistent workgroups: 246 -> 220 us; plain launch: 201 -> 205 us)
 constexpr int kUpsPrio[2][4] = {{3, 0, 0, 0}, {3, 1, 2, 3}};
+#ifndef MEAO_X_UPS_EXACT_R8
+#define MEAO_X_UPS_EXACT_R8 0      // 1 = every UNORM8 bilateral result through the full exact-division sequence (the round-2 form) instead of
+#endif                             // bilateral_upsample_r8: L1->L0 176 -> 196 us, L2->L1 54 -> 57 us (profiles/r03_ab_verified_r8_bilateral.txt)
 #ifndef MEAO_X_PHASE_CLOCKS
 #define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py),
 #endif                          // persistent launches log start / end / CU of every workgroup (tools/wg_log.py)
@@ -1120,6 +1123,62 @@ __device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_dept
     }
 }
 
+// BilateralUpsample's result as the UNORM8 code the pass stores, for DIV_EXACT_RCP operands (a frame without hostile depth:
+// every operand finite, weights and AO values >= 0, hi_ao <= 1).
+//
+// The code is floor(RN(RN(sat(q) * 255) + 0.5)) for the q of the correctly rounded chain (bilateral_upsample).  An estimate q~
+// from the same operations with every division replaced by dividend * v_rcp_f32 differs from q by at most 32 u relatively
+// (u = 2^-24):
+//   weights   RN(K * rcp(x)) against RN(K / x): 2u (v_rcp_f32, 1 ulp) + u (the product) + u (the quotient's rounding) = 4u;
+//   the sums  have non-negative terms only, so they inherit the largest relative error of a term plus one u per rounding in
+//             either chain: total 4u + 2 * 4u = 12u, weighted sum 4u + 2 * 6u = 16u;
+//   quotient  u (RN) + 3u (rcp + product) on top: 12u + 16u + 4u = 32u = 2^-19.
+// The weighted average times hi_ao is at most 1 (+ rounding), so the estimate is off by < 4.9e-4 of a code; the reference's
+// two roundings in the conversion and the fused one of the estimate add < 4.6e-5.  If v~ = fma(sat(q~), 255, 0.5) is further
+// than kR8Margin = 2^-10 (1.8 x that bound) from an integer, floor(v~) IS the reference's code.  Otherwise -- 2^-9 of the texels
+// of a noisy frame, none where the AO is flat (q~ = 1 -> v~ = 255.5) -- the lane runs the exact sequence.  v_rcp_f32's 1-ulp
+// accuracy is checked exhaustively on the running device by meao_selftest(4), the agreement of estimate and exact code on
+// hashed operands by meao_selftest(7).
+// GROUPED: the four weight reciprocals back to back, as in bilateral_upsample_grouped.
+constexpr float kR8Margin = 0x1p-10f;
+
+template <bool GROUPED>
+__device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float hi_ao, const float (&d)[4], const float (&a)[4],
+                                                          const BilateralConsts &k, bool *took_exact_path = nullptr)
+{
+    float x[4], r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = __builtin_fabsf(hi_depth - d[i]) + k.tolerance;
+    if constexpr (GROUPED) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_rcp_f32 %0, %1" : "=v"(r[i]) : "v"(x[i]));
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(x[i]);
+    }
+    const float w0 = k.nine * r[0], w1 = k.three * r[1], w2 = r[2], w3 = k.three * r[3];
+    const float total = (((w0 + w1) + w2) + w3) + k.noise;
+    float sm = a[0] * w0;
+    sm = mad(a[1], w1, sm);
+    sm = mad(a[2], w2, sm);
+    sm = mad(a[3], w3, sm);
+    const float q = (hi_ao * (sm + k.noise)) * __builtin_amdgcn_rcpf(total);
+    const float v = mad(sat(q), 255.0f, 0.5f + kR8Margin);          // v~ + margin: its floor is the code unless its fraction is < 2 margins
+    uint32_t code = static_cast<uint32_t>(v);
+    const bool near_boundary = __builtin_amdgcn_fractf(v) < 2.0f * kR8Margin;
+    if (took_exact_path) *took_exact_path = near_boundary;
+    if (__builtin_expect(near_boundary, 0)) {
+        // The whole exact sequence again, from an opaque copy of the depth so that nothing of the estimate (x, 1 / x) has to
+        // stay in registers for this rare path: the kernels that carry a downsample tile have none to spare.
+        float hd = hi_depth;
+        asm volatile("" : "+v"(hd));
+        code = f32_to_unorm8(bilateral_upsample<DIV_EXACT_RCP>(hd, hi_ao, d[0], d[1], d[2], d[3], a[0], a[1], a[2], a[3], k));
+    }
+    return code;
+}
+
 // One tile of Upsample.main (FINAL) / main_blendout; every thread of the workgroup must call it
 // (barriers inside; lanes outside the image leave after the last one).
 template <bool FINAL, int TILE_H = ups_tile_h(FINAL)>
@@ -1259,6 +1318,7 @@ __device__ __forceinline__ void ups_store_results(const UpsampleArgs &a, int til
 struct NoHook {
     static constexpr bool kBeforeBilateral = false;
     static constexpr bool kGroupReciprocals = true;      // bilateral_upsample_grouped
+    static constexpr bool kEstimateR8 = true;            // bilateral_upsample_r8
     __device__ __forceinline__ void after_prefetch() const {}
     __device__ __forceinline__ void before_bilateral() const {}
 };
@@ -1553,7 +1613,22 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 }
             }
             ao_t res[4];
-            if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
+            if constexpr (!MEAO_X_UPS_EXACT_R8 && Hook::kEstimateR8 && DIV == DIV_EXACT_RCP && AOFMT == MEAO_AO_R8) {
+                // UNORM8 storage: the code from the uncorrected reciprocals wherever that provably is the reference's code
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // as below
+                    const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+                    float gd[4], ga[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int g = (comp + i) & 3;
+                        gd[i] = dl[rr + gy[g]][cc + gx[g]];
+                        ga[i] = vb[rr + gy[g]][cc + gx[g]];
+                    }
+                    res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals>(hd[e], ha[e], gd, ga, bilateral_k));
+                }
+            } else if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
                 // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than
                 // one that follows another (tools/ubench_issue.hip "bilateral mix": 3.81 -> 3.55 cycles per instruction).  A/B:
                 // L2->L1 65 -> 58.5 us, L1->L0 202.5 -> 199.2 us; two texels per group: the same (profiles/r03_ab_rcp_group*.jsonl).
@@ -1731,6 +1806,12 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
         }
         const size_t at = static_cast<size_t>(Y) * hw + X;
         float v;
+        if constexpr (!MEAO_X_UPS_EXACT_R8 && DIV == DIV_EXACT_RCP && AOFMT == MEAO_AO_R8) {
+            const ao_t q = static_cast<ao_t>(bilateral_upsample_r8<true>(hoist_d[j], AO::decode(hoist_a[j]), dk, ak, bilateral_k));
+            out[wr * out_pitch + wc] = AO::decode(q);
+            if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) dst[at] = q;
+            continue;
+        }
         if constexpr (DIV == DIV_EXACT_RCP) {       // the four weight reciprocals back to back (see upsample_tile)
             const float ghd[1] = {hoist_d[j]}, gha[1] = {AO::decode(hoist_a[j])};
             const float gd[1][4] = {{dk[0], dk[1], dk[2], dk[3]}}, ga[1][4] = {{ak[0], ak[1], ak[2], ak[3]}};
@@ -1856,6 +1937,7 @@ __global__ __launch_bounds__(kThreads) void upsample_three_level_kernel(const Up
 struct IssueCarriedLoads {
     static constexpr bool kBeforeBilateral = true;
     static constexpr bool kGroupReciprocals = false;     // the kernels that carry a downsample tile are short of registers: A/B +3 %
+    static constexpr bool kEstimateR8 = false;           // ... and wait on memory, not on VALU issue: 10 % fewer instructions, +4 us
     const DownsampleArgs &d;
     float (&v)[kDsTileH / kDsRowsPerPass][4];
     bool mine;
@@ -1932,6 +2014,7 @@ template <int AOFMT, bool FINAL, int TILE_H>
 struct IssueNextTileLoads {
     static constexpr bool kBeforeBilateral = true;
     static constexpr bool kGroupReciprocals = true;
+    static constexpr bool kEstimateR8 = true;
     const UpsampleArgs &a;
     UpsLoads<AOFMT, FINAL, TILE_H> &next;
     bool active;
@@ -2374,7 +2457,33 @@ __global__ __launch_bounds__(kThreads) void selftest_div_kernel(unsigned long lo
         const float x = __builtin_bit_cast(float, static_cast<uint32_t>(i));
         if (which == 4) {
             if (!in_exact_range(x, 0x1p-100f, 0x1p100f)) continue;
-            bad += rcp_strict<DIV_EXACT_RCP>(x) != 1.0f / x;
+            const float exact = 1.0f / x;
+            bad += rcp_strict<DIV_EXACT_RCP>(x) != exact;
+            // the uncorrected v_rcp_f32 is at most one ulp from the correctly rounded reciprocal (what bilateral_upsample_r8's bound uses)
+            const int32_t ulps = static_cast<int32_t>(__builtin_bit_cast(uint32_t, __builtin_amdgcn_rcpf(x))) -
+                                 static_cast<int32_t>(__builtin_bit_cast(uint32_t, exact));
+            bad += ulps < -1 || ulps > 1;
+        } else if (which == 7) {
+            // bilateral_upsample_r8 against the UNORM8 code of the exact chain on hashed operands: depths in (0, 1], the four
+            // low-res depths within a random relative distance (2^-24 .. 2) of the hi-res one, AO values in [0, 1] (one in four
+            // a UNORM8 code, as the unblurred taps are), tolerance and noise constants across the ranges the exact mode accepts
+            uint32_t h = static_cast<uint32_t>(i) * 2654435761u + 0x9E3779B9u;
+            auto next = [&h]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return h; };
+            auto unit = [&next]() { return static_cast<float>(next() >> 8) * 0x1p-24f; };                  // [0, 1)
+            auto pow2 = [&next](int lo, int hi) { return __builtin_bit_cast(float, static_cast<uint32_t>(127 + lo + static_cast<int>(next() % static_cast<uint32_t>(hi - lo + 1))) << 23); };
+            const float hd = pow2(-12, -1) * (1.0f + unit());
+            float d[4], a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = hd * (1.0f + (unit() - 0.5f) * pow2(-23, 1));
+                if (!(d[k] >= 0x1p-24f)) d[k] = 0x1p-24f;
+                a[k] = (next() & 3u) == 0 ? unorm8_to_f32(next() & 255u) : unit();
+            }
+            const float hi_ao = (next() & 1u) ? 1.0f : unorm8_to_f32(next() & 255u);
+            const BilateralConsts k(pow2(-44, 20), pow2(-30, 50));
+            const uint32_t want = f32_to_unorm8(bilateral_upsample<DIV_EXACT_RCP>(hd, hi_ao, d[0], d[1], d[2], d[3], a[0], a[1], a[2], a[3], k));
+            bad += bilateral_upsample_r8<false>(hd, hi_ao, d, a, k) != want;
+            bad += bilateral_upsample_r8<true>(hd, hi_ao, d, a, k) != want;
         } else if (which == 5) {
             if (!in_exact_range(x, 0x1p-100f, 0x1p100f)) continue;
             bad += div_const<DIV_EXACT_RCP, 3>(x) != 3.0f / x;
@@ -2685,7 +2794,7 @@ hipError_t launch_selftest(int which, unsigned long long *count, hipStream_t s)
     case 1: selftest_f16_kernel<true><<<dim3(4096), dim3(kThreads), 0, s>>>(count); break;
     case 2: selftest_unorm8_decode_kernel<<<dim3(1), dim3(256), 0, s>>>(count); break;
     case 3: selftest_f16_decode_kernel<<<dim3(65536 / kThreads), dim3(kThreads), 0, s>>>(count); break;
-    case 4: case 5: case 6: selftest_div_kernel<<<dim3(4096), dim3(kThreads), 0, s>>>(count, which); break;
+    case 4: case 5: case 6: case 7: selftest_div_kernel<<<dim3(4096), dim3(kThreads), 0, s>>>(count, which); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

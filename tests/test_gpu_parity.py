@@ -171,10 +171,11 @@ def test_largest_batch(oracle):
         ao.close()
 
 
-@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_hardware_conversions_exhaustive(oracle, which):
     """All 2^32 f32 -> f16 inputs (both rounding modes), all 256 UNORM8 and all 65536 f16
-    decodes: hardware conversion == the bit-level model the oracle uses."""
+    decodes: hardware conversion == the bit-level model the oracle uses; 4-6: the exact-division sequences; 7: the UNORM8
+    bilateral result from uncorrected reciprocals (bilateral_upsample_r8) == the code of the exact chain."""
     s = H.settings(oracle, 16, 16)
     ao = H.component(s)
     try:
