@@ -45,6 +45,10 @@
 //    reason the persistent-workgroup forms of these kernels (MEAO_X_UPS_PERSISTENT) lose to the plain launches.
 //  * v_rcp_f32 pays ~3 cycles when it follows a non-transcendental instruction: the four weight reciprocals of a
 //    bilateral texel are issued back to back (bilateral_upsample_grouped).
+//  * Results that are stored as UNORM8 do not need the correction steps of their divisions wherever the uncorrected
+//    quotient provably converts to the same code: bilateral_upsample_r8 checks that from the estimate itself (distance
+//    of the scaled value from the next rounding boundary against a proven error bound) and redoes the rare texel exactly.
+//    Not in the kernel that carries the next batch's downsample tile: it waits on memory, not on VALU issue.
 #include "meao_kernels.hpp"
 
 #include <algorithm>
