@@ -77,6 +77,7 @@ VARIANTS = {
     "persist3prio": ["-DMEAO_X_UPS_PERSISTENT=3", "-DMEAO_X_UPS_PRIO_SCHEME=1"],
     "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],
     "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],
+    "twolevel7": ["-DMEAO_X_TWO_LEVEL_WAVES=7"],
 }
 
 

@@ -73,6 +73,9 @@ constexpr int kUpsPrio[2][4] = {{3, 0, 0, 0}, {3, 1, 2, 3}};
 #ifndef MEAO_X_UPS_EXACT_R8
 #define MEAO_X_UPS_EXACT_R8 0      // 1 = every UNORM8 bilateral result through the full exact-division sequence (the round-2 form) instead of
 #endif                             // bilateral_upsample_r8: L1->L0 176 -> 196 us, L2->L1 54 -> 57 us (profiles/r03_ab_verified_r8_bilateral.txt)
+#ifndef MEAO_X_TWO_LEVEL_WAVES
+#define MEAO_X_TWO_LEVEL_WAVES 8   // waves per SIMD the two-level blend kernel is compiled for (7: 65 VGPRs, 8: 64; 4080 workgroups are 2.28 / 1.99
+#endif                             // rounds of the CUs' slots: 35.3 -> 34.3 us, profiles/r03_ab_two_level_waves.txt)
 #ifndef MEAO_X_PHASE_CLOCKS
 #define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py),
 #endif                          // persistent launches log start / end / CU of every workgroup (tools/wg_log.py)
@@ -1853,7 +1856,7 @@ __device__ __forceinline__ void upsample_two_level_tile(const UpsampleArgs &oute
 }
 
 template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(kThreads) void upsample_two_level_kernel(const UpsampleArgs outer, const UpsampleArgs inner)
+__global__ __launch_bounds__(kThreads, MEAO_X_TWO_LEVEL_WAVES) void upsample_two_level_kernel(const UpsampleArgs outer, const UpsampleArgs inner)
 {
     __shared__ __attribute__((aligned(16))) float smem[UpsLds<false>::kFloats];
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x), frame = blockIdx.z;

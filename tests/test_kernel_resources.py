@@ -35,7 +35,7 @@ HOT = {
     "upsample_kernel<0, false, true, 0>": (7, 72, 163840 // 7),                             # seven 256-thread workgroups per CU
     "upsample_final_with_next_downsample_kernel<0, false, 0>": (7, 72, 163840 // 7),
     "upsample_kernel<0, false, false, 0>": (8, 64, 163840 // 8),
-    "upsample_two_level_kernel<0, false, 0>": (7, 72, 163840 // 8),                       # 65 VGPRs since the grouped reciprocals (r03: faster anyway)
+    "upsample_two_level_kernel<0, false, 0>": (8, 64, 163840 // 8),                       # compiled for 8 waves per SIMD: 4080 workgroups = 1.99 rounds of the slots
     "downsample_kernel<false, true, 0>": (8, 64, 0),
 }
 
