@@ -78,6 +78,7 @@ VARIANTS = {
     "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],
     "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],
     "twolevel7": ["-DMEAO_X_TWO_LEVEL_WAVES=7"],
+    "r8recompute": ["-DMEAO_X_R8_REUSE=0"],
 }
 
 

@@ -73,6 +73,9 @@ constexpr int kUpsPrio[2][4] = {{3, 0, 0, 0}, {3, 1, 2, 3}};
 #ifndef MEAO_X_UPS_EXACT_R8
 #define MEAO_X_UPS_EXACT_R8 0      // 1 = every UNORM8 bilateral result through the full exact-division sequence (the round-2 form) instead of
 #endif                             // bilateral_upsample_r8: L1->L0 176 -> 196 us, L2->L1 54 -> 57 us (profiles/r03_ab_verified_r8_bilateral.txt)
+#ifndef MEAO_X_R8_REUSE
+#define MEAO_X_R8_REUSE 1
+#endif
 #ifndef MEAO_X_TWO_LEVEL_WAVES
 #define MEAO_X_TWO_LEVEL_WAVES 8   // waves per SIMD the two-level blend kernel is compiled for (7: 65 VGPRs, 8: 64; 4080 workgroups are 2.28 / 1.99
 #endif                             // rounds of the CUs' slots: 35.3 -> 34.3 us, profiles/r03_ab_two_level_waves.txt)
@@ -1147,11 +1150,14 @@ __device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_dept
 // accuracy is checked exhaustively on the running device by meao_selftest(4), the agreement of estimate and exact code on
 // hashed operands by meao_selftest(7).
 // GROUPED: the four weight reciprocals back to back, as in bilateral_upsample_grouped.
+// REUSE: the exact path starts from the estimate's x and 1 / x (14 instructions fewer on that path, 5 - 8 VGPRs more live across
+// the branch); without it the whole exact sequence is run again from an opaque copy of the depth, so that nothing of the estimate
+// has to stay in registers for the rare path (the nested kernels have none to spare).
 constexpr float kR8Margin = 0x1p-10f;
 
-template <bool GROUPED>
+template <bool GROUPED, bool REUSE = false>
 __device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float hi_ao, const float (&d)[4], const float (&a)[4],
-                                                          const BilateralConsts &k, bool *took_exact_path = nullptr)
+                                                          const BilateralConsts &k)
 {
     float x[4], r[4];
 #pragma unroll
@@ -1175,13 +1181,32 @@ __device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float 
     const float v = mad(sat(q), 255.0f, 0.5f + kR8Margin);          // v~ + margin: its floor is the code unless its fraction is < 2 margins
     uint32_t code = static_cast<uint32_t>(v);
     const bool near_boundary = __builtin_amdgcn_fractf(v) < 2.0f * kR8Margin;
-    if (took_exact_path) *took_exact_path = near_boundary;
     if (__builtin_expect(near_boundary, 0)) {
-        // The whole exact sequence again, from an opaque copy of the depth so that nothing of the estimate (x, 1 / x) has to
-        // stay in registers for this rare path: the kernels that carry a downsample tile have none to spare.
-        float hd = hi_depth;
-        asm volatile("" : "+v"(hd));
-        code = f32_to_unorm8(bilateral_upsample<DIV_EXACT_RCP>(hd, hi_ao, d[0], d[1], d[2], d[3], a[0], a[1], a[2], a[3], k));
+        if constexpr (REUSE) {
+            float w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i == 2) {                                              // rcp_strict
+                    const float e = mad(-x[i], r[i], 1.0f);
+                    w[i] = mad(e, r[i], r[i]);
+                } else {                                                   // div_const<9 | 3>
+                    const float kv = i == 0 ? k.nine : k.three;
+                    const float qw = kv * r[i];
+                    const float e = mad(-x[i], qw, kv);
+                    w[i] = mad(e, r[i], qw);
+                }
+            }
+            const float exact_total = (((w[0] + w[1]) + w[2]) + w[3]) + k.noise;
+            float s = a[0] * w[0];
+            s = mad(a[1], w[1], s);
+            s = mad(a[2], w[2], s);
+            s = mad(a[3], w[3], s);
+            code = f32_to_unorm8(div_strict<DIV_EXACT_RCP>(hi_ao * (s + k.noise), exact_total));
+        } else {
+            float hd = hi_depth;
+            asm volatile("" : "+v"(hd));
+            code = f32_to_unorm8(bilateral_upsample<DIV_EXACT_RCP>(hd, hi_ao, d[0], d[1], d[2], d[3], a[0], a[1], a[2], a[3], k));
+        }
     }
     return code;
 }
@@ -1633,7 +1658,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                         gd[i] = dl[rr + gy[g]][cc + gx[g]];
                         ga[i] = vb[rr + gy[g]][cc + gx[g]];
                     }
-                    res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals>(hd[e], ha[e], gd, ga, bilateral_k));
+                    res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, MEAO_X_R8_REUSE && !NESTED && !PRELOADED>(hd[e], ha[e], gd, ga, bilateral_k));
                 }
             } else if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
                 // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than
@@ -2489,8 +2514,10 @@ __global__ __launch_bounds__(kThreads) void selftest_div_kernel(unsigned long lo
             const float hi_ao = (next() & 1u) ? 1.0f : unorm8_to_f32(next() & 255u);
             const BilateralConsts k(pow2(-44, 20), pow2(-30, 50));
             const uint32_t want = f32_to_unorm8(bilateral_upsample<DIV_EXACT_RCP>(hd, hi_ao, d[0], d[1], d[2], d[3], a[0], a[1], a[2], a[3], k));
-            bad += bilateral_upsample_r8<false>(hd, hi_ao, d, a, k) != want;
-            bad += bilateral_upsample_r8<true>(hd, hi_ao, d, a, k) != want;
+            bad += bilateral_upsample_r8<false, false>(hd, hi_ao, d, a, k) != want;
+            bad += bilateral_upsample_r8<true, false>(hd, hi_ao, d, a, k) != want;
+            bad += bilateral_upsample_r8<false, true>(hd, hi_ao, d, a, k) != want;
+            bad += bilateral_upsample_r8<true, true>(hd, hi_ao, d, a, k) != want;
         } else if (which == 5) {
             if (!in_exact_range(x, 0x1p-100f, 0x1p100f)) continue;
             bad += div_const<DIV_EXACT_RCP, 3>(x) != 3.0f / x;
