@@ -1137,18 +1137,20 @@ __device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_dept
 // every operand finite, weights and AO values >= 0, hi_ao <= 1).
 //
 // The code is floor(RN(RN(sat(q) * 255) + 0.5)) for the q of the correctly rounded chain (bilateral_upsample).  An estimate q~
-// from the same operations with every division replaced by dividend * v_rcp_f32 differs from q by at most 32 u relatively
+// from the same operations with every division replaced by dividend * v_rcp_f32 differs from q by at most 35 u relatively
 // (u = 2^-24):
-//   weights   RN(K * rcp(x)) against RN(K / x): 2u (v_rcp_f32, 1 ulp) + u (the product) + u (the quotient's rounding) = 4u;
+//   v_rcp_f32 is within one ulp of the correctly rounded reciprocal (meao_selftest(4): every binary32 in range), i.e. within
+//             1.5 ulp = 3u of the true one;
+//   weights   RN(K * rcp(x)) against RN(K / x): 3u + u (the product) + u (the quotient's rounding) = 5u;
 //   the sums  have non-negative terms only, so they inherit the largest relative error of a term plus one u per rounding in
-//             either chain: total 4u + 2 * 4u = 12u, weighted sum 4u + 2 * 6u = 16u;
-//   quotient  u (RN) + 3u (rcp + product) on top: 12u + 16u + 4u = 32u = 2^-19.
-// The weighted average times hi_ao is at most 1 (+ rounding), so the estimate is off by < 4.9e-4 of a code; the reference's
-// two roundings in the conversion and the fused one of the estimate add < 4.6e-5.  If v~ = fma(sat(q~), 255, 0.5) is further
-// than kR8Margin = 2^-10 (1.8 x that bound) from an integer, floor(v~) IS the reference's code.  Otherwise -- 2^-9 of the texels
-// of a noisy frame, none where the AO is flat (q~ = 1 -> v~ = 255.5) -- the lane runs the exact sequence.  v_rcp_f32's 1-ulp
-// accuracy is checked exhaustively on the running device by meao_selftest(4), the agreement of estimate and exact code on
-// hashed operands by meao_selftest(7).
+//             either chain: total 5u + 2 * 4u = 13u, weighted sum (times hi_ao) 5u + 2 * 6u = 17u;
+//   quotient  u (RN) + 4u (rcp + product) on top: 13u + 17u + 5u = 35u = 1.1 * 2^-19.
+// The weighted average times hi_ao is at most 1 (+ rounding), so the estimate is off by < 5.4e-4 of a code; the reference's
+// two roundings in the conversion and the fused one of the estimate add < 2.3e-5.  If v~ = fma(sat(q~), 255, 0.5) is further
+// than kR8Margin = 2^-10 (1.7 x that bound) from an integer, floor(v~) IS the reference's code.  Otherwise -- 2^-9 of the texels
+// of a noisy frame, none where the AO is flat (q~ = 1 -> v~ = 255.5) -- the lane runs the exact sequence.  The agreement of
+// estimate and exact code is also checked on the running device for 2^32 hashed operand sets (meao_selftest(7)) and, with
+// adversarial 1-ulp reciprocal errors, in numpy by tests/test_r8_estimate_bound.py.
 // GROUPED: the four weight reciprocals back to back, as in bilateral_upsample_grouped.
 // REUSE: the exact path starts from the estimate's x and 1 / x (14 instructions fewer on that path, 5 - 8 VGPRs more live across
 // the branch); without it the whole exact sequence is run again from an opaque copy of the depth, so that nothing of the estimate

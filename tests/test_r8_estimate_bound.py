@@ -1,0 +1,80 @@
+"""CPU model of bilateral_upsample_r8 (miniengineao_amd/csrc/meao_kernels.hip): the UNORM8 code taken from the
+uncorrected-reciprocal estimate must equal the code of the correctly rounded chain whenever the estimate is further
+than the margin from a rounding boundary -- here with ADVERSARIAL reciprocals (every v_rcp_f32 replaced by the correctly
+rounded reciprocal moved by -1, 0 or +1 ulp, the worst the device check meao_selftest(4) allows), so the test does not
+depend on how the hardware's reciprocal happens to err.  Also reports how much of the proven bound random operands use."""
+import numpy as np
+
+F = np.float32
+MARGIN = F(2.0 ** -10)
+
+
+def fma(a, b, c):
+    # float64 holds the product of two binary32 exactly; the sum rounds once to 53 bits and once to 24 (a double rounding
+    # 2^-29 ulp events apart from a true fma: far below anything this test resolves)
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)
+
+
+def rcp_exact(x):
+    return (1.0 / x.astype(np.float64)).astype(F)
+
+
+def nudge(x, ulps):
+    return (x.view(np.int32) + ulps.astype(np.int32)).view(F)
+
+
+def unorm8(q):
+    s = np.clip(q, F(0), F(1)) * F(255)
+    return (s + F(0.5)).astype(np.uint32)
+
+
+def exact_chain(hd, hi_ao, d, a, tol, noise):
+    ks = [F(9), F(3), F(1), F(3)]
+    w = [(k.astype(np.float64) / (np.abs(hd - d[i]) + tol).astype(np.float64)).astype(F) for i, k in enumerate(ks)]
+    total = (((w[0] + w[1]) + w[2]) + w[3]) + noise
+    s = a[0] * w[0]
+    for i in (1, 2, 3):
+        s = fma(a[i], w[i], s)
+    p = hi_ao * (s + noise)
+    return (p.astype(np.float64) / total.astype(np.float64)).astype(F)
+
+
+def estimate_chain(hd, hi_ao, d, a, tol, noise, rng):
+    n = hd.shape[0]
+    r = [nudge(rcp_exact(np.abs(hd - d[i]) + tol), rng.integers(-1, 2, n)) for i in range(4)]
+    w = [F(9) * r[0], F(3) * r[1], r[2], F(3) * r[3]]
+    total = (((w[0] + w[1]) + w[2]) + w[3]) + noise
+    s = a[0] * w[0]
+    for i in (1, 2, 3):
+        s = fma(a[i], w[i], s)
+    q = (hi_ao * (s + noise)) * nudge(rcp_exact(total), rng.integers(-1, 2, n))
+    return fma(np.clip(q, F(0), F(1)), np.full(n, 255, F), np.full(n, F(0.5) + MARGIN, F))
+
+
+def operands(rng, n):
+    hd = (2.0 ** rng.integers(-12, 0, n) * (1 + rng.random(n))).astype(F)
+    d = [np.maximum(hd * (1 + (rng.random(n) - 0.5) * 2.0 ** rng.integers(-23, 2, n)), 2.0 ** -24).astype(F) for _ in range(4)]
+    a = [np.where(rng.integers(0, 4, n) == 0, (rng.integers(0, 256, n) / 255.0), rng.random(n)).astype(F) for _ in range(4)]
+    hi_ao = np.where(rng.integers(0, 2, n) == 0, 1.0, rng.integers(0, 256, n) / 255.0).astype(F)
+    tol = (2.0 ** rng.integers(-44, 21, n)).astype(F)
+    noise = (2.0 ** rng.integers(-30, 51, n)).astype(F)
+    return hd, hi_ao, d, a, tol, noise
+
+
+def test_estimate_code_equals_exact_code_outside_the_margin():
+    rng = np.random.default_rng(20260925)
+    worst, near, total = 0.0, 0, 0
+    for _ in range(8):
+        ops = operands(rng, 1 << 18)
+        want = unorm8(exact_chain(*ops))
+        v = estimate_chain(*ops, rng)
+        safe = (v - np.floor(v)) >= F(2) * MARGIN           # the kernel's test: fract(v~ + margin) >= 2 margins
+        got = v.astype(np.uint32)
+        assert np.array_equal(got[safe], want[safe])
+        # distance of the estimate from the exact chain's scaled value, in codes
+        q = exact_chain(*ops).astype(np.float64)
+        exact_scaled = np.clip(q, 0, 1) * 255.0 + 0.5
+        worst = max(worst, float(np.max(np.abs((v.astype(np.float64) - float(MARGIN)) - exact_scaled))))
+        near += int(np.count_nonzero(~safe)); total += safe.size
+    assert worst < 5.7e-4 < float(MARGIN)                   # the proven bound (35 u * 255 + conversion roundings), and the margin above it
+    assert 0.5 * 2.0 ** -9 < near / total < 2.0 * 2.0 ** -9  # the exact path is taken about once in 512 texels
