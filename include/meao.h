@@ -271,7 +271,9 @@ MEAO_API int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const 
  * re-allocates the context's intermediates with a second set of downsample buffers (one device
  * synchronisation; on allocation failure the context is left unchanged and usable). */
 MEAO_API int32_t meao_prefetch_batch(meao_ctx *ctx, int32_t n, const void *const *depth);
-/* Waits for `stream`; NULL = the stream of the last meao_execute* of this context. */
+/* Waits for `stream`; NULL = the stream of the last meao_execute* of this context.  meao_composite /
+ * meao_composite_flush do not change what NULL means: a composite issued on another stream is waited for
+ * by naming that stream here (or by synchronising it directly). */
 MEAO_API int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream);
 
 /* ---- observability (replaces the _debug 1..17 views, AO.cs:787-820) --------------------- */

@@ -115,6 +115,7 @@ class AmbientOcclusion:
         """Screen-size change (AO.cs:338-341)."""
         L.check(self._lib.meao_resize(self._ctx, width, height), self._ctx)
         self._cfg.width, self._cfg.height = width, height
+        self._composite_waiting = False        # meao_resize runs a waiting composite as plain launches
 
     def _sync_params(self) -> None:
         if self._dirty:
@@ -140,6 +141,7 @@ class AmbientOcclusion:
         pin = (C.c_void_p * n)(*[d.ctypes.data for d in ins])
         pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         L.check(self._lib.meao_execute_batch(self._ctx, n, pin, L.MEM_HOST, pout, L.MEM_HOST, None), self._ctx)
+        self._composite_waiting = False
         return outs
 
     def execute_device(self, depth_ptrs: Sequence[int], out_ptrs: Sequence[int], stream: int = 0) -> None:
@@ -150,6 +152,7 @@ class AmbientOcclusion:
         pout = (C.c_void_p * n)(*out_ptrs)
         L.check(self._lib.meao_execute_batch(self._ctx, n, pin, L.MEM_DEVICE, pout, L.MEM_DEVICE,
                                              C.c_void_p(stream) if stream else None), self._ctx)
+        self._composite_waiting = False        # a waiting composite rode in (or was run before) this call's render kernel
 
     def prefetch_device(self, depth_ptrs: Sequence[int]) -> None:
         """Announce the device depth frames of the call after next (meao_prefetch_batch): the next
@@ -192,9 +195,16 @@ class AmbientOcclusion:
         g = (C.c_void_p * n)(*gbuffer0_ptrs) if gbuffer0_ptrs else None
         L.check(self._lib.meao_composite_enqueue(self._ctx, mode, n, (C.c_void_p * n)(*ao_ptrs),
                                                  (C.c_void_p * n)(*color_ptrs), g), self._ctx)
+        self._composite_waiting = True
 
     def composite_flush(self, stream: int = 0) -> None:
         L.check(self._lib.meao_composite_flush(self._ctx, C.c_void_p(stream) if stream else None), self._ctx)
+        self._composite_waiting = False
+
+    @property
+    def composite_pending(self) -> bool:
+        """A batch enqueued with composite_enqueue_device() that no execute / flush / resize has run yet."""
+        return bool(getattr(self, "_composite_waiting", False))
 
     # ---- observability (the _debug views, AO.cs:787-820) -------------------------------
     def debug_buffer(self, debug_id: int, frame: int = 0) -> np.ndarray:
@@ -245,8 +255,18 @@ class AmbientOcclusion:
         L.check(self._lib.meao_selftest(self._ctx, which, C.byref(n)), self._ctx)
         return n.value
 
-    def close(self) -> None:
+    def close(self, flush_composite: bool = False) -> None:
+        """meao_destroy.  A composite batch still waiting is DISCARDED by the library (its targets are caller memory
+        that is usually gone when a context dies): pass flush_composite=True while those buffers are alive to run it
+        first; otherwise the loss is reported as a RuntimeWarning instead of passing silently."""
         if self._ctx:
+            if self.composite_pending:
+                if flush_composite:
+                    self.composite_flush()
+                else:
+                    import warnings
+                    warnings.warn("AmbientOcclusion.close(): a composite batch was still waiting and is discarded "
+                                  "(call composite_flush() or close(flush_composite=True) first)", RuntimeWarning, stacklevel=2)
             self._lib.meao_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -313,6 +333,7 @@ class AmbientOcclusionPool:
         pin = (C.c_void_p * n)(*[d.ctypes.data for d in ins])
         pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         self._check(self._lib.meao_pool_execute_batch(self._pool, n, pin, L.MEM_HOST, pout, L.MEM_HOST))
+        self._composite_waiting = False
         return outs
 
     def execute_device(self, depth_ptrs: Sequence[int], out_ptrs: Sequence[int]) -> None:
@@ -320,6 +341,7 @@ class AmbientOcclusionPool:
         n = len(depth_ptrs)
         pin, pout = (C.c_void_p * n)(*depth_ptrs), (C.c_void_p * n)(*out_ptrs)
         self._check(self._lib.meao_pool_execute_batch(self._pool, n, pin, L.MEM_DEVICE, pout, L.MEM_DEVICE))
+        self._composite_waiting = False
 
     def prefetch_device(self, depth_ptrs: Sequence[int]) -> None:
         """meao_pool_prefetch_batch: the frames of the call after next, dealt like execute_device deals them."""
@@ -332,9 +354,13 @@ class AmbientOcclusionPool:
         g = (C.c_void_p * n)(*gbuffer0_ptrs) if gbuffer0_ptrs else None
         self._check(self._lib.meao_pool_composite_enqueue(self._pool, mode, n, (C.c_void_p * n)(*ao_ptrs),
                                                           (C.c_void_p * n)(*color_ptrs), g))
+        self._composite_waiting = True
 
     def composite_flush(self) -> None:
         self._check(self._lib.meao_pool_composite_flush(self._pool))
+        self._composite_waiting = False
+
+    composite_pending = property(lambda s: bool(getattr(s, "_composite_waiting", False)))
 
     def gather_path(self, member: int, dst_device: int) -> int:
         """L.POOL_PATH_*: how gather_to_device copies from `member`'s device to dst_device."""
@@ -352,8 +378,16 @@ class AmbientOcclusionPool:
     def synchronize(self) -> None:
         self._check(self._lib.meao_pool_synchronize(self._pool))
 
-    def close(self) -> None:
+    def close(self, flush_composite: bool = False) -> None:
+        """meao_pool_destroy; a composite still waiting is discarded unless flush_composite (see AmbientOcclusion.close)."""
         if self._pool:
+            if self.composite_pending:
+                if flush_composite:
+                    self.composite_flush()
+                else:
+                    import warnings
+                    warnings.warn("AmbientOcclusionPool.close(): a composite batch was still waiting and is discarded "
+                                  "(call composite_flush() or close(flush_composite=True) first)", RuntimeWarning, stacklevel=2)
             self._lib.meao_pool_destroy(self._pool)
             self._pool = C.c_void_p()
 

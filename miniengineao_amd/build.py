@@ -82,14 +82,35 @@ VARIANTS = {
 }
 
 
-def build_variants(names=None):
-    """Variant libraries miniengineao_amd/lib/variants/libmeao_<name>.so (MEAO_LIB_PATH selects one at run time)."""
+def build_variants(names=None, strict=False):
+    """Variant libraries miniengineao_amd/lib/variants/libmeao_<name>.so (MEAO_LIB_PATH selects one at run time).
+    Experimental, off-by-default arms: a variant that fails to compile is reported and skipped (its stale .so is
+    removed, so tests/test_variants_gpu.py does not run an old build) -- only the product library gates a build
+    (ADVICE r3).  strict=True raises instead.  Returns the paths that were built."""
     from concurrent.futures import ThreadPoolExecutor
     out_dir = os.path.join(LIB_DIR, "variants")
     os.makedirs(out_dir, exist_ok=True)
     todo = [(n, f) for n, f in VARIANTS.items() if names is None or n in names]
+    if names is None:           # libraries of arms that no longer exist
+        for old in os.listdir(out_dir):
+            if old.startswith("libmeao_") and old[len("libmeao_"):-len(".so")] not in VARIANTS:
+                os.remove(os.path.join(out_dir, old))
+
+    def one(nf):
+        path = os.path.join(out_dir, f"libmeao_{nf[0]}.so")
+        try:
+            return build_lib(force=True, extra_flags=nf[1], out_path=path)
+        except RuntimeError as e:
+            if strict:
+                raise
+            if os.path.exists(path):
+                os.remove(path)
+            print(f"[build] variant {nf[0]} {nf[1]} did NOT build (skipped, the product is unaffected):\n{str(e)[-2000:]}",
+                  file=sys.stderr, flush=True)
+            return None
+
     with ThreadPoolExecutor(4) as ex:
-        return list(ex.map(lambda nf: build_lib(force=True, extra_flags=nf[1], out_path=os.path.join(out_dir, f"libmeao_{nf[0]}.so")), todo))
+        return [p for p in ex.map(one, todo) if p]
 
 
 DEMO_PATH = os.path.join(LIB_DIR, "ao_host_demo")

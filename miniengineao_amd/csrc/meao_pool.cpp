@@ -191,12 +191,13 @@ int32_t meao_pool_execute_batch(meao_pool *p, int32_t n, const void *const *dept
         const int32_t k = share_of(m, G, n, depth, d);
         share_of(m, G, n, ao_out, o);
         if (k == 0) continue;
+        // a member that fails may already have put copies from / to the caller's host buffers in flight before it
+        // failed: its stream is waited for like the others' 
+        issued = m + 1;
         const int32_t rc = meao::execute_batch_internal(p->ctx[m], k, d, depth_loc, o, out_loc, p->stream[m], false);
         if (rc != MEAO_OK)
             status = pool_fail(p, rc, std::string("meao_pool_execute_batch: member ") + std::to_string(m) + ": " +
                                           meao_last_error(p->ctx[m]));
-        else
-            issued = m + 1;
     }
     if (host) {     // the host buffers are the caller's again when the call returns: wait for what was issued
         for (int32_t m = 0; m < issued; ++m)

@@ -16,11 +16,14 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def _free_port() -> int:
+def free_port() -> int:
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         return sock.getsockname()[1]
+
+
+_free_port = free_port
 
 
 def init(backend: str = "nccl", device: "torch.device | None" = None) -> Tuple[int, int, int]:
@@ -34,7 +37,7 @@ def init(backend: str = "nccl", device: "torch.device | None" = None) -> Tuple[i
             # (MEAO_FORCE_DIST=1) gets here, and it takes a free port instead of a hard-wired one
             if world > 1:
                 raise RuntimeError("MASTER_PORT is not set: launch with torch.distributed.run (or export MASTER_ADDR / MASTER_PORT)")
-            os.environ["MASTER_PORT"] = str(_free_port())
+            os.environ["MASTER_PORT"] = str(free_port())
         kwargs = {}
         if backend == "nccl" and device is not None:
             kwargs["device_id"] = device

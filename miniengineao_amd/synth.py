@@ -125,9 +125,18 @@ def occluder_field(width: int, height: int, seed: int = 0x1234ABCD, n_rects: int
     return linear01_to_raw(lin, cam)
 
 
-def atrium(width: int, height: int, cam: Camera = SPONZA_CAMERA) -> np.ndarray:
-    """S3: analytic ray-cast of a floor, ceiling, two side walls, a back wall and two
-    rows of 8 cylinders, seen through the Sponza scene camera."""
+_ATRIUM_CACHE: dict = {}
+
+
+def _atrium_linear01(width: int, height: int, cam: Camera) -> np.ndarray:
+    key = (width, height, cam)
+    if key not in _ATRIUM_CACHE:
+        _ATRIUM_CACHE.clear()                     # one scene at a time (a 4K f64 image is 66 MB)
+        _ATRIUM_CACHE[key] = _atrium_linear01_uncached(width, height, cam)
+    return _ATRIUM_CACHE[key].copy()
+
+
+def _atrium_linear01_uncached(width: int, height: int, cam: Camera) -> np.ndarray:
     aspect = width / height
     th = math.tan(math.radians(cam.fov_y_deg) * 0.5)
     px = (np.arange(width, dtype=np.float64)[None, :] + 0.5) / width * 2.0 - 1.0
@@ -155,7 +164,34 @@ def atrium(width: int, height: int, cam: Camera = SPONZA_CAMERA) -> np.ndarray:
             hit = disc > 0
             root = np.where(hit, (-b - np.sqrt(np.where(hit, disc, 0.0))) / (2.0 * a), np.inf)
             t = np.minimum(t, np.where(hit & (root > 0), root, np.inf))
-    lin = np.clip(t / cam.far, cam.near / cam.far * 1.5, 0.99)
+    return np.clip(t / cam.far, cam.near / cam.far * 1.5, 0.99)
+
+
+def atrium(width: int, height: int, cam: Camera = SPONZA_CAMERA) -> np.ndarray:
+    """S3: analytic ray-cast of a floor, ceiling, two side walls, a back wall and two
+    rows of 8 cylinders, seen through the Sponza scene camera."""
+    return linear01_to_raw(_atrium_linear01(width, height, cam), cam)
+
+
+def atrium_with_occluders(width: int, height: int, seed: int, n_boxes: int = 24, cam: Camera = SPONZA_CAMERA) -> np.ndarray:
+    """S3 + seeded screen-space boxes standing in front of what they cover (S2's rectangle rule):
+    distinct frames of the same scene for batches (bench.py: frame 0 of a batch is the plain atrium,
+    frame f > 0 uses seed + f), so that a frame-index mix-up shows in the per-frame checksums."""
+    lin = _atrium_linear01(width, height, cam)
+    rng = _XorShift32(seed)
+    scale = min(width, height)
+    floor = cam.near / cam.far * 1.5
+    for _ in range(n_boxes):
+        cx, cy = rng.unit() * width, rng.unit() * height
+        hw = (0.01 + 0.07 * rng.unit()) * scale
+        hh = (0.02 + 0.12 * rng.unit()) * scale
+        frac = 0.35 + 0.6 * rng.unit()
+        x0, x1 = max(0, int(cx - hw)), min(width, int(cx + hw) + 1)
+        y0, y1 = max(0, int(cy - hh)), min(height, int(cy + hh) + 1)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        region = lin[y0:y1, x0:x1]
+        lin[y0:y1, x0:x1] = np.minimum(region, max(region.min() * frac, floor))
     return linear01_to_raw(lin, cam)
 
 

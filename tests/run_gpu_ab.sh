@@ -2,8 +2,8 @@
 TAG=$1; A=$2; B=$3
 mkdir -p gpurun_out
 for i in 1 2 3; do
-  timeout 300 python bench.py --no-cpu-baseline --skip-latency --validate-frames 1 $A 2>/dev/null | grep '^{' > gpurun_out/ab_${TAG}_A$i.json
-  timeout 300 python bench.py --no-cpu-baseline --skip-latency --validate-frames 1 $B 2>/dev/null | grep '^{' > gpurun_out/ab_${TAG}_B$i.json
+  timeout 300 python bench.py --no-cpu-baseline --skip-latency --no-copy-ceiling --no-best-host-config --validate-frames 1 $A 2>/dev/null | grep '^{' > gpurun_out/ab_${TAG}_A$i.json
+  timeout 300 python bench.py --no-cpu-baseline --skip-latency --no-copy-ceiling --no-best-host-config --validate-frames 1 $B 2>/dev/null | grep '^{' > gpurun_out/ab_${TAG}_B$i.json
 done
 python - <<PY
 import json,glob

@@ -6,7 +6,7 @@ export OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 120 rocprofv3 -L > $OUT/counters_available.txt 2>&1
-run() { name=$1; shift; case " ${PMC_GROUPS:-sq1 sq2 sq3 sq4 sq5 fetch write} " in *" $name "*) ;; *) return;; esac; timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o pmc -- python $REPO/bench.py --no-cpu-baseline --skip-latency --no-other-workloads --validate-frames 0 --min-time-ms 0 --steps 3 --warmup 1 $BENCH_ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+run() { name=$1; shift; case " ${PMC_GROUPS:-sq1 sq2 sq3 sq4 sq5 fetch write} " in *" $name "*) ;; *) return;; esac; timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o pmc -- python $REPO/bench.py --no-cpu-baseline --skip-latency --no-other-workloads --no-copy-ceiling --no-best-host-config --validate-frames 0 --min-time-ms 0 --steps 3 --warmup 1 $BENCH_ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 BENCH_ARGS="$*"
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE

@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def rows():
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc here: the compile-time resource table cannot be produced")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--json"],
                          capture_output=True, text=True, check=True, cwd=ROOT, timeout=900)
     table = json.loads(out.stdout)
