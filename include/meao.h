@@ -402,8 +402,12 @@ MEAO_API int32_t meao_hostile_frames(meao_ctx *ctx, uint64_t *out_mask);
 typedef enum meao_debug_key {
     MEAO_DEBUG_FUSE_COARSE_BLEND = 0, MEAO_DEBUG_NESTED_MAX_TILES = 1, MEAO_DEBUG_RENDER_SMALL_MAX_TILES = 2,
     MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4, MEAO_DEBUG_FAIL_NEXT_ALLOCS = 5,
-    MEAO_DEBUG_DS_SHARE_IN_BLEND = 6   /* percent (0..100) of the next batch's downsample tiles (meao_prefetch_batch) carried by
+    MEAO_DEBUG_DS_SHARE_IN_BLEND = 6,  /* percent (0..100) of the next batch's downsample tiles (meao_prefetch_batch) carried by
                                         * the L2 -> L1 blend launch instead of the last kernel */
+    MEAO_DEBUG_DS_SIDE_STREAM = 7      /* 0 = off.  gate + 10 * shape: the announced batch's downsample pass runs as its own kernel on a
+                                        * second, low-priority stream of the context, released when the call's stream reaches `gate`
+                                        * (1 = the full-resolution upsample launch, 2 = L2 -> L1, 3 = the coarse blend launch, 4 = render);
+                                        * shape 0..3 = loads in flight per lane {16 + 120 VGPRs declared, 16, 8, 4}.  Results identical. */
 } meao_debug_key;
 MEAO_API int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value);
 

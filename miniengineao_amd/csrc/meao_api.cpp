@@ -76,6 +76,15 @@ struct meao_ctx {
     int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
     int nested_max_tiles = 512;        // calls with at most this many L2->L1 tiles (frames x tiles) run the three blend passes as one launch
     int ds_share_in_blend = 0;         // percent of the carried (next batch's) downsample tiles that ride in the L2->L1 blend launch instead of the last kernel
+    // MEAO_DEBUG_DS_SIDE_STREAM (0 = off): the announced next batch's downsample pass as its OWN kernel on a second,
+    // low-priority stream of the context, gated behind a point of this call's launch sequence, instead of riding inside
+    // the last upsample kernel.  value = gate + 10 * shape: gate 1 = in front of the full-resolution launch (co-runs with
+    // it), 2 = in front of L2->L1, 3 = in front of the coarse blend launch, 4 = in front of render; shape 0 = 16 loads
+    // per lane in flight, 120 VGPRs declared, 1 = 16 loads, 2 = 8 loads, 3 = 4 loads (the stand-alone pass's tile).
+    int ds_side_stream = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_gate = nullptr, side_done = nullptr;
+    bool side_pending = false;         // a side-stream downsample was issued and no later execute has ordered itself behind it yet
 
     // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue),
     // and the stream its AO frames were produced on (where a flush that is not given a stream runs it)
@@ -381,6 +390,14 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     };
     auto next_generation = [&]() { if (++ctx->gen_counter == 0) ++ctx->gen_counter; return ctx->gen_counter; };   // never 0
 
+    // A downsample pass of the previous call that ran on the side stream (MEAO_DEBUG_DS_SIDE_STREAM): everything this
+    // call launches is ordered behind it -- its readers if the announcement was right, and its own downsample pass,
+    // which may write the same set, if it was not.
+    if (ctx->side_pending) {
+        MEAO_HIP(ctx, hipStreamWaitEvent(stream, ctx->side_done, 0));
+        ctx->side_pending = false;
+    }
+
     // A previous call may already have downsampled exactly these frames (meao_prefetch_batch).  The
     // prefetched set is only valid on the stream of the execute that carried it: stream order is what
     // orders that kernel before this call's readers.
@@ -504,10 +521,48 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         return MEAO_OK;
     };
 
+    // MEAO_DEBUG_DS_SIDE_STREAM: the announced batch's downsample pass as its own kernel on the side stream, released
+    // when `stream` reaches gate `g` of this call.  (The set it writes was last read by the PREVIOUS call's kernels,
+    // all in front of every gate in stream order; the next execute waits for side_done before anything else.)
+    const int side_gate_at = (ctx->ds_side_stream > 0 && ctx->next_n > 0 && !capturing) ? ctx->ds_side_stream % 10 : 0;
+    auto side_downsample_at = [&](int g) -> int {
+        if (g != side_gate_at || ctx->next_n == 0) return MEAO_OK;
+        const int other = 1 - ctx->ds_cur, shape = ctx->ds_side_stream / 10;
+        DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, other, 0);
+        if (!ds.vec_ok || c.depth_format != MEAO_DEPTH_F32) return MEAO_OK;     // stays with the last kernel (fused form)
+        ds.row_passes = shape <= 1 ? 16 : (shape == 2 ? 8 : 4);
+        ds.tiles_y = (p.mip[0].h + ds.row_passes * kDsRowsPerPass - 1) / (ds.row_passes * kDsRowsPerPass);
+        ds.tile_end = ds.tiles_x * ds.tiles_y;
+        if (!ctx->side_stream) {
+            int least = 0, greatest = 0;
+            MEAO_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            MEAO_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, least));
+            MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->side_gate, hipEventDisableTiming));
+            MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
+        }
+        ctx->set_gen[other] = next_generation();
+        ds.generation = ctx->set_gen[other];
+        TraceRange tr(ctx, "meao:downsample_next(side stream)");
+        MEAO_HIP(ctx, hipEventRecord(ctx->side_gate, stream));
+        MEAO_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_gate, 0));
+        MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
+        MEAO_HIP(ctx, launch_downsample_side(ds, ctx->next_n, shape == 0, ctx->side_stream));
+        MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
+        MEAO_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
+        ctx->side_pending = true;
+        ctx->ready_n = ctx->next_n;
+        ctx->ready_set = other;
+        ctx->ready_stream = stream;
+        std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
+        ctx->next_n = 0;
+        return MEAO_OK;
+    };
+
     if (ctx->pending_comp.frames > 0 && c.sample_set == MEAO_SAMPLES_EXHAUSTIVE) {
         const int rc = flush_pending_composite(ctx, stream);     // the 68-sample render kernel carries nothing
         if (rc != MEAO_OK) return rc;
     }
+    { const int rc = side_downsample_at(4); if (rc != MEAO_OK) return rc; }
     {
         TraceRange tr(ctx, ctx->pending_comp.frames > 0 ? "meao:render+composite_of_previous_call" : "meao:render");
         MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
@@ -526,6 +581,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         MEAO_HIP(ctx, launch_render_wide(render_args(1, c.num_levels, true), c.ao_format, n, stream));
         MEAO_HIP(ctx, end(MEAO_PASS_RENDER_HQ, stream));
     }
+    { const int rc = side_downsample_at(3); if (rc != MEAO_OK) return rc; }
     bool blend_done = false;
     const int l1_tiles = ((p.mip[1].w + kUpsTileW - 1) / kUpsTileW) * ((p.mip[1].h + ups_tile_h(false) - 1) / ups_tile_h(false));
     if (ctx->fuse_coarse_blend && c.num_levels == 4 && c.hq_levels == 0 && n * l1_tiles <= ctx->nested_max_tiles) {
@@ -551,6 +607,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     }
     // Part of the announced next batch's downsample pass can ride in the L2 -> L1 blend launch (latency-bound, HBM and
     // issue slots idle) instead of the last kernel: tiles [0, carried_in_blend) of every frame
+    { const int rc = side_downsample_at(2); if (rc != MEAO_OK) return rc; }
     int carried_in_blend = 0;
     uint32_t next_gen = 0;
     if (c.num_levels >= 2 && !blend_done) {
@@ -575,6 +632,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             if (rc != MEAO_OK) return rc;
         }
     }
+    { const int rc = side_downsample_at(1); if (rc != MEAO_OK) return rc; }
     {   // Upsample.main: the result
         TraceRange tr(ctx, kUpsRange[0]);
         const UpsampleArgs up = upsample_args(0);
@@ -840,6 +898,9 @@ int32_t meao_destroy(meao_ctx *ctx)
     if (ctx->hostile) (void)hipFree(ctx->hostile);
     if (ctx->roctx_lib) (void)dlclose(ctx->roctx_lib);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->side_gate) (void)hipEventDestroy(ctx->side_gate);
+    if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     if (prev_device >= 0) (void)hipSetDevice(prev_device);
@@ -1262,6 +1323,10 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
+    case MEAO_DEBUG_DS_SIDE_STREAM:
+        if (value < 0 || value % 10 > 4 || value / 10 > 3) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");
+        ctx->ds_side_stream = value;
+        break;
     default: return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: unknown key");
     }
     if (!ctx->graphs.empty()) {      // captured sequences embed the launch structure

@@ -378,7 +378,10 @@ __device__ __forceinline__ bool nice_denominator(float den)
 // First half of a downsample tile: the raw depth texels of this lane, 4 per row in each of the 4 row passes.
 // F32_ONLY: the caller has established a.depth_format == MEAO_DEPTH_F32 (no format switch in the code).
 // PASSES row passes of kDsRowsPerPass rows: 4 = the 32-row tile, 1 = the 8-row tile of small calls.
-template <bool VEC, bool F32_ONLY = false, int PASSES = kDsTileH / kDsRowsPerPass>
+// CLAMP_ROWS (f32, 16-byte loads): rows past the frame re-read its last row instead of being skipped, so that every load
+// is unconditional and the one wait for them sits in front of the finish loop, not inside its first row's branch (at the
+// join behind that branch the compiler otherwise waits with vmcnt(0) for the first row's STORES as well).
+template <bool VEC, bool F32_ONLY = false, int PASSES = kDsTileH / kDsRowsPerPass, bool CLAMP_ROWS = false>
 __device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, int tile, int frame,
                                                      float (&v)[PASSES][4])
 {
@@ -391,6 +394,16 @@ __device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, in
 
     // The depth-copy blit of the reference (Blit.shader pass 0) is folded into this load: the
     // texel format is decoded here (wave-uniform switch), 4 texels per lane per row.
+    if constexpr (CLAMP_ROWS) {
+        static_assert(VEC && F32_ONLY, "the clamped form is the 16-byte f32 one");
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) {
+            const int y = min(yb + k * kDsRowsPerPass, H - 1);
+            const float4v q = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(static_cast<const float *>(depth) + static_cast<size_t>(y) * W + x0));
+            v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < PASSES; ++k) {
         const int y = yb + k * kDsRowsPerPass;
@@ -523,6 +536,21 @@ template <bool RTNE, bool VEC, int DIV>
 __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleArgs a)
 {
     downsample_tile<RTNE, VEC, DIV>(a, blockIdx.x, blockIdx.z);
+}
+
+// The pass as a CO-RUNNER of the full-resolution upsample launch (meao_debug_set MEAO_DEBUG_DS_SIDE_STREAM): its own kernel
+// on a second, low-priority stream.  The upsample launch keeps seven 4-wave workgroups per CU (LDS), i.e. one wave slot
+// per SIMD and ~120 VGPRs per lane stay free: a co-resident downsample workgroup gets its memory-level parallelism from a
+// deep per-lane queue (PASSES 16-byte loads in flight: a 128 x 8*PASSES tile) instead of from occupancy.
+// PAD_VGPRS: the kernel declares 120 VGPRs whatever it uses, so that exactly one of its workgroups fits next to seven
+// upsample workgroups and the registers a finishing upsample workgroup frees (56) can only go to the next upsample one.
+template <bool RTNE, int DIV, int PASSES, bool PAD_VGPRS>
+__global__ __launch_bounds__(kThreads) void downsample_side_kernel(const DownsampleArgs a)
+{
+    if constexpr (PAD_VGPRS) asm volatile("" ::: "v119");
+    float v[PASSES][4];
+    downsample_tile_load<true, true, PASSES, true>(a, blockIdx.x, blockIdx.z, v);
+    downsample_tile_finish<RTNE, true, DIV, PASSES>(a, blockIdx.x, blockIdx.z, v);
 }
 
 // Small calls (a 1080p frame: 510 tiles of 128 x 32): tiles of one row pass, four times the workgroups, one
@@ -2574,6 +2602,29 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
     } else {
         if (vec) downsample_kernel<false, true, DIV_IEEE><<<grid, block, 0, s>>>(a);
         else downsample_kernel<false, false, DIV_IEEE><<<grid, block, 0, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+template <int PASSES, bool PAD>
+static void launch_downsample_side_t(const DownsampleArgs &a, dim3 grid, hipStream_t s)
+{
+    if (a.f16_rtne) downsample_side_kernel<true, DIV_IEEE, PASSES, PAD><<<grid, dim3(kThreads), 0, s>>>(a);
+    else if (a.exact_rcp_div == 2) downsample_side_kernel<false, DIV_FAST, PASSES, PAD><<<grid, dim3(kThreads), 0, s>>>(a);
+    else if (a.exact_rcp_div) downsample_side_kernel<false, DIV_EXACT_RCP, PASSES, PAD><<<grid, dim3(kThreads), 0, s>>>(a);
+    else downsample_side_kernel<false, DIV_IEEE, PASSES, PAD><<<grid, dim3(kThreads), 0, s>>>(a);
+}
+
+// a.row_passes in {4, 8, 16} (a.tiles_y counted in tiles of 8 * row_passes rows); f32 depth, 16-byte aligned rows only
+hipError_t launch_downsample_side(const DownsampleArgs &a, int frames, bool pad_vgprs, hipStream_t s)
+{
+    if (a.vec_ok == 0 || a.depth_format != MEAO_DEPTH_F32) return hipErrorInvalidValue;
+    const dim3 grid(a.tiles_x * a.tiles_y, 1, frames);
+    switch (a.row_passes) {
+    case 4: pad_vgprs ? launch_downsample_side_t<4, true>(a, grid, s) : launch_downsample_side_t<4, false>(a, grid, s); break;
+    case 8: pad_vgprs ? launch_downsample_side_t<8, true>(a, grid, s) : launch_downsample_side_t<8, false>(a, grid, s); break;
+    case 16: pad_vgprs ? launch_downsample_side_t<16, true>(a, grid, s) : launch_downsample_side_t<16, false>(a, grid, s); break;
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

@@ -120,6 +120,9 @@ struct TileAtlasArgs {
 };
 
 hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s);
+// The pass as its own kernel meant to co-run with the full-resolution upsample launch from a second stream: tiles of
+// 128 x 8 * a.row_passes texels (row_passes 4, 8 or 16 loads in flight per lane), optionally declaring 120 VGPRs.
+hipError_t launch_downsample_side(const DownsampleArgs &a, int frames, bool pad_vgprs, hipStream_t s);
 hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,

@@ -18,6 +18,8 @@ ap.add_argument("--pipeline", action="store_true")
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--tag", default="")
 ap.add_argument("--ds-share", type=int, default=0, help="MEAO_DEBUG_DS_SHARE_IN_BLEND percent (pipelined only)")
+ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
+                help="meao_debug_set before the run, e.g. DS_SIDE_STREAM=1 (repeatable)")
 a = ap.parse_args()
 w, h, kind, cam, intensity, ao_format, _ = WORKLOADS[a.workload]
 B = a.batch or max(1, (3840 * 2160 * 16) // (w * h))
@@ -30,6 +32,9 @@ ao = AmbientOcclusion(w, h, num_levels=4, ao_format=ao_format, max_batch=B, near
 ao.intensity = intensity
 if a.ds_share:
     ao.debug_set(_lib.DEBUG_DS_SHARE_IN_BLEND, a.ds_share)
+for kv in a.debug_set:
+    key, value = kv.split("=")
+    ao.debug_set(getattr(_lib, "DEBUG_" + key), int(value))
 dp, op = [t.data_ptr() for t in dd], [t.data_ptr() for t in out]
 st = torch.cuda.current_stream(dev).cuda_stream
 def step():
@@ -53,7 +58,11 @@ if a.check:
     from oracle import oracle as O
     s = O.Settings(w, h, proj00=cam.proj00(w, h), near_clip=cam.near, far_clip=cam.far, reversed_z=cam.reversed_z,
                    intensity=intensity, ao_format=ao_format)
-    want = O.run(frames[0], s, nthreads=os.cpu_count(), result_only=True)["result"]
-    res["ok"] = bool(np.array_equal(out[0].cpu().numpy().view(want.dtype), want))
-res["tag"] = (a.tag or os.path.basename(os.environ.get("MEAO_LIB_PATH", "product"))) + (f"+share{a.ds_share}" if a.ds_share else "")
+    ok = True
+    for f in sorted({0, B - 1}):
+        want = O.run(frames[f], s, nthreads=os.cpu_count(), result_only=True)["result"]
+        ok = ok and bool(np.array_equal(out[f].cpu().numpy().view(want.dtype), want))
+    res["ok"] = ok
+res["tag"] = (a.tag or os.path.basename(os.environ.get("MEAO_LIB_PATH", "product"))) + (f"+share{a.ds_share}" if a.ds_share else "") + \
+    "".join("+" + kv for kv in a.debug_set)
 print(json.dumps(res), flush=True)

@@ -596,3 +596,54 @@ def test_carried_downsample_split_between_blend_and_last_kernel(oracle, share, w
         assert n == 3 and ms[0] > 0        # only the first step ran a stand-alone downsample pass
     finally:
         ao.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 4, 11, 21, 33])
+@pytest.mark.parametrize("w,h,batch", [(512, 256, 2), (1280, 720, 3), (644, 364, 2), (640, 131, 1)])
+def test_next_downsample_on_the_side_stream(oracle, mode, w, h, batch):
+    """MEAO_DEBUG_DS_SIDE_STREAM: the announced batch's downsample pass as its own kernel on the context's second,
+    low-priority stream, released at a gate of the call (1 = in front of the full-resolution launch ... 4 = in front of
+    render), tiles of 128 x 128 / 64 / 32 texels (16 / 8 / 4 loads in flight per lane).  Five steps WITHOUT a host
+    synchronisation between them (the orderings are events between the two streams), a hostile frame, a mispredicted
+    announcement whose stale side kernel writes the set the next call's own pass uses: every buffer against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = H.settings(oracle, w, h)
+    seqs = [[synth.make("S2", w, h, seed=700 + 10 * k + f) for f in range(batch)] for k in range(5)]
+    seqs[1][batch - 1] = H.hostile_frame(w, h, 77, density=0.002)
+    dd = [[torch.from_numpy(f).to(dev) for f in b] for b in seqs]
+    out = [[torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in b] for b in seqs]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_SIDE_STREAM: mode})
+    announce = {0: 1, 1: 2, 2: 4, 3: None, 4: None}          # step 2 announces set 4 but set 3 arrives
+    try:
+        for k in range(5):
+            if announce[k] is not None:
+                ao.prefetch_device([t.data_ptr() for t in dd[announce[k]]])
+            ao.execute_device([t.data_ptr() for t in dd[k]], [t.data_ptr() for t in out[k]], st)
+        torch.cuda.synchronize(dev)
+        for k in range(5):
+            for f in range(batch):
+                want = oracle.run(seqs[k][f], s, result_only=(k != 4))
+                ok, bad = H.nan_aware_equal(out[k][f].cpu().numpy(), want["result"])
+                assert ok, (k, f, int(bad.sum()))
+                if k == 4:
+                    for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+                        ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
+                        assert ok, (H.NAMES[i], f, int(bad.sum()))
+        # steady state with intermediates: the consumer of a side-stream set
+        ao.set_profiling(True)
+        for k in (0, 1):
+            ao.prefetch_device([t.data_ptr() for t in dd[1]])
+            ao.execute_device([t.data_ptr() for t in dd[k]], [t.data_ptr() for t in out[k]], st)
+        torch.cuda.synchronize(dev)
+        for f in range(batch):
+            want = oracle.run(seqs[1][f], s)
+            for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+                ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
+                assert ok, (H.NAMES[i], f, int(bad.sum()))
+        assert ao.hostile_frames() == 1 << (batch - 1)
+        ms, n = ao.pass_times_ms()
+        assert n == 2 and ms[0] > 0        # the side-stream kernel is timed in the downsample slot (events on ITS stream)
+    finally:
+        ao.close()
