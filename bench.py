@@ -110,7 +110,7 @@ def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
         table = json.load(open(path))
         row = table[workload][kernel]
         out = {"bytes": int(row["bytes_per_frame"] * frames_per_launch),
-               "source": f"committed PMC pass {table.get('_tag', '(untagged)')} in profiles/pmc_traffic.json -- "
+               "source": f"committed PMC pass {table.get('_tags', {}).get(workload, table.get('_tag', '(untagged)'))} in profiles/pmc_traffic.json -- "
                          "separate rocprofv3 --pmc runs, NOT measured in this run",
                "note": row.get("note", "")}
         if "valu_wave_insts_per_frame" in row:      # SQ_INSTS_VALU of the same PMC passes
@@ -300,10 +300,13 @@ def measure_other_workload(name, args, dev, local_rank):
         check, _ = wl.validate(1 if name == "8k" else 2)
         rows, alg, names = pass_table(wl.ao, pass_ms, wl.B, wl.pipelined)
         dom = max(rows, key=lambda r: r["ms"])
+        traffic = pmc_traffic(name, dom["kernel"], wl.B)       # committed PMC pass of THIS workload (profiles/pmc_traffic.json)
+        dom_real = None if not traffic else round(traffic["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         out = {"workload": wl.desc, "frames_per_step": wl.B, "steps": steps,
                "value": round(float(wl.w) * wl.h * wl.B * steps / elapsed / 1e6, 1), "unit": "Mpixels/s",
                "ms_per_step": round(elapsed / steps * 1e3, 4),
-               "dominant": {"kernel": dom["kernel"], "frac": dom["frac"], "ms": dom["ms"]},
+               "dominant": {"kernel": dom["kernel"], "frac": dom["frac"], "ms": dom["ms"], "real_traffic_frac": dom_real,
+                            "traffic": traffic},
                "whole_frame_frac": round(sum(wl.ao.algorithmic_bytes()) * wl.B / (elapsed / steps) / 1e9 / HBM_PEAK_GBPS, 4),
                "passes": rows, "validation_pipelined": check}
         if wl.pipelined:

@@ -407,7 +407,8 @@ typedef enum meao_debug_key {
     MEAO_DEBUG_DS_SIDE_STREAM = 7      /* 0 = off.  gate + 10 * shape: the announced batch's downsample pass runs as its own kernel on a
                                         * second, low-priority stream of the context, released when the call's stream reaches `gate`
                                         * (1 = the full-resolution upsample launch, 2 = L2 -> L1, 3 = the coarse blend launch, 4 = render);
-                                        * shape 0..3 = loads in flight per lane {16 + 120 VGPRs declared, 16, 8, 4}.  Results identical. */
+                                        * shape 0..3 = loads in flight per lane {16 + 120 VGPRs declared, 16, 8, 4}; + 100 * p: stream priority
+                                        * p = 0 lowest, 1 default, 2 highest.  Results identical. */
 } meao_debug_key;
 MEAO_API int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value);
 

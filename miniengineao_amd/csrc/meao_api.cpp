@@ -527,7 +527,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     const int side_gate_at = (ctx->ds_side_stream > 0 && ctx->next_n > 0 && !capturing) ? ctx->ds_side_stream % 10 : 0;
     auto side_downsample_at = [&](int g) -> int {
         if (g != side_gate_at || ctx->next_n == 0) return MEAO_OK;
-        const int other = 1 - ctx->ds_cur, shape = ctx->ds_side_stream / 10;
+        const int other = 1 - ctx->ds_cur, shape = ctx->ds_side_stream / 10 % 10, prio = ctx->ds_side_stream / 100;
         DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, other, 0);
         if (!ds.vec_ok || c.depth_format != MEAO_DEPTH_F32) return MEAO_OK;     // stays with the last kernel (fused form)
         ds.row_passes = shape <= 1 ? 16 : (shape == 2 ? 8 : 4);
@@ -536,7 +536,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         if (!ctx->side_stream) {
             int least = 0, greatest = 0;
             MEAO_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            MEAO_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, least));
+            MEAO_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio == 0 ? least : (prio == 1 ? 0 : greatest)));
             MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->side_gate, hipEventDisableTiming));
             MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
         }
@@ -1324,7 +1324,18 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
-        if (value < 0 || value % 10 > 4 || value / 10 > 3) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");
+        if (value < 0 || value % 10 > 4 || value / 10 % 10 > 3 || value / 100 > 2)
+            return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");
+        if (ctx->side_stream && value / 100 != ctx->ds_side_stream / 100) {       // the stream's priority is fixed at creation
+            const int rc = use_device(ctx);
+            if (rc != MEAO_OK) return rc;
+            (void)hipStreamSynchronize(ctx->side_stream);
+            (void)hipStreamDestroy(ctx->side_stream);
+            (void)hipEventDestroy(ctx->side_gate);
+            (void)hipEventDestroy(ctx->side_done);
+            ctx->side_stream = nullptr; ctx->side_gate = ctx->side_done = nullptr;
+            ctx->side_pending = false;
+        }
         ctx->ds_side_stream = value;
         break;
     default: return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: unknown key");

@@ -79,6 +79,10 @@ constexpr int kUpsPrio[2][4] = {{3, 0, 0, 0}, {3, 1, 2, 3}};
 #ifndef MEAO_X_TWO_LEVEL_WAVES
 #define MEAO_X_TWO_LEVEL_WAVES 8   // waves per SIMD the two-level blend kernel is compiled for (7: 65 VGPRs, 8: 64; 4080 workgroups are 2.28 / 1.99
 #endif                             // rounds of the CUs' slots: 35.3 -> 34.3 us, profiles/r03_ab_two_level_waves.txt)
+#ifndef MEAO_X_HOT_PATH_ONLY
+#define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
+#endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the
+                                // static instruction counts of the ISA are the dynamic ones of (almost) every workgroup
 #ifndef MEAO_X_PHASE_CLOCKS
 #define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py),
 #endif                          // persistent launches log start / end / CU of every workgroup (tools/wg_log.py)
@@ -538,20 +542,121 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleAr
     downsample_tile<RTNE, VEC, DIV>(a, blockIdx.x, blockIdx.z);
 }
 
-// The pass as a CO-RUNNER of the full-resolution upsample launch (meao_debug_set MEAO_DEBUG_DS_SIDE_STREAM): its own kernel
-// on a second, low-priority stream.  The upsample launch keeps seven 4-wave workgroups per CU (LDS), i.e. one wave slot
-// per SIMD and ~120 VGPRs per lane stay free: a co-resident downsample workgroup gets its memory-level parallelism from a
-// deep per-lane queue (PASSES 16-byte loads in flight: a 128 x 8*PASSES tile) instead of from occupancy.
+// The pass as a CO-RUNNER of the VALU-bound launches (meao_debug_set MEAO_DEBUG_DS_SIDE_STREAM): its own kernel on a second,
+// low-priority stream.  Two things differ from the stand-alone pass, which waits on memory and does not care:
+//  * a co-resident workgroup gets its memory-level parallelism from a deep per-lane queue (PASSES 16-byte loads in flight:
+//    a 128 x 8*PASSES tile) instead of from occupancy -- the launches it runs next to leave it one wave slot per SIMD;
+//  * its VALU instructions are taken from kernels that are bound by VALU issue, so there are as few as possible: ~8 per texel
+//    instead of ~18.  Rows are dealt to waves so that a row's parity is wave-uniform (wave w: rows w and w + 4 of every
+//    8-row pass): the waves of odd rows skip the mip stores with a scalar branch, only wave 0 ever sees L2..L4; the range
+//    test of the four denominators is two unsigned min / max chains on their bit patterns (negative values and NaNs are the
+//    largest unsigned words) instead of four v_med3 + four compares; the far-plane select runs only where a lane holds a
+//    far-plane texel; one 32-bit byte offset per buffer, advanced by a uniform stride per row pass (saddr addressing).
+// Same bits as downsample_tile (tests/test_gpu_more.py::test_next_downsample_on_the_side_stream, hostile frames included).
 // PAD_VGPRS: the kernel declares 120 VGPRs whatever it uses, so that exactly one of its workgroups fits next to seven
 // upsample workgroups and the registers a finishing upsample workgroup frees (56) can only go to the next upsample one.
+template <bool RTNE, int DIV, int PASSES, bool FULL>
+__device__ __forceinline__ void downsample_side_tile(const DownsampleArgs &a, int tile, int frame)
+{
+    const uint32_t tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
+    const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+    const uint32_t W = static_cast<uint32_t>(a.w[0]);
+    const int H = a.h[0];
+    const uint32_t x0 = static_cast<uint32_t>(tile_x) * kDsTileW + (tid & 31u) * 4u;
+    const int row = wave + 4 * static_cast<int>((tid >> 5) & 1u);              // rows w, w + 4 of each pass: parity is wave-uniform
+    const int y0 = tile_y * (PASSES * kDsRowsPerPass) + row;
+    if (x0 >= W) return;
+    const float *__restrict__ depth = static_cast<const float *>(a.depth[frame]);
+    uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
+    float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
+    float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
+    float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
+    float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
+    const float zp0 = a.zp0, zp1 = a.zp1;
+    const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
+    const uint32_t w1 = a.w[1], w2 = a.w[2], w3 = a.w[3], w4 = a.w[4];
+
+    // texel index of (x0, y0 + 8k) is t0 + k * 8W.  FULL: every row of the tile is inside the frame
+    const uint32_t t0 = static_cast<uint32_t>(y0) * W + x0, t_step = 8u * W;
+    float4v q[PASSES];
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+        uint32_t t = t0 + static_cast<uint32_t>(k) * t_step;
+        if constexpr (!FULL) t = static_cast<uint32_t>(min(y0 + 8 * k, H - 1)) * W + x0;      // re-reads the last row; never used
+        q[k] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(depth, t * 4u)));
+    }
+    const uint32_t o1 = (static_cast<uint32_t>(y0 >> 1) * w1 + (x0 >> 1)) * 4u, o2 = (static_cast<uint32_t>(y0 >> 2) * w2 + (x0 >> 2)) * 4u;
+    const uint32_t o3 = (static_cast<uint32_t>(y0 >> 3) * w3 + (x0 >> 3)) * 4u, o4 = (static_cast<uint32_t>(y0 >> 4) * w4 + (x0 >> 4)) * 4u;
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+        if constexpr (!FULL) { if (y0 + 8 * k >= H) break; }
+        const float v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+        float lin[4];
+        if constexpr (DIV == DIV_EXACT_RCP) {
+            float den[4];
+            uint32_t bits[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { den[e] = mad(zp0, v[e], zp1); bits[e] = __builtin_bit_cast(uint32_t, den[e]); }
+            // all four denominators in [2^-20, 2^24] (nice_denominator): as unsigned words, negative values and NaNs are the largest
+            const uint32_t lo = min(min(min(bits[0], bits[1]), bits[2]), bits[3]), hi = max(max(max(bits[0], bits[1]), bits[2]), bits[3]);
+            if (__builtin_expect(lo >= 0x35800000u && hi <= 0x4B800000u, 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r = __builtin_amdgcn_rcpf(den[e]);
+                    lin[e] = mad(mad(-den[e], r, 1.0f), r, r);                  // rcp_strict: DS1:40
+                }
+                const bool far = (v[0] == sky_depth) | (v[1] == sky_depth) | (v[2] == sky_depth) | (v[3] == sky_depth);
+                if (__builtin_expect(far, 0)) {                                 // DS1:41-45
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lin[e] = v[e] == sky_depth ? 1e5f : lin[e];
+                    asm volatile("" : "+v"(lin[0]), "+v"(lin[1]), "+v"(lin[2]), "+v"(lin[3]));   // stays a branch: rare lanes only
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[e], zp0, zp1, sky_depth);
+                a.hostile[frame] = a.generation;     // racing stores of the same value
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[e], zp0, zp1, sky_depth);
+        }
+        const uint32_t t = t0 + static_cast<uint32_t>(k) * t_step;
+        typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+        uint2v h;                                                                // LinearZ[st] = dist (DS1:46)
+        if constexpr (RTNE) {
+            h.x = f32_to_f16_bits<true>(lin[0]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[1])) << 16);
+            h.y = f32_to_f16_bits<true>(lin[2]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[3])) << 16);
+        } else {
+            h.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[0], lin[1]));
+            h.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[2], lin[3]));
+        }
+        __builtin_nontemporal_store(h, reinterpret_cast<uint2v *>(at_byte_offset(linear, t * 2u)));
+        if ((wave & 1) == 0) {                                                   // even rows (wave-uniform): DS2x (DS1:64-70)
+            __builtin_nontemporal_store(float2v{lin[0], lin[2]},
+                                        reinterpret_cast<float2v *>(at_byte_offset(low1, o1 + static_cast<uint32_t>(k) * (16u * w1))));
+            if (wave == 0) {                                                     // rows 0, 4 of the pass: DS4x (DS1:73-77)
+                *at_byte_offset(low2, o2 + static_cast<uint32_t>(k) * (8u * w2)) = lin[0];
+                if (row == 0 && (x0 & 7u) == 0) {                                // DS8x (DS2:35-40)
+                    *at_byte_offset(low3, o3 + static_cast<uint32_t>(k) * (4u * w3)) = lin[0];
+                    if ((k & 1) == 0 && (x0 & 15u) == 0)                         // DS16x (DS2:43-49)
+                        *at_byte_offset(low4, o4 + static_cast<uint32_t>(k / 2) * (4u * w4)) = lin[0];
+                }
+            }
+        }
+    }
+}
+
 template <bool RTNE, int DIV, int PASSES, bool PAD_VGPRS>
 __global__ __launch_bounds__(kThreads) void downsample_side_kernel(const DownsampleArgs a)
 {
+    static_assert(PASSES % 2 == 0, "tile rows are a multiple of 16 (the L4 test uses the parity of the pass)");
     if constexpr (PAD_VGPRS) asm volatile("" ::: "v119");
-    float v[PASSES][4];
-    downsample_tile_load<true, true, PASSES, true>(a, blockIdx.x, blockIdx.z, v);
-    downsample_tile_finish<RTNE, true, DIV, PASSES>(a, blockIdx.x, blockIdx.z, v);
+    const int tile = blockIdx.x, frame = blockIdx.z;
+    if ((tile / a.tiles_x + 1) * (PASSES * kDsRowsPerPass) <= a.h[0]) downsample_side_tile<RTNE, DIV, PASSES, true>(a, tile, frame);
+    else downsample_side_tile<RTNE, DIV, PASSES, false>(a, tile, frame);
 }
+
 
 // Small calls (a 1080p frame: 510 tiles of 128 x 32): tiles of one row pass, four times the workgroups, one
 // load-compute-store round each instead of four in a row.
@@ -781,6 +886,7 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n)
 // verified operand range of the exact v_rcp_f32 sequences (see nice_denominator).
 __device__ __forceinline__ bool frame_is_hostile(const uint32_t *hostile, uint32_t generation, int frame)
 {
+    if constexpr (MEAO_X_HOT_PATH_ONLY) return false;
     return __builtin_nontemporal_load(hostile + frame) == generation;
 }
 
@@ -1295,15 +1401,16 @@ __device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, int til
             const int hy_raw = HY0 + 2 * ((tid >> 4) + 16 * pass) + f;
             const int hy = CLAMPED ? min(hy_raw, hh - 1) : hy_raw;
             if (CLAMPED || (hhx0 < hw && hy < hh)) {
-                const size_t hrow = static_cast<size_t>(hy) * hw + hhx0;
+                // texel index in the level (< 2^27): 32-bit byte offsets from the frame's uniform bases (saddr addressing)
+                const uint32_t hrow = static_cast<uint32_t>(hy * hw + hhx0);
                 if constexpr (FINAL) {
-                    L.hd16[pass][f] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(
-                        frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow));
+                    L.hd16[pass][f] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(at_byte_offset(
+                        frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame), hrow * 2u)));
                 } else {
-                    L.hd32[pass][f] = *reinterpret_cast<const float4v *>(
-                        frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow);
-                    L.ha[pass][f] = *reinterpret_cast<const typename AO::type4 *>(
-                        frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow);
+                    L.hd32[pass][f] = *reinterpret_cast<const float4v *>(at_byte_offset(
+                        frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame), hrow * 4u));
+                    L.ha[pass][f] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(
+                        frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame), hrow * static_cast<uint32_t>(sizeof(ao_t))));
                 }
             }
         }
@@ -1328,9 +1435,9 @@ __device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, 
         const int i = min(tid + round * kThreads, Loads::kItems - 1);
         const int r = i / 10, k = i % 10;
         const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
-        const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
-        L.wd[round] = *reinterpret_cast<const float4v *>(lo_depth + idx);
-        L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
+        const uint32_t idx = static_cast<uint32_t>(cy * lw + (LX0 - 4 + 4 * k));
+        L.wd[round] = *reinterpret_cast<const float4v *>(at_byte_offset(lo_depth, idx * 4u));
+        L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(lo_ao, idx * static_cast<uint32_t>(sizeof(ao_t))));
     }
     if constexpr (!WINDOW_ONLY) {
         __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
@@ -1364,7 +1471,8 @@ __device__ __forceinline__ void ups_store_results(const UpsampleArgs &a, int til
         for (int f = 0; f < 2; ++f) {
             const int hy = HY0 + 2 * ((tid >> 4) + 16 * pass) + f;
             if (hy < a.hh) {
-                typename AO::type4 *o = reinterpret_cast<typename AO::type4 *>(dst + static_cast<size_t>(hy) * a.hw + hx0);
+                typename AO::type4 *o = reinterpret_cast<typename AO::type4 *>(
+                    at_byte_offset(dst, static_cast<uint32_t>(hy * a.hw + hx0) * static_cast<uint32_t>(sizeof(ao_t))));
                 const typename AO::type4 v = __builtin_bit_cast(typename AO::type4, R.r4[pass][f]);
                 if constexpr (FINAL) __builtin_nontemporal_store(v, o);
                 else *o = v;
@@ -1446,9 +1554,9 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     auto &hoist_hd16 = L.hd16;
     auto &hoist_hd32 = L.hd32;
     auto &hoist_ha = L.ha;
-    const bool hoist_ok = a.vec_ok != 0;
+    const bool hoist_ok = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;
     // interior tile, 16-byte loads everywhere, no second AO input: window loads first (ups_issue_interior_loads)
-    const bool window_first = PRELOADED || (!NESTED && ups_tile_is_interior<FINAL, TILE_H>(a, tile));
+    const bool window_first = PRELOADED || (!NESTED && (MEAO_X_HOT_PATH_ONLY || ups_tile_is_interior<FINAL, TILE_H>(a, tile)));
     if constexpr (!PRELOADED)
         if (hoist_ok && !window_first) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false>(a, tile, frame, L);
 
@@ -1618,7 +1726,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     if constexpr (kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][3] != 0) __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][3]);
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
                                    : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
-    const bool vec_ok = a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
+    const bool vec_ok = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
     // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
     constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
     const int tx = tid & 15;
@@ -1732,7 +1840,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                     bilateral_k);
                 res[e] = AO::template encode<RTNE>(v);
             }
-            ao_t *o = dst + hrow;
+            ao_t *o = vec_ok ? at_byte_offset(dst, static_cast<uint32_t>(hy * hw + hx0) * static_cast<uint32_t>(sizeof(ao_t))) : dst + hrow;
             if (vec_ok) {
                 typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
                 // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
@@ -1810,68 +1918,92 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
 
     // The hi-res operands of the bilateral step depend on nothing computed here: loaded now, used three
     // barriers later (at most 38 x 22 window texels: four per lane).
-    constexpr int kHoisted = (38 * 22 + kThreads - 1) / kThreads;
+    constexpr int kHoisted = (40 * 22 + kThreads - 1) / kThreads;          // items on the output pitch: at most 40 x 22
     float hoist_d[kHoisted];
     ao_t hoist_a[kHoisted];
+    // (window items on the output array's pitch, a compile-time value at every call site; see the loops below)
 #pragma unroll
     for (int j = 0; j < kHoisted; ++j) {
-        const int i = min(static_cast<int>(threadIdx.x) + j * kThreads, win_w * win_h - 1);
-        const int X = clampi(vx0 + i % win_w, 0, hw - 1), Y = clampi(vy0 + i / win_w, 0, hh - 1);
-        const size_t at = static_cast<size_t>(Y) * hw + X;
-        hoist_d[j] = hi_depth[at];
-        hoist_a[j] = hi_ao[at];
+        const int i = min(static_cast<int>(threadIdx.x) + j * kThreads, out_pitch * win_h - 1);
+        const int X = clampi(vx0 + min(i % out_pitch, win_w - 1), 0, hw - 1), Y = clampi(vy0 + i / out_pitch, 0, hh - 1);
+        const uint32_t at = static_cast<uint32_t>(Y * hw + X);
+        hoist_d[j] = *at_byte_offset(hi_depth, at * 4u);
+        hoist_a[j] = *at_byte_offset(hi_ao, at * static_cast<uint32_t>(sizeof(ao_t)));
     }
 
-    for (int i = threadIdx.x; i < rw * rh; i += kThreads) {
-        const int r = i / rw, c = i % rw;
-        const size_t idx = static_cast<size_t>(clampi(ry0 + r, 0, lh - 1)) * lw + clampi(rx0 + c, 0, lw - 1);
-        const float d = lo_depth[idx];
-        r_dep[r * kNestRawW + c] = d;
-        r_inv[r * kNestRawW + c] = rcp_strict<DIV>(d);                       // UPS:67
-        if constexpr (!TAPS_IN_LDS) r_ao[r * kNestRawW + c] = AO::decode(lo_ao[idx]);
+    // Work items are laid out on the arrays' compile-time pitches (item i = row i / pitch, column i % pitch; columns past the
+    // extent idle): the extents are run-time values, and a division by one costs ~25 VALU instructions where a division by
+    // a constant costs three -- the four loops of this function did eight of them per lane (a third of the two-level
+    // kernel's instructions were integer arithmetic, profiles/r03_pmc_summary.txt).
+    for (int i = threadIdx.x; i < kNestRawW * rh; i += kThreads) {
+        const int r = i / kNestRawW, c = i % kNestRawW;
+        if (c >= rw) continue;
+        const uint32_t idx = static_cast<uint32_t>(clampi(ry0 + r, 0, lh - 1) * lw + clampi(rx0 + c, 0, lw - 1));   // a level is < 2^30 texels
+        const float d = *at_byte_offset(lo_depth, idx * 4u);
+        r_dep[i] = d;
+        r_inv[i] = rcp_strict<DIV>(d);                                          // UPS:67
+        if constexpr (!TAPS_IN_LDS) r_ao[i] = AO::decode(*at_byte_offset(lo_ao, idx * static_cast<uint32_t>(sizeof(ao_t))));
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nlw * rh; i += kThreads) {                     // BlurHorizontally, one output per lane
-        const int r = i / nlw, c = i % nlw;
+    for (int i = threadIdx.x; i < kNestLowW * rh; i += kThreads) {               // BlurHorizontally, one output per lane
+        const int r = i / kNestLowW, c = i % kNestLowW;
+        if (c >= nlw) continue;
         float av[5], zv[5], o[1];
 #pragma unroll
         for (int t = 0; t < 5; ++t) { av[t] = r_ao[r * kNestRawW + c + t]; zv[t] = r_inv[r * kNestRawW + c + t]; }
         blur_run<1>(bk, av, zv, o);
-        hb[r * kNestLowW + c] = o[0];
+        hb[i] = o[0];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nlw * nlh; i += kThreads) {                    // BlurVertically
-        const int r = i / nlw, c = i % nlw;
-        float av[5], zv[5], o[1];
+    // BlurVertically.  The interior extent (20 x 12 = 240 outputs) is one round of the workgroup on a pitch of 20
+    auto blur_vertically = [&](auto pitch_c) {
+        constexpr int kPitch = decltype(pitch_c)::value;
+        for (int i = threadIdx.x; i < kPitch * nlh; i += kThreads) {
+            const int r = i / kPitch, c = i % kPitch;
+            if (kPitch != kNestLowW || c < nlw) {
+                float av[5], zv[5], o[1];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) { av[t] = hb[(r + t) * kNestLowW + c]; zv[t] = r_inv[(r + t) * kNestRawW + c + 2]; }
-        blur_run<1>(bk, av, zv, o);
-        vb[r * kNestLowW + c] = o[0];
-    }
+                for (int t = 0; t < 5; ++t) { av[t] = hb[(r + t) * kNestLowW + c]; zv[t] = r_inv[(r + t) * kNestRawW + c + 2]; }
+                blur_run<1>(bk, av, zv, o);
+                vb[r * kNestLowW + c] = o[0];
+            }
+        }
+    };
+    if (nlw == kNestLowW - 1) blur_vertically(std::integral_constant<int, kNestLowW - 1>());
+    else blur_vertically(std::integral_constant<int, kNestLowW>());
     __syncthreads();
-    constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};                // Gather order, as in upsample_tile
 #pragma unroll
     for (int j = 0; j < kHoisted; ++j) {
         const int i = threadIdx.x + j * kThreads;
-        if (i >= win_w * win_h) break;
-        const int wr = i / win_w, wc = i % win_w;
+        if (i >= out_pitch * win_h) break;
+        const int wr = i / out_pitch, wc = i % out_pitch;
+        if (wc >= win_w) continue;
         const int X = clampi(vx0 + wc, 0, hw - 1), Y = clampi(vy0 + wr, 0, hh - 1);
         const int Dx = (X + 1) >> 1, Dy = (Y + 1) >> 1;
-        const int comp = (X & 1) ? ((Y & 1) ? 3 : 0) : ((Y & 1) ? 2 : 1);
+        // Tap k of the texel is Gather component g = (comp + k) & 3 of dispatch thread D: texel D + (gx[g], gy[g]), i.e. the four
+        // texels {Dx - 1, Dx} x {Dy - 1, Dy} in an order that rotates with the texel's parity (comp, UPS:229-232).  comp is a per-lane
+        // value here (the window is dealt to lanes linearly), so the taps' byte distances below D in either array -- {4, 0, pitch * 4,
+        // pitch * 4 + 4} for g = 0..3 -- sit in one word that is rotated by comp bytes: five integer operations for four addresses.
+        // (Indexing gx[] / gy[] with the run-time g made the compiler put the tables in memory: eight global loads per texel.)
+        const uint32_t comp = ((static_cast<uint32_t>(Y) & 1u) << 1) | (((static_cast<uint32_t>(X ^ Y)) & 1u) ^ 1u);   // (X odd, Y odd): (1,0) 0, (0,0) 1, (0,1) 2, (1,1) 3
+        constexpr uint32_t kBelowVb = 4u | (0u << 8) | (static_cast<uint32_t>(kNestLowW * 4) << 16) | (static_cast<uint32_t>(kNestLowW * 4 + 4) << 24);
+        constexpr uint32_t kBelowDep = 4u | (0u << 8) | (static_cast<uint32_t>(kNestRawW * 4) << 16) | (static_cast<uint32_t>(kNestRawW * 4 + 4) << 24);
+        static_assert(kNestLowW * 4 + 4 < 256 && kNestRawW * 4 + 4 < 256, "byte fields");
+        const uint32_t below_vb = __builtin_amdgcn_alignbit(kBelowVb, kBelowVb, comp * 8u), below_dep = __builtin_amdgcn_alignbit(kBelowDep, kBelowDep, comp * 8u);
+        const char *const vb_at_d = reinterpret_cast<const char *>(vb + ((Dy - dy_lo) * kNestLowW + (Dx - dx_lo)));
+        const char *const dep_at_d = reinterpret_cast<const char *>(r_dep + ((Dy - ry0) * kNestRawW + (Dx - rx0)));
         float dk[4], ak[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int g = (comp + k) & 3;
-            const int lx = Dx + gx[g], ly = Dy + gy[g];
-            ak[k] = vb[(ly - dy_lo) * kNestLowW + (lx - dx_lo)];
-            dk[k] = r_dep[(ly - ry0) * kNestRawW + (lx - rx0)];
+            ak[k] = *reinterpret_cast<const float *>(vb_at_d - ((below_vb >> (8 * k)) & 0xffu));
+            dk[k] = *reinterpret_cast<const float *>(dep_at_d - ((below_dep >> (8 * k)) & 0xffu));
         }
-        const size_t at = static_cast<size_t>(Y) * hw + X;
+        const uint32_t at = static_cast<uint32_t>(Y * hw + X) * static_cast<uint32_t>(sizeof(ao_t));      // byte offset in the level
         float v;
         if constexpr (!MEAO_X_UPS_EXACT_R8 && DIV == DIV_EXACT_RCP && AOFMT == MEAO_AO_R8) {
             const ao_t q = static_cast<ao_t>(bilateral_upsample_r8<true>(hoist_d[j], AO::decode(hoist_a[j]), dk, ak, bilateral_k));
-            out[wr * out_pitch + wc] = AO::decode(q);
-            if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) dst[at] = q;
+            out[i] = AO::decode(q);
+            if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) *at_byte_offset(dst, at) = q;
             continue;
         }
         if constexpr (DIV == DIV_EXACT_RCP) {       // the four weight reciprocals back to back (see upsample_tile)
@@ -1885,8 +2017,8 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
                                         bilateral_k);
         }
         const ao_t q = AO::template encode<RTNE>(v);
-        out[wr * out_pitch + wc] = AO::decode(q);
-        if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) dst[at] = q;
+        out[i] = AO::decode(q);
+        if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) *at_byte_offset(dst, at) = q;
     }
     __syncthreads();
 }

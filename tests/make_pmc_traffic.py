@@ -21,13 +21,13 @@ import sys
 KERNELS = {
     "downsample_kernel": ("downsample", 2.0, "reads are one 16 B/lane stream: FETCH_SIZE x2 (calibrated: equals 4*W*H bytes/frame)"),
     "render_kernel": ("render", 2.0, "window fill is 16 B/lane: FETCH_SIZE x2"),
-    "upsample_kernel<0, false, true": ("upsample_L1_to_L0", 1.0, "8 B/lane (f16 depth) + 16 B/lane + 4 B/lane reads: FETCH_SIZE left raw (uncalibrated width); raw value equals compulsory + apron bytes"),
-    "upsample_kernel<0, false, false": ("upsample_blend_passes", 1.0, "mean of the stand-alone main_blendout launches (L2->L1 only when L4->L3 rides inside L3->L2); FETCH_SIZE raw"),
-    "upsample_two_level_kernel<0, false": ("upsample_L4_to_L3+L3_to_L2", 1.0, "the fused two-level launch; FETCH_SIZE raw"),
+    "upsample_kernel<A, false, true": ("upsample_L1_to_L0", 1.0, "8 B/lane (f16 depth) + 16 B/lane + 4 B/lane reads: FETCH_SIZE left raw (uncalibrated width); raw value equals compulsory + apron bytes"),
+    "upsample_kernel<A, false, false": ("upsample_blend_passes", 1.0, "mean of the stand-alone main_blendout launches (L2->L1 only when L4->L3 rides inside L3->L2); FETCH_SIZE raw"),
+    "upsample_two_level_kernel<A, false": ("upsample_L4_to_L3+L3_to_L2", 1.0, "the fused two-level launch; FETCH_SIZE raw"),
     # the last upsample kernel carrying the next batch's downsample pass (meao_prefetch_batch): the carried
     # 16 B/lane depth stream (4*W*H bytes per frame, known exactly) is tallied at half size like in
     # downsample_kernel, the upsample reads are raw -> add the missing half of the depth stream
-    "upsample_final_with_next_downsample_kernel<0, false": ("upsample_L1_to_L0+downsample_next", 1.0,
+    "upsample_final_with_next_downsample_kernel<A, false": ("upsample_L1_to_L0+downsample_next", 1.0,
                                                            "FETCH_SIZE raw + 2*W*H bytes per frame (the half of the carried 16 B/lane depth stream that the counter misses)"),
 }
 DEPTH_STREAM_HALF = {"4k": 2 * 3840 * 2160, "1080p": 2 * 1920 * 1080, "8k": 2 * 7680 * 4320}
@@ -47,7 +47,9 @@ def main():
     fetch, write = mean_counter(root, "fetch", "FETCH_SIZE"), mean_counter(root, "write", "WRITE_SIZE")
     valu = mean_counter(root, "sq1", "SQ_INSTS_VALU")      # VALU wave-instructions per dispatch, whole GPU
     table = {}
+    ao = "1" if workload == "8k" else "0"          # AOFMT template argument of the workload's kernels (8K: fp16 AO storage)
     for frag, (name, factor, note) in KERNELS.items():
+        frag = frag.replace("<A,", f"<{ao},")
         f = [v for k, v in fetch.items() if frag in k]
         w = [v for k, v in write.items() if frag in k]
         if not f or not w:
@@ -67,7 +69,9 @@ def main():
     except OSError:
         full = {}
     full[workload] = table
-    full["_tag"] = os.path.basename(os.path.normpath(root)).replace("pmc_", "")
+    full.setdefault("_tags", {"4k": full.get("_tag", "(untagged)")} if "4k" in full and workload != "4k" else {})
+    full["_tags"][workload] = os.path.basename(os.path.normpath(root)).replace("pmc_", "")
+    full["_tag"] = full["_tags"].get("4k", full["_tags"][workload])
     full["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tests/run_pmc.sh); see tests/make_pmc_traffic.py"
     json.dump(full, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(table, indent=1))
