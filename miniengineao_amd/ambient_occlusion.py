@@ -291,12 +291,13 @@ class AmbientOcclusionPool:
     def __init__(self, width: int, height: int, devices: Sequence[int], *, max_batch: int = 1,
                  ao_format: int = L.AO_R8, near_clip: float = 0.3, far_clip: float = 1000.0,
                  projection00: Optional[float] = None, reversed_z: bool = True, intensity: float = 1.0,
-                 pipelined: bool = False):
+                 pipelined: bool = False, launch_mode: int = L.LAUNCH_DIRECT):
         self._lib = L.load()
         cfg = L.Config()
         self._lib.meao_default_config(C.byref(cfg))
         cfg.width, cfg.height, cfg.max_batch, cfg.ao_format = width, height, max_batch, ao_format
         cfg.pipelined = 1 if pipelined else 0
+        cfg.launch_mode = launch_mode
         self._cfg = cfg
         self.devices = list(devices)
         self._pool = C.c_void_p()

@@ -82,6 +82,7 @@ struct meao_ctx {
     // it), 2 = in front of L2->L1, 3 = in front of the coarse blend launch, 4 = in front of render; shape 0 = 16 loads
     // per lane in flight, 120 VGPRs declared, 1 = 16 loads, 2 = 8 loads, 3 = 4 loads (the stand-alone pass's tile).
     int ds_side_stream = 0;
+    int render_tile_h = 0;             // MEAO_DEBUG_RENDER_TILE_H: 64 = the 128 x 64 / 1024-thread render tiles (checker set, interleaved pass)
     hipStream_t side_stream = nullptr;
     hipEvent_t side_gate = nullptr, side_done = nullptr;
     bool side_pending = false;         // a side-stream downsample was issued and no later execute has ordered itself behind it yet
@@ -431,6 +432,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             for (int l = first; l <= last; ++l)
                 tiles32 += ((p.mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p.mip[l].h + kRenTileH - 1) / kRenTileH);
             if (n * tiles32 <= ctx->render_small_max_tiles) tile_h = kRenTileHSmall;
+            else if (ctx->render_tile_h == kRenTileHTall && ctx->pending_comp.frames == 0) tile_h = kRenTileHTall;
         }
         rn.tile_h = tile_h;
         for (int l = first; l <= last; ++l) {
@@ -521,40 +523,60 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         return MEAO_OK;
     };
 
-    // MEAO_DEBUG_DS_SIDE_STREAM: the announced batch's downsample pass as its own kernel on the side stream, released
-    // when `stream` reaches gate `g` of this call.  (The set it writes was last read by the PREVIOUS call's kernels,
-    // all in front of every gate in stream order; the next execute waits for side_done before anything else.)
-    const int side_gate_at = (ctx->ds_side_stream > 0 && ctx->next_n > 0 && !capturing) ? ctx->ds_side_stream % 10 : 0;
+    // MEAO_DEBUG_DS_SIDE_STREAM: the announced batch's downsample pass as its own kernel(s) on the side stream, released when
+    // `stream` reaches a gate of this call: all frames at gate A, or the first `split` tenths of them there and the rest at a
+    // later gate B.  (The set they write was last read by the PREVIOUS call's kernels, all in front of every gate in stream
+    // order; the next execute waits for side_done before anything else.)
+    struct SidePlan { bool active = false; int total = 0, first_part = 0, issued = 0, gate_a = 0, gate_b = 0, shape = 0, prio = 0, other = 0; } side;
+    if (ctx->ds_side_stream > 0 && ctx->next_n > 0 && !capturing && c.depth_format == MEAO_DEPTH_F32 &&
+        downsample_args(ctx->next_n, ctx->next_depth, 1 - ctx->ds_cur, 0).vec_ok) {      // anything else stays with the last kernel (fused form)
+        const int v = ctx->ds_side_stream, split = v / 1000 % 10;
+        side.active = true;
+        side.total = ctx->next_n;
+        side.gate_a = v % 10; side.shape = v / 10 % 10; side.prio = v / 100 % 10;
+        side.gate_b = v / 10000 % 10 ? v / 10000 % 10 : 1;
+        side.first_part = (split == 0 || side.gate_b >= side.gate_a) ? side.total
+                                                                     : std::min(side.total, std::max(1, (side.total * split + 9) / 10));
+        side.other = 1 - ctx->ds_cur;
+    }
     auto side_downsample_at = [&](int g) -> int {
-        if (g != side_gate_at || ctx->next_n == 0) return MEAO_OK;
-        const int other = 1 - ctx->ds_cur, shape = ctx->ds_side_stream / 10 % 10, prio = ctx->ds_side_stream / 100;
-        DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, other, 0);
-        if (!ds.vec_ok || c.depth_format != MEAO_DEPTH_F32) return MEAO_OK;     // stays with the last kernel (fused form)
-        ds.row_passes = shape <= 1 ? 16 : (shape == 2 ? 8 : 4);
-        ds.tiles_y = (p.mip[0].h + ds.row_passes * kDsRowsPerPass - 1) / (ds.row_passes * kDsRowsPerPass);
-        ds.tile_end = ds.tiles_x * ds.tiles_y;
+        if (!side.active || side.issued == side.total) return MEAO_OK;
+        int first, count;
+        if (g == side.gate_a && side.issued == 0) { first = 0; count = side.first_part; }
+        else if (g == side.gate_b && side.issued == side.first_part) { first = side.issued; count = side.total - first; }
+        else return MEAO_OK;
         if (!ctx->side_stream) {
             int least = 0, greatest = 0;
             MEAO_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            MEAO_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio == 0 ? least : (prio == 1 ? 0 : greatest)));
+            MEAO_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking,
+                                                      side.prio == 0 ? least : (side.prio == 1 ? 0 : greatest)));
             MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->side_gate, hipEventDisableTiming));
             MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
         }
-        ctx->set_gen[other] = next_generation();
-        ds.generation = ctx->set_gen[other];
+        if (first == 0) ctx->set_gen[side.other] = next_generation();       // one generation for all parts
+        DownsampleArgs ds = downsample_args(count, ctx->next_depth + first, side.other, ctx->set_gen[side.other]);
+        ds.linear = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(ds.linear) + ctx->slot_bytes * first);    // frames [first, first + count)
+        for (int k = 0; k < 4; ++k) ds.low[k] = reinterpret_cast<float *>(reinterpret_cast<char *>(ds.low[k]) + ctx->slot_bytes * first);
+        ds.hostile += first;
+        ds.row_passes = side.shape <= 1 ? 16 : (side.shape == 2 ? 8 : 4);
+        ds.tiles_y = (p.mip[0].h + ds.row_passes * kDsRowsPerPass - 1) / (ds.row_passes * kDsRowsPerPass);
+        ds.tile_end = ds.tiles_x * ds.tiles_y;
         TraceRange tr(ctx, "meao:downsample_next(side stream)");
         MEAO_HIP(ctx, hipEventRecord(ctx->side_gate, stream));
         MEAO_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_gate, 0));
-        MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
-        MEAO_HIP(ctx, launch_downsample_side(ds, ctx->next_n, shape == 0, ctx->side_stream));
-        MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
-        MEAO_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
+        if (first == 0) MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
+        MEAO_HIP(ctx, launch_downsample_side(ds, count, side.shape == 0, ctx->side_stream));
+        side.issued = first + count;
         ctx->side_pending = true;
-        ctx->ready_n = ctx->next_n;
-        ctx->ready_set = other;
-        ctx->ready_stream = stream;
-        std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
-        ctx->next_n = 0;
+        if (side.issued == side.total) {
+            MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));      // the slot spans all parts (and the wait between them)
+            MEAO_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
+            ctx->ready_n = ctx->next_n;
+            ctx->ready_set = side.other;
+            ctx->ready_stream = stream;
+            std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
+            ctx->next_n = 0;
+        }
         return MEAO_OK;
     };
 
@@ -612,7 +634,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     uint32_t next_gen = 0;
     if (c.num_levels >= 2 && !blend_done) {
         const UpsampleArgs up1 = upsample_args(1);
-        if (ctx->next_n > 0 && ctx->ds_share_in_blend > 0 && ctx->next_n <= n) {
+        if (ctx->next_n > 0 && ctx->ds_share_in_blend > 0 && ctx->next_n <= n && !side.active) {
             next_gen = next_generation();
             DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, 1 - ctx->ds_cur, next_gen);
             const int blend_tiles = up1.tiles_x * up1.tiles_y, ds_tiles = ds.tiles_x * ds.tiles_y;
@@ -1323,10 +1345,14 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
+    case MEAO_DEBUG_RENDER_TILE_H:
+        if (value != 0 && value != kRenTileH && value != kRenTileHTall) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: RENDER_TILE_H is 0, 32 or 64");
+        ctx->render_tile_h = value;
+        break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
-        if (value < 0 || value % 10 > 4 || value / 10 % 10 > 3 || value / 100 > 2)
+        if (value < 0 || value % 10 > 4 || value / 10 % 10 > 3 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
             return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");
-        if (ctx->side_stream && value / 100 != ctx->ds_side_stream / 100) {       // the stream's priority is fixed at creation
+        if (ctx->side_stream && value / 100 % 10 != ctx->ds_side_stream / 100 % 10) {       // the stream's priority is fixed at creation
             const int rc = use_device(ctx);
             if (rc != MEAO_OK) return rc;
             (void)hipStreamSynchronize(ctx->side_stream);

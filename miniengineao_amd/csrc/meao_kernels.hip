@@ -897,11 +897,11 @@ struct NoRenderHook {
     __device__ __forceinline__ void end(int) {}
 };
 
-template <int AOFMT, bool RTNE, int DIV, bool EXH, typename Hook = NoRenderHook, int TILE_H = kRenTileH>
+template <int AOFMT, bool RTNE, int DIV, bool EXH, typename Hook = NoRenderHook, int TILE_H = kRenTileH, int THREADS = ren_tile_w(EXH) * 4>
 __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, int frame, int block, Hook hook = Hook())
 {
     typedef AoTexel<AOFMT> AO;
-    constexpr int kRenTileW = ren_tile_w(EXH), kRenThreads = kRenTileW * 4, kRenLdsW = kRenTileW + 2 * kRenApron;
+    constexpr int kRenTileW = ren_tile_w(EXH), kRenThreads = THREADS, kRenLdsW = kRenTileW + 2 * kRenApron;
     constexpr int kRenTileH = TILE_H, kRenLdsH = TILE_H + 2 * kRenApron;      // shadow the 32-row constants
 
     int b = block, lv = 0;
@@ -976,8 +976,10 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     constexpr int kBlocksX = kRenTileW / 32, kWaves = kRenThreads / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
+    constexpr int kIterations = kBlocksX * (kRenTileH / 4) / kWaves;        // 32 x 4 blocks of the tile per wave
+    static_assert(kIterations * kWaves == kBlocksX * (kRenTileH / 4), "the tile's blocks divide evenly among the waves");
 #pragma unroll 1
-    for (int k = 0; k < kRenTileH / 8; ++k) {
+    for (int k = 0; k < kIterations; ++k) {
         const int blk = k * kWaves + wave;
         const int txl = (blk % kBlocksX) * 16 + (lane & 15), ly = (blk / kBlocksX) * 4 + (lane >> 4);
         const int X = X0 + 2 * txl, Y = Y0 + ly;
@@ -1033,6 +1035,22 @@ __global__ __launch_bounds__(ren_tile_w(EXH) * 4, EXH ? 1 : 8) void render_kerne
                                    (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11))) << 8);
     }
 #endif
+}
+
+// Experiment (meao_debug_set MEAO_DEBUG_RENDER_TILE_H 64): 128 x 64 tiles, 1024 threads, a 60 KB window -- two
+// workgroups = 32 waves per CU as before, apron share 1.875x instead of 2.5x, half the workgroup hand-overs per texel.
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(1024, 8) void render_tall_kernel(const RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[(kRenTileHTall + 2 * kRenApron) * (ren_tile_w(false) + 2 * kRenApron)];
+    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(a.hostile, a.generation, frame)) {
+            render_tile<AOFMT, RTNE, DIV_IEEE, false, NoRenderHook, kRenTileHTall, 1024>(a, tile, frame, block);
+            return;
+        }
+    }
+    render_tile<AOFMT, RTNE, DIV, false, NoRenderHook, kRenTileHTall, 1024>(a, tile, frame, block);
 }
 
 // One or two small frames per call (fewer 128 x 32 tiles than CUs): 128 x 8 tiles, four times the workgroups,
@@ -2765,13 +2783,14 @@ hipError_t launch_downsample_side(const DownsampleArgs &a, int frames, bool pad_
 template <bool WIDE, int AOFMT, bool RTNE, int DIV>
 static void launch_render_t(const RenderArgs &a, dim3 grid, hipStream_t s)
 {
-    const dim3 block(WIDE ? kThreads : ren_tile_w(a.exhaustive != 0) * 4);
+    const dim3 block(WIDE ? kThreads : (a.tile_h == kRenTileHTall ? 1024 : ren_tile_w(a.exhaustive != 0) * 4));
     if constexpr (WIDE) {
         if (a.exhaustive) render_wide_kernel<AOFMT, RTNE, DIV, true><<<grid, block, 0, s>>>(a);
         else render_wide_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);
     } else {
         if (a.exhaustive) render_kernel<AOFMT, RTNE, DIV, true><<<grid, block, 0, s>>>(a);
         else if (a.tile_h == kRenTileHSmall) render_small_kernel<AOFMT, RTNE, DIV><<<grid, block, 0, s>>>(a);
+        else if (a.tile_h == kRenTileHTall) render_tall_kernel<AOFMT, RTNE, DIV><<<grid, block, 0, s>>>(a);
         else render_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);
     }
 }
