@@ -82,7 +82,6 @@ struct meao_ctx {
     // it), 2 = in front of L2->L1, 3 = in front of the coarse blend launch, 4 = in front of render; shape 0 = 16 loads
     // per lane in flight, 120 VGPRs declared, 1 = 16 loads, 2 = 8 loads, 3 = 4 loads (the stand-alone pass's tile).
     int ds_side_stream = 0;
-    int render_tile_h = 0;             // MEAO_DEBUG_RENDER_TILE_H: 64 = the 128 x 64 / 1024-thread render tiles (checker set, interleaved pass)
     hipStream_t side_stream = nullptr;
     hipEvent_t side_gate = nullptr, side_done = nullptr;
     bool side_pending = false;         // a side-stream downsample was issued and no later execute has ordered itself behind it yet
@@ -432,7 +431,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             for (int l = first; l <= last; ++l)
                 tiles32 += ((p.mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p.mip[l].h + kRenTileH - 1) / kRenTileH);
             if (n * tiles32 <= ctx->render_small_max_tiles) tile_h = kRenTileHSmall;
-            else if (ctx->render_tile_h == kRenTileHTall && ctx->pending_comp.frames == 0) tile_h = kRenTileHTall;
         }
         rn.tile_h = tile_h;
         for (int l = first; l <= last; ++l) {
@@ -558,14 +556,14 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         ds.linear = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(ds.linear) + ctx->slot_bytes * first);    // frames [first, first + count)
         for (int k = 0; k < 4; ++k) ds.low[k] = reinterpret_cast<float *>(reinterpret_cast<char *>(ds.low[k]) + ctx->slot_bytes * first);
         ds.hostile += first;
-        ds.row_passes = side.shape <= 1 ? 16 : (side.shape == 2 ? 8 : 4);
+        ds.row_passes = side.shape <= 1 ? 16 : (side.shape == 2 || side.shape == 4 ? 8 : 4);       // shape 4: 8 loads, 120 VGPRs declared
         ds.tiles_y = (p.mip[0].h + ds.row_passes * kDsRowsPerPass - 1) / (ds.row_passes * kDsRowsPerPass);
         ds.tile_end = ds.tiles_x * ds.tiles_y;
         TraceRange tr(ctx, "meao:downsample_next(side stream)");
         MEAO_HIP(ctx, hipEventRecord(ctx->side_gate, stream));
         MEAO_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_gate, 0));
         if (first == 0) MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
-        MEAO_HIP(ctx, launch_downsample_side(ds, count, side.shape == 0, ctx->side_stream));
+        MEAO_HIP(ctx, launch_downsample_side(ds, count, side.shape == 0 || side.shape == 4, ctx->side_stream));
         side.issued = first + count;
         ctx->side_pending = true;
         if (side.issued == side.total) {
@@ -1345,12 +1343,8 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
-    case MEAO_DEBUG_RENDER_TILE_H:
-        if (value != 0 && value != kRenTileH && value != kRenTileHTall) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: RENDER_TILE_H is 0, 32 or 64");
-        ctx->render_tile_h = value;
-        break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
-        if (value < 0 || value % 10 > 4 || value / 10 % 10 > 3 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
+        if (value < 0 || value % 10 > 4 || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
             return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");
         if (ctx->side_stream && value / 100 % 10 != ctx->ds_side_stream / 100 % 10) {       // the stream's priority is fixed at creation
             const int rc = use_device(ctx);

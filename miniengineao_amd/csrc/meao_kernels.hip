@@ -1037,22 +1037,11 @@ __global__ __launch_bounds__(ren_tile_w(EXH) * 4, EXH ? 1 : 8) void render_kerne
 #endif
 }
 
-// Experiment (meao_debug_set MEAO_DEBUG_RENDER_TILE_H 64): 128 x 64 tiles, 1024 threads, a 60 KB window -- two
-// workgroups = 32 waves per CU as before, apron share 1.875x instead of 2.5x, half the workgroup hand-overs per texel.
-template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(1024, 8) void render_tall_kernel(const RenderArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float tile[(kRenTileHTall + 2 * kRenApron) * (ren_tile_w(false) + 2 * kRenApron)];
-    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
-    if constexpr (DIV == DIV_EXACT_RCP) {
-        if (frame_is_hostile(a.hostile, a.generation, frame)) {
-            render_tile<AOFMT, RTNE, DIV_IEEE, false, NoRenderHook, kRenTileHTall, 1024>(a, tile, frame, block);
-            return;
-        }
-    }
-    render_tile<AOFMT, RTNE, DIV, false, NoRenderHook, kRenTileHTall, 1024>(a, tile, frame, block);
-}
-
+// (128 x 64 tiles with 1024 threads -- a 60 KB window, two workgroups = 32 waves per CU, apron share 1.875x instead of 2.5x, half
+// the hand-overs per texel -- measured 170.2 vs 166.2 us per 16 frames at 4K, profiles/r04_ab_render_tile_128x64.jsonl: the
+// barrier of sixteen waves and a hand-over that idles half a CU cost more than the smaller apron saves.  With 96 x 32 (r03),
+// 64 x 32 (r01) and the dynamic blocks (r03) that closes the tile-shape question: render runs at 2.98 cycles per VALU
+// instruction, the hand-over of a full CU's LDS is what separates it from the 2.4-2.55 of its loop, and no shape removes it.)
 // One or two small frames per call (fewer 128 x 32 tiles than CUs): 128 x 8 tiles, four times the workgroups,
 // one texel-loop iteration each -- the call waits for one workgroup's serial time, not for throughput.
 template <int AOFMT, bool RTNE, int DIV>
@@ -2783,14 +2772,13 @@ hipError_t launch_downsample_side(const DownsampleArgs &a, int frames, bool pad_
 template <bool WIDE, int AOFMT, bool RTNE, int DIV>
 static void launch_render_t(const RenderArgs &a, dim3 grid, hipStream_t s)
 {
-    const dim3 block(WIDE ? kThreads : (a.tile_h == kRenTileHTall ? 1024 : ren_tile_w(a.exhaustive != 0) * 4));
+    const dim3 block(WIDE ? kThreads : ren_tile_w(a.exhaustive != 0) * 4);
     if constexpr (WIDE) {
         if (a.exhaustive) render_wide_kernel<AOFMT, RTNE, DIV, true><<<grid, block, 0, s>>>(a);
         else render_wide_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);
     } else {
         if (a.exhaustive) render_kernel<AOFMT, RTNE, DIV, true><<<grid, block, 0, s>>>(a);
         else if (a.tile_h == kRenTileHSmall) render_small_kernel<AOFMT, RTNE, DIV><<<grid, block, 0, s>>>(a);
-        else if (a.tile_h == kRenTileHTall) render_tall_kernel<AOFMT, RTNE, DIV><<<grid, block, 0, s>>>(a);
         else render_kernel<AOFMT, RTNE, DIV, false><<<grid, block, 0, s>>>(a);
     }
 }

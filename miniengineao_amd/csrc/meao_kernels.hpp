@@ -40,7 +40,6 @@ struct DownsampleArgs {
 constexpr int ren_tile_w(bool exhaustive) { return exhaustive ? 64 : 128; }
 constexpr int kRenTileH = 32;
 constexpr int kRenTileHSmall = 8;               // calls with fewer 128 x 32 tiles than CUs: four times the workgroups, one texel-loop iteration each
-constexpr int kRenTileHTall = 64;               // experiment: 128 x 64 tiles with 1024 threads (meao_debug_set MEAO_DEBUG_RENDER_TILE_H)
 constexpr int kWideTileW = 64;                                 // Render.main (wide) keeps 64 x 32, 256 threads
 // downsample tile 128 x 32 (A/B against 256 x 16 and 512 x 8: profiles/r02_ab_v20_ds_tile_shape.jsonl) -- 4096 texels, 256 lanes x 4 row passes
 constexpr int kDsTileW = 128, kDsTileH = 4096 / kDsTileW;

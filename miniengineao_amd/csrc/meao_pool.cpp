@@ -3,8 +3,11 @@
 // The path shards across independent frames only (the reference keeps no temporal
 // state, AO.cs:291-308): frame f of a batch goes to pool member f mod G, every member owns a
 // complete context (all intermediates) and a stream on its device, and there is no data-path
-// exchange.  One host thread drives all members -- the launches are asynchronous -- so a C# host can
-// bind these entry points directly ([DllImport]) instead of running one process per GPU.
+// exchange.  One host thread calls the pool -- the launches are asynchronous -- so a C# host can
+// bind these entry points directly ([DllImport]) instead of running one process per GPU.  Inside, the
+// launch sequences of DEVICE batches are enqueued by one worker thread per member: a member's 4-5 launches cost
+// 10-14 us of host time, and eight members fed one after the other (111 us per step) cannot keep up with one 4K
+// frame per GPU (57-61 us of GPU time: BASELINE config 4, tools/pool_enqueue_cost.py); in parallel they can.
 // The pipelined forms of the single-context API exist here too (meao_pool_prefetch_batch,
 // meao_pool_composite_enqueue): the in-process host gets the same step the per-GPU processes of bench.py run.
 // Results stay on the owning device (or go to host memory); meao_pool_gather_to_device copies them to
@@ -12,14 +15,77 @@
 // creation, meao_pool_gather_path says which) when a single consumer wants the whole batch.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "meao_kernels.hpp"
 
+// One worker per member: runs the member's share of a pool call on the member's device.  The caller posts a job to
+// every worker and waits for all of them, so a context is only ever touched by one thread at a time.  A worker spins for
+// a while after its last job (a stream of steps keeps it hot: a condition-variable wake-up costs as much as the job),
+// then sleeps.
+struct PoolWorker {
+    std::thread thread;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> state{0};            // 0 idle, 1 job posted, 2 job done, 3 quit
+    std::function<int32_t()> job;
+    int32_t rc = 0;
+    int32_t device = 0;
+    void loop()
+    {
+        (void)hipSetDevice(device);
+        for (;;) {
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+            int st;
+            while ((st = state.load(std::memory_order_acquire)) != 1 && st != 3) {
+                if (std::chrono::steady_clock::now() > spin_until) {
+                    std::unique_lock<std::mutex> lock(mu);
+                    cv.wait(lock, [&] { const int v = state.load(std::memory_order_acquire); return v == 1 || v == 3; });
+                }
+            }
+            if (st == 3) return;
+            rc = job();
+            state.store(2, std::memory_order_release);
+        }
+    }
+    void post(std::function<int32_t()> fn)
+    {
+        job = std::move(fn);
+        {
+            std::lock_guard<std::mutex> lock(mu);      // pairs with the predicate check of a worker about to sleep
+            state.store(1, std::memory_order_release);
+        }
+        cv.notify_one();
+    }
+    int32_t wait()
+    {
+        while (state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+        state.store(0, std::memory_order_release);
+        return rc;
+    }
+    void quit()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            state.store(3, std::memory_order_release);
+        }
+        cv.notify_one();
+        if (thread.joinable()) thread.join();
+    }
+};
+
 struct meao_pool {
+    std::vector<std::unique_ptr<PoolWorker>> worker;      // started by the first DEVICE batch of a pool with several members
     std::vector<meao_ctx *> ctx;
     std::vector<int32_t> device;
     std::vector<hipStream_t> stream;
@@ -56,6 +122,36 @@ int32_t share_of(int32_t m, int32_t G, int32_t n, T *const *all, T **mine)
     int32_t k = 0;
     for (int32_t f = m; f < n; f += G) mine[k++] = all[f];
     return k;
+}
+
+// fn(m) for every member: on the members' worker threads (all at once) when the pool has several members, else here.
+// Returns the first failing member's status (every member is run and waited for either way).
+int32_t for_each_member(meao_pool *p, const std::function<int32_t(int32_t)> &fn, bool threaded, int32_t *failed_member)
+{
+    const int32_t G = static_cast<int32_t>(p->ctx.size());
+    int32_t status = MEAO_OK;
+    *failed_member = -1;
+    if (!threaded || G < 2) {
+        for (int32_t m = 0; m < G; ++m) {
+            const int32_t rc = fn(m);
+            if (rc != MEAO_OK && status == MEAO_OK) { status = rc; *failed_member = m; }
+        }
+        return status;
+    }
+    if (p->worker.empty()) {
+        for (int32_t m = 0; m < G; ++m) {
+            p->worker.emplace_back(new PoolWorker());
+            p->worker.back()->device = p->device[m];
+            PoolWorker *w = p->worker.back().get();
+            w->thread = std::thread([w] { w->loop(); });
+        }
+    }
+    for (int32_t m = 0; m < G; ++m) p->worker[m]->post([&fn, m] { return fn(m); });
+    for (int32_t m = 0; m < G; ++m) {
+        const int32_t rc = p->worker[m]->wait();
+        if (rc != MEAO_OK && status == MEAO_OK) { status = rc; *failed_member = m; }
+    }
+    return status;
 }
 
 }  // namespace
@@ -133,6 +229,8 @@ int32_t meao_pool_destroy(meao_pool *p)
 {
     if (!p) return MEAO_OK;
     DeviceGuard guard;
+    for (auto &w : p->worker) w->quit();
+    p->worker.clear();
     for (size_t i = 0; i < p->ctx.size(); ++i) {
         (void)hipSetDevice(p->device[i]);
         // The member's context has this stream as the stream of its last call (graph replays in flight,
@@ -184,23 +282,23 @@ int32_t meao_pool_execute_batch(meao_pool *p, int32_t n, const void *const *dept
     // sequence on its own stream.  With HOST memory every member's staged copies and launches are put in
     // flight first and all members are waited for afterwards: member m+1's upload overlaps member m's kernels.
     const bool host = depth_loc == MEAO_MEM_HOST || out_loc == MEAO_MEM_HOST;
-    int32_t issued = 0, status = MEAO_OK;
-    for (int32_t m = 0; m < G && status == MEAO_OK; ++m) {
+    int32_t failed = -1;
+    // DEVICE batches: every member's launch sequence is enqueued by its own worker thread (see the top of this file).
+    // HOST batches are dominated by their staged copies and stay on the calling thread.
+    int32_t status = for_each_member(p, [&](int32_t m) -> int32_t {
         const void *d[MEAO_MAX_BATCH];
         void *o[MEAO_MAX_BATCH];
         const int32_t k = share_of(m, G, n, depth, d);
         share_of(m, G, n, ao_out, o);
-        if (k == 0) continue;
-        // a member that fails may already have put copies from / to the caller's host buffers in flight before it
-        // failed: its stream is waited for like the others' 
-        issued = m + 1;
-        const int32_t rc = meao::execute_batch_internal(p->ctx[m], k, d, depth_loc, o, out_loc, p->stream[m], false);
-        if (rc != MEAO_OK)
-            status = pool_fail(p, rc, std::string("meao_pool_execute_batch: member ") + std::to_string(m) + ": " +
-                                          meao_last_error(p->ctx[m]));
-    }
-    if (host) {     // the host buffers are the caller's again when the call returns: wait for what was issued
-        for (int32_t m = 0; m < issued; ++m)
+        if (k == 0) return MEAO_OK;
+        return meao::execute_batch_internal(p->ctx[m], k, d, depth_loc, o, out_loc, p->stream[m], false);
+    }, !host, &failed);
+    if (status != MEAO_OK)
+        status = pool_fail(p, status, std::string("meao_pool_execute_batch: member ") + std::to_string(failed) + ": " +
+                                          meao_last_error(p->ctx[failed]));
+    if (host) {     // the host buffers are the caller's again when the call returns: wait for every member, also one that
+                    // failed -- it may have put copies from / to the caller's buffers in flight before it failed
+        for (int32_t m = 0; m < G; ++m)
             if (hipSetDevice(p->device[m]) != hipSuccess || hipStreamSynchronize(p->stream[m]) != hipSuccess) {
                 (void)hipGetLastError();
                 if (status == MEAO_OK) status = pool_fail(p, MEAO_ERR_HIP, "meao_pool_execute_batch: stream synchronisation failed");
@@ -216,15 +314,19 @@ int32_t meao_pool_prefetch_batch(meao_pool *p, int32_t n, const void *const *dep
     if (n < 1 || n > p->max_batch * G)
         return pool_fail(p, MEAO_ERR_INVALID_ARGUMENT, "meao_pool_prefetch_batch: n must be 1..max_batch * members");
     DeviceGuard guard;
-    for (int32_t m = 0; m < G; ++m) {
+    int32_t failed = -1;
+    // (a context with cfg.pipelined = 1 never allocates or synchronises here: this is bookkeeping, cheaper than a hand-over
+    // to the workers -- and the first call of a context created without it re-allocates, which must not race anything)
+    const int32_t status = for_each_member(p, [&](int32_t m) -> int32_t {
         const void *d[MEAO_MAX_BATCH];
         const int32_t k = share_of(m, G, n, depth, d);
-        if (k == 0) continue;
-        const int32_t rc = meao_prefetch_batch(p->ctx[m], k, d);
-        if (rc != MEAO_OK)
-            return pool_fail(p, rc, std::string("meao_pool_prefetch_batch: member ") + std::to_string(m) + ": " +
-                                        meao_last_error(p->ctx[m]));
-    }
+        if (k == 0) return MEAO_OK;
+        if (hipSetDevice(p->device[m]) != hipSuccess) { (void)hipGetLastError(); return MEAO_ERR_HIP; }
+        return meao_prefetch_batch(p->ctx[m], k, d);
+    }, false, &failed);
+    if (status != MEAO_OK)
+        return pool_fail(p, status, std::string("meao_pool_prefetch_batch: member ") + std::to_string(failed) + ": " +
+                                        meao_last_error(p->ctx[failed]));
     return MEAO_OK;
 }
 
