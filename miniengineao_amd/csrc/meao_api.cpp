@@ -82,7 +82,6 @@ struct meao_ctx {
     // it), 2 = in front of L2->L1, 3 = in front of the coarse blend launch, 4 = in front of render; shape 0 = 16 loads
     // per lane in flight, 120 VGPRs declared, 1 = 16 loads, 2 = 8 loads, 3 = 4 loads (the stand-alone pass's tile).
     int ds_side_stream = 0;
-    int final_late_depth = 0;          // MEAO_DEBUG_FINAL_LATE_DEPTH: the plain full-resolution pass in its eight-workgroups-per-CU form
     hipStream_t side_stream = nullptr;
     hipEvent_t side_gate = nullptr, side_done = nullptr;
     bool side_pending = false;         // a side-stream downsample was issued and no later execute has ordered itself behind it yet
@@ -497,7 +496,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         up.hostile = hostile;
         up.generation = generation;
         up.tickets = ctx->hostile + 2 * MEAO_MAX_BATCH;
-        up.late_depth = hi == 0 ? ctx->final_late_depth : 0;
         bool vec_ok = (up.hw & 3) == 0;
         if (hi > 0) {   // main_blendout: blend with Occlusion<hi>, write Combined<hi>
             up.hi_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi - 1));
@@ -1345,7 +1343,6 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
-    case MEAO_DEBUG_FINAL_LATE_DEPTH: ctx->final_late_depth = value != 0; break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
         if (value < 0 || value % 10 > 4 || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
             return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");

@@ -1356,11 +1356,11 @@ __device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float 
 
 // One tile of Upsample.main (FINAL) / main_blendout; every thread of the workgroup must call it
 // (barriers inside; lanes outside the image leave after the last one).
-// DEP_LATE (experiment B of VERDICT r3 #2, meao_debug_set MEAO_DEBUG_FINAL_LATE_DEPTH): the LoResDB window is not kept in LDS from
-// the fill on -- it waits in the registers its loads filled and is written behind the V-blur, into the array the H-blurred values
-// have just vacated: 17.6 KB instead of 22.8 KB per workgroup, eight workgroups per CU instead of seven, at the price of one more
-// barrier and 8 VGPRs that stay live across both blur phases.
-template <bool FINAL, int TILE_H = ups_tile_h(FINAL), bool DEP_LATE = false>
+// (Eight workgroups per CU were measured in round 4: the LoResDB window kept in the registers its loads filled and written behind
+// the V-blur into the array the H-blurred values had vacated -- 17.6 KB, 57 VGPRs, one barrier more, bit-exact -- runs at 176.0 us
+// against 176.1 us: the same busy cycles, 10 % more wave-cycles, 17 % more waiting.  The pass is bound by the issue rate of its
+// instruction mix, not by the number of waves that hide latency: profiles/r04_ab_final_late_depth_8_workgroups.txt.)
+template <bool FINAL, int TILE_H = ups_tile_h(FINAL)>
 struct UpsLds {
     typedef UpsTile<TILE_H> T;
     static constexpr int kDep0 = FINAL ? 2 : 0;                                   // first row / column kept
@@ -1368,8 +1368,7 @@ struct UpsLds {
     static constexpr int kDepPitch = FINAL ? 36 : T::kRawPitch;
     static constexpr int kInvN = T::kRawH * T::kRawPitch, kHbN = T::kRawH * T::kBlurPitch, kDepN = kDepH * kDepPitch;
     static constexpr int kAoN = T::kRawH * T::kRawPitch;
-    static constexpr int kFloats = kInvN + kHbN + (DEP_LATE ? 0 : kDepN) + kAoN;
-    static_assert(!DEP_LATE || (FINAL && kDepN <= kHbN), "the late depth window fits the array of the H-blurred values");
+    static constexpr int kFloats = kInvN + kHbN + kDepN + kAoN;
 };
 
 // The global loads of an interior tile (no horizontal clamping, 16-byte loads everywhere, no second AO input): its low-res
@@ -1509,7 +1508,7 @@ struct NoHook {
 // (ups_issue_interior_loads<.., WINDOW_ONLY>); its hi-res operands are loaded here, at the top of the tile, as always; its
 // output texels go to `deferred` instead of memory (ups_store_results, called by the next tile's hook).
 template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL),
-          bool PRELOADED = false, bool DEP_LATE = false>
+          bool PRELOADED = false>
 __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook(),
                                               const UpsLoads<AOFMT, FINAL, TILE_H> *pre = nullptr,
                                               UpsResults<AOFMT, TILE_H> *deferred = nullptr)
@@ -1525,18 +1524,17 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     // what the bilateral phase gathers (rows / columns 2 .. kLow+5): 22.3 KB per workgroup instead of
     // 24.1 KB, which lets a seventh workgroup share the CU's 160 KB (with __launch_bounds__(.., 7):
     // A/B on one box, 357 -> 343 us for the kernel that also carries the next downsample pass).
-    typedef UpsLds<FINAL, TILE_H, DEP_LATE> Lds;
-    static_assert(!DEP_LATE || (!NESTED && !PRELOADED), "the late depth window is a form of the plain full-resolution tile");
+    typedef UpsLds<FINAL, TILE_H> Lds;
     constexpr int kDep0 = Lds::kDep0, kDepH = Lds::kDepH, kDepW = Lds::kDepW, kDepPitch = Lds::kDepPitch;
-    constexpr int kInvN = Lds::kInvN, kHbN = Lds::kHbN, kDepN = DEP_LATE ? 0 : Lds::kDepN, kAoN = Lds::kAoN;     // kDepN: floats s_dep occupies of its own
+    constexpr int kInvN = Lds::kInvN, kHbN = Lds::kHbN, kDepN = Lds::kDepN, kAoN = Lds::kAoN;
     static_assert(kDepW <= kDepPitch && (T::kRawRows - T::kRawH) * T::kRawPitch <= kHbN &&
                   (T::kRawRows - T::kRawH) * T::kBlurPitch <= kDepN + kAoN, "scratch rows stay inside the allocation");
     static_assert(T::kVRows * T::kBlurPitch <= kAoN, "s_vb fits in s_ao");
     static_assert(kInvN % 4 == 0 && kHbN % 4 == 0 && kDepN % 4 == 0, "16-byte alignment of the carved arrays");
     float *const s_inv = smem;                       // 1 / LoResDB   (DepthCache)
     float *const s_hb = s_inv + kInvN;               // after BlurHorizontally (AOCache2)
-    float *const s_dep = DEP_LATE ? s_hb : s_hb + kHbN;   // LoResDB    (LoDepths gather), window from (kDep0, kDep0); DEP_LATE: written behind the V-blur
-    float *const s_ao = s_hb + kHbN + kDepN;         // LoResAO1 taps (AOCache1 before blur)
+    float *const s_dep = s_hb + kHbN;                // LoResDB       (LoDepths gather), window from (kDep0, kDep0)
+    float *const s_ao = s_dep + kDepN;               // LoResAO1 taps (AOCache1 before blur)
     float *const s_vb = s_ao;                        // after BlurVertically (AOCache1): the raw taps are dead once H-blurred
     auto dep_at = [&](int r, int c) -> float & { return s_dep[(r - kDep0) * kDepPitch + (c - kDep0)]; };
     auto dep_kept = [&](int r, int c) { return !FINAL || (r >= kDep0 && r < kDep0 + kDepH && c >= kDep0 && c < kDep0 + kDepW); };
@@ -1606,7 +1604,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 for (int e = 0; e < 4; ++e) {
                     const int c = 4 * k + e - 1;
                     if (c >= 0 && c < T::kRawW) {
-                        if (!DEP_LATE && dep_kept(r, c)) dep_at(r, c) = dv[e];
+                        if (dep_kept(r, c)) dep_at(r, c) = dv[e];
                         s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
                         if constexpr (!NESTED) s_ao[r * T::kRawPitch + c] = av[e];
                     }
@@ -1636,7 +1634,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * k + e - 1;
                 if (c >= 0 && c < T::kRawW) {
-                    if (!DEP_LATE && dep_kept(r, c)) dep_at(r, c) = dv[e];
+                    if (dep_kept(r, c)) dep_at(r, c) = dv[e];
                     s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
                     if constexpr (!NESTED) s_ao[r * T::kRawPitch + c] = av[e];
                 }
@@ -1648,7 +1646,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
             const size_t idx = static_cast<size_t>(cy) * lw + cx;
             const float d = lo_depth[idx];
-            if (!DEP_LATE && dep_kept(r, c)) dep_at(r, c) = d;
+            if (dep_kept(r, c)) dep_at(r, c) = d;
             s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
             if constexpr (!NESTED) {
                 float av = AO::decode(lo_ao[idx]);
@@ -1717,32 +1715,6 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     clk.mark(4);         // 4: V-blur
     __syncthreads();
     clk.mark(5);         // 5: barrier
-    if constexpr (DEP_LATE) {
-        // nobody reads s_hb any more: the LoResDB window goes there now, from the registers its loads filled (interior tiles) or
-        // from L2 again (the few border tiles)
-        if (window_first) {
-#pragma unroll
-            for (int round = 0; round < Loads::kRounds; ++round) {
-                const int i = tid + round * kThreads;
-                if (i < Loads::kItems) {
-                    const int r = i / 10, k = i % 10;
-                    const float dv[4] = {L.wd[round].x, L.wd[round].y, L.wd[round].z, L.wd[round].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = 4 * k + e - 1;
-                        if (c >= 0 && c < T::kRawW && dep_kept(r, c)) dep_at(r, c) = dv[e];
-                    }
-                }
-            }
-        } else {
-            for (int i = tid; i < kDepW * kDepH; i += kThreads) {
-                const int r = kDep0 + i / kDepW, c = kDep0 + i % kDepW;
-                const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
-                dep_at(r, c) = lo_depth[static_cast<size_t>(cy) * lw + cx];
-            }
-        }
-        __syncthreads();
-    }
     if constexpr (Hook::kBeforeBilateral) {
         // vmcnt retires in order: a load issued here would sit behind nothing only if the hoisted operands
         // are waited for first -- naming them in an asm makes the compiler put that wait here
@@ -2096,16 +2068,16 @@ __global__ __launch_bounds__(kThreads, MEAO_X_TWO_LEVEL_WAVES) void upsample_two
 }
 
 // The (rare) hostile-frame variant of a tile: the same code with IEEE division.
-template <int AOFMT, bool RTNE, bool FINAL, int DIV, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL), bool DEP_LATE = false>
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
 __device__ __forceinline__ void upsample_tile_checked(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
 {
     if constexpr (DIV == DIV_EXACT_RCP) {
         if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
-            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE, false, Hook, TILE_H, false, DEP_LATE>(a, smem, tile, frame, hook);
+            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE, false, Hook, TILE_H>(a, smem, tile, frame, hook);
             return;
         }
     }
-    upsample_tile<AOFMT, RTNE, FINAL, DIV, false, Hook, TILE_H, false, DEP_LATE>(a, smem, tile, frame, hook);
+    upsample_tile<AOFMT, RTNE, FINAL, DIV, false, Hook, TILE_H>(a, smem, tile, frame, hook);
 }
 
 template <int AOFMT, bool RTNE, bool FINAL, int DIV>
@@ -2113,14 +2085,6 @@ __global__ __launch_bounds__(kThreads, FINAL ? 7 : 1) void upsample_kernel(const
 {
     __shared__ __attribute__((aligned(16))) float smem[UpsLds<FINAL>::kFloats];
     upsample_tile_checked<AOFMT, RTNE, FINAL, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
-}
-
-// Experiment B: the full-resolution pass with the late depth window (UpsLds<.., DEP_LATE>): eight workgroups per CU.
-template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(kThreads, 8) void upsample_final_late_depth_kernel(const UpsampleArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float smem[UpsLds<true, ups_tile_h(true), true>::kFloats];
-    upsample_tile_checked<AOFMT, RTNE, true, DIV, NoHook, ups_tile_h(true), true>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
 
 // Upsample.main for calls with few tiles (one 1080p frame: 510 tiles of 64 x 64 on 256 CUs): 64 x 32 tiles, twice
@@ -2902,7 +2866,6 @@ static void launch_upsample_t(const UpsampleArgs &a, bool final_pass, dim3 grid,
     }
 #endif
     if (final_pass && a.tile_h == kUpsTileHSmall) upsample_final_small_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
-    else if (final_pass && a.late_depth) upsample_final_late_depth_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else if (final_pass) upsample_kernel<AOFMT, RTNE, true, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else upsample_kernel<AOFMT, RTNE, false, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
 }

@@ -105,7 +105,6 @@ struct UpsampleArgs {
     int32_t vec_ok;            // hw % 4 == 0 and, in the final pass, every dst pointer aligned for 4-texel stores
     const uint32_t *hostile;   // as in RenderArgs
     uint32_t generation;
-    int32_t late_depth;        // plain full-resolution pass: the 17.6 KB / eight-workgroups-per-CU form (MEAO_DEBUG_FINAL_LATE_DEPTH)
     uint32_t *tickets;         // kTicketWords zeroed words: [group] next tile ticket of persistent launches, [kTicketWords - 1] finished workgroups (self-resetting)
 };
 constexpr int kTicketWords = 1025;

@@ -648,25 +648,3 @@ def test_next_downsample_on_the_side_stream(oracle, mode, w, h, batch):
     finally:
         ao.close()
 
-
-@pytest.mark.parametrize("variant", [dict(), dict(ao_format=1, f16_rounding=1), dict(hq_levels=2)])
-@pytest.mark.parametrize("w,h,batch", [(1280, 720, 2), (515, 301, 2), (322, 182, 3), (2048, 1152, 1)])
-def test_full_resolution_pass_with_the_late_depth_window(oracle, variant, w, h, batch):
-    """MEAO_DEBUG_FINAL_LATE_DEPTH: the plain full-resolution upsample launch in its eight-workgroups-per-CU form (the
-    low-res depth window waits in registers and is written behind the V-blur; border tiles, odd widths, the premin
-    variant and hostile frames re-read it from memory): every buffer of every frame against the oracle."""
-    s = H.settings(oracle, w, h, **variant)
-    frames = [synth.make("S2", w, h, seed=40 + f) for f in range(batch)]
-    frames[batch - 1] = H.hostile_frame(w, h, 41, density=0.005)
-    ao = H.component(s, max_batch=batch, debug={L.DEBUG_FINAL_LATE_DEPTH: 1, L.DEBUG_FINAL_SMALL_MAX_TILES: 0})
-    try:
-        outs = ao.render_batch(frames)
-        for f in range(batch):
-            want = oracle.run(frames[f], s)
-            ok, bad = H.nan_aware_equal(outs[f], want["result"])
-            assert ok, (f, int(bad.sum()))
-            for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
-                ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
-                assert ok, (H.NAMES[i], f, int(bad.sum()))
-    finally:
-        ao.close()
