@@ -73,12 +73,8 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out_pa
 
 # Experimental arms of meao_kernels.hip (MEAO_X_* switches) that are kept in the source: name -> -D flags
 VARIANTS = {
-    "persist2": ["-DMEAO_X_UPS_PERSISTENT=2"],
-    "persist3prio": ["-DMEAO_X_UPS_PERSISTENT=3", "-DMEAO_X_UPS_PRIO_SCHEME=1"],
-    "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],
-    "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],
-    "twolevel7": ["-DMEAO_X_TWO_LEVEL_WAVES=7"],
-    "r8recompute": ["-DMEAO_X_R8_REUSE=0"],
+    "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],          # diagnostic: phase stamps, render residency log
+    "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],         # every UNORM8 bilateral result through the exact-division sequences (cross-check of the estimate)
 }
 
 

@@ -495,7 +495,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         up.exact_rcp_div = ctx->exact_rcp_div;
         up.hostile = hostile;
         up.generation = generation;
-        up.tickets = ctx->hostile + 2 * MEAO_MAX_BATCH;
         bool vec_ok = (up.hw & 3) == 0;
         if (hi > 0) {   // main_blendout: blend with Occlusion<hi>, write Combined<hi>
             up.hi_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi - 1));
@@ -884,8 +883,7 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
     }
     if (rc == MEAO_OK) {
         // hostile-depth flags: 2 downsample sets x MEAO_MAX_BATCH frames, zero = never hostile (generations start at 1)
-        // (+ kTicketWords behind them: the tile tickets of persistent kernels, self-resetting, zero between launches)
-        const size_t bytes = (2 * MEAO_MAX_BATCH + kTicketWords) * sizeof(uint32_t);
+        const size_t bytes = 2 * MEAO_MAX_BATCH * sizeof(uint32_t);
         e = hipMalloc(reinterpret_cast<void **>(&ctx->hostile), bytes);
         if (e == hipSuccess) e = hipMemset(ctx->hostile, 0, bytes);
         if (e != hipSuccess) rc = fail_hip(ctx, e, "hipMalloc (hostile flags)");

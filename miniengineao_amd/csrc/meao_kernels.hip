@@ -42,7 +42,7 @@
 //    (blend_window_into_lds): no inter-workgroup synchronisation, bit-identical buffers.
 //  * The SIMDs issue oldest-wave-first.  A hardware-dispatched workgroup is born youngest and ages while its tile
 //    progresses, so the furthest-along tile always goes first -- a software pipeline across tiles for free, and the
-//    reason the persistent-workgroup forms of these kernels (MEAO_X_UPS_PERSISTENT) lose to the plain launches.
+//    reason persistent-workgroup forms of these kernels lost to the plain launches (round 3, LABNOTES.md).
 //  * v_rcp_f32 pays ~3 cycles when it follows a non-transcendental instruction: the four weight reciprocals of a
 //    bilateral texel are issued back to back (bilateral_upsample_grouped).
 //  * Results that are stored as UNORM8 do not need the correction steps of their divisions wherever the uncorrected
@@ -59,33 +59,16 @@
 // profiles/README.md lists them.  Experimental arms of the current round live behind the MEAO_X_* switches
 // of this block only (tests/build_variants.py builds variants next to the product library;
 // tests/test_variants_gpu.py runs a parity smoke through every variant library it finds).
-#ifndef MEAO_X_UPS_PERSISTENT
-#define MEAO_X_UPS_PERSISTENT 0 // full-resolution upsample pass as persistent workgroups (7 per CU) looping over (frame, tile), the next tile's
-#endif                          // window loads issued in front of the current tile's bilateral phase, its stores deferred into the next tile:
-                                // 2 = fixed stride, 3 = the seven workgroups of a CU draw their tiles from one atomic ticket counter.
-                                // Measured (profiles/r03_ab_persistent_*.jsonl, r03_wg_log_*.txt): 246 / 285 us against 201 us for the plain
-                                // launch -- the SIMDs issue oldest-wave-first, which gives the hardware-dispatched launch a free software
-                                // pipeline (the furthest-along tile goes first); persistent waves never age relative to each other.
-#ifndef MEAO_X_UPS_PRIO_SCHEME
-#define MEAO_X_UPS_PRIO_SCHEME 0      // s_setprio per upsample phase {fill, H-blur, V-blur, bilateral}: 0 = {3, 0, 0, 0} (product), 1 = {3, 1, 2, 3}
-#endif                                // (emulates "furthest-along first" for persistent workgroups: 246 -> 220 us; plain launch: 201 -> 205 us)
-constexpr int kUpsPrio[2][4] = {{3, 0, 0, 0}, {3, 1, 2, 3}};
 #ifndef MEAO_X_UPS_EXACT_R8
 #define MEAO_X_UPS_EXACT_R8 0      // 1 = every UNORM8 bilateral result through the full exact-division sequence (the round-2 form) instead of
 #endif                             // bilateral_upsample_r8: L1->L0 176 -> 196 us, L2->L1 54 -> 57 us (profiles/r03_ab_verified_r8_bilateral.txt)
-#ifndef MEAO_X_R8_REUSE
-#define MEAO_X_R8_REUSE 1
-#endif
-#ifndef MEAO_X_TWO_LEVEL_WAVES
-#define MEAO_X_TWO_LEVEL_WAVES 8   // waves per SIMD the two-level blend kernel is compiled for (7: 65 VGPRs, 8: 64; 4080 workgroups are 2.28 / 1.99
-#endif                             // rounds of the CUs' slots: 35.3 -> 34.3 us, profiles/r03_ab_two_level_waves.txt)
 #ifndef MEAO_X_HOT_PATH_ONLY
 #define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
 #endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the
                                 // static instruction counts of the ISA are the dynamic ones of (almost) every workgroup
 #ifndef MEAO_X_PHASE_CLOCKS
 #define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py),
-#endif                          // persistent launches log start / end / CU of every workgroup (tools/wg_log.py)
+#endif                          // the render launch logs start / end / CU of every workgroup (tools/render_wg_log.py)
 
 #if MEAO_X_PHASE_CLOCKS
 // [phase] summed 100 MHz ticks and [32 + phase] wave counts, per upsample-tile phase (0..7 full-resolution pass,
@@ -98,7 +81,7 @@ extern "C" __attribute__((visibility("default"))) int meao_x_phase_clocks(unsign
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clocks), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 extern "C" __attribute__((visibility("default"))) int meao_x_wg_log_preset(void);
-// per workgroup of the last persistent launch: start, end (100 MHz), HW_ID, XCC_ID
+// per workgroup of the last logged launch: start, end (100 MHz), HW_ID, XCC_ID
 __device__ unsigned long long g_wg_log[16384 * 4];
 extern "C" __attribute__((visibility("default"))) int meao_x_wg_log(unsigned long long *out, int workgroups)
 {
@@ -158,9 +141,8 @@ constexpr int kThreads = 256;
 
 __device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// threadIdx.x behind an optimisation barrier: inside the tile loop of a persistent kernel every lane-dependent index
-// (LDS addresses, run numbers, texel coordinates) is loop-invariant, and the compiler would hoist all of them out of
-// the loop into long-lived registers (38 spilled VGPRs in the first persistent upsample kernel).
+// threadIdx.x behind an optimisation barrier: lane-dependent indices (LDS addresses, run numbers, texel coordinates) derived
+// from it are computed where they are used instead of being hoisted to the top of the tile into long-lived registers.
 __device__ __forceinline__ int thread_index_opaque()
 {
     int t = static_cast<int>(threadIdx.x);
@@ -1373,8 +1355,7 @@ struct UpsLds {
 
 // The global loads of an interior tile (no horizontal clamping, 16-byte loads everywhere, no second AO input): its low-res
 // window as 16-byte row quads [LX0 - 4 + 4k, +4) -- depth and AO -- and the hi-res operands of the bilateral phase
-// (f16 depth in the full-resolution pass, f32 depth + AO in the blend passes).  Issued at the top of the tile, or -- in the
-// persistent kernels -- a whole tile ahead, in front of the previous tile's bilateral phase.
+// (f16 depth in the full-resolution pass, f32 depth + AO in the blend passes).  Issued at the top of the tile.
 template <int AOFMT, bool FINAL, int TILE_H>
 struct UpsLoads {
     typedef AoTexel<AOFMT> AO;
@@ -1430,7 +1411,7 @@ __device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, int til
 // All loads of an interior tile: window first, hi-res operands behind them.  The window comes from L2 (written by the
 // previous pass), the hi-res operands of the final pass from HBM; vmcnt retires loads in issue order, so with the hi-res
 // loads in front the window wait would last an HBM latency.
-template <int AOFMT, bool FINAL, int TILE_H, bool WINDOW_ONLY = false>
+template <int AOFMT, bool FINAL, int TILE_H>
 __device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
 {
     const int tid = thread_index_opaque();
@@ -1450,45 +1431,9 @@ __device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, 
         L.wd[round] = *reinterpret_cast<const float4v *>(at_byte_offset(lo_depth, idx * 4u));
         L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(lo_ao, idx * static_cast<uint32_t>(sizeof(ao_t))));
     }
-    if constexpr (!WINDOW_ONLY) {
-        __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
-        ups_issue_hoisted<AOFMT, FINAL, TILE_H, true>(a, tile, frame, L);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// The output texels of a tile, held in registers: a persistent workgroup stores them a phase into its NEXT tile.  On this
-// part stores count in vmcnt like loads and the compiler waits with vmcnt(0) for anything carried around a loop: stores
-// issued at the end of a tile would put their round trip to HBM in front of the next tile's first load wait.
-template <int AOFMT, int TILE_H>
-struct UpsResults {
-    typedef typename std::conditional<sizeof(typename AoTexel<AOFMT>::type4) == 4, uint32_t, uint64_t>::type bits_t;   // four texels
-    bits_t r4[TILE_H / 32][2];
-};
-
-template <int AOFMT, bool FINAL, int TILE_H>
-__device__ __forceinline__ void ups_store_results(const UpsampleArgs &a, int tile, int frame, const UpsResults<AOFMT, TILE_H> &R)
-{
-    typedef AoTexel<AOFMT> AO;
-    typedef typename AO::type ao_t;
-    const int tid = thread_index_opaque();
-    const int HX0 = (tile % a.tiles_x) * kUpsTileW, HY0 = (tile / a.tiles_x) * TILE_H;
-    const int hx0 = HX0 + 4 * (tid & 15);
-    if (hx0 >= a.hw) return;
-    ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame]) : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
-#pragma unroll
-    for (int pass = 0; pass < TILE_H / 32; ++pass)
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const int hy = HY0 + 2 * ((tid >> 4) + 16 * pass) + f;
-            if (hy < a.hh) {
-                typename AO::type4 *o = reinterpret_cast<typename AO::type4 *>(
-                    at_byte_offset(dst, static_cast<uint32_t>(hy * a.hw + hx0) * static_cast<uint32_t>(sizeof(ao_t))));
-                const typename AO::type4 v = __builtin_bit_cast(typename AO::type4, R.r4[pass][f]);
-                if constexpr (FINAL) __builtin_nontemporal_store(v, o);
-                else *o = v;
-            }
-        }
+    __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
+    ups_issue_hoisted<AOFMT, FINAL, TILE_H, true>(a, tile, frame, L);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // NESTED: the LoResAO1 taps (s_ao) were already produced in LDS by blend_window_into_lds (the
@@ -1504,14 +1449,8 @@ struct NoHook {
     __device__ __forceinline__ void before_bilateral() const {}
 };
 
-// PRELOADED (persistent kernels): `pre` holds the window loads of this -- interior -- tile, issued a tile ago
-// (ups_issue_interior_loads<.., WINDOW_ONLY>); its hi-res operands are loaded here, at the top of the tile, as always; its
-// output texels go to `deferred` instead of memory (ups_store_results, called by the next tile's hook).
-template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL),
-          bool PRELOADED = false>
-__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook(),
-                                              const UpsLoads<AOFMT, FINAL, TILE_H> *pre = nullptr,
-                                              UpsResults<AOFMT, TILE_H> *deferred = nullptr)
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
+__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
 {
     const int tid = thread_index_opaque();
     typedef AoTexel<AOFMT> AO;
@@ -1551,35 +1490,28 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
 
     PhaseClock clk(FINAL ? 0 : 8);
-    __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][0]);
+    __builtin_amdgcn_s_setprio(3);
     // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
     // are issued first, so that their latency hides behind the prefetch and blur phases.
     constexpr int kPasses = kTileH / 32;
     typedef UpsLoads<AOFMT, FINAL, TILE_H> Loads;
     Loads L;
-    if constexpr (PRELOADED) {
-#pragma unroll
-        for (int round = 0; round < Loads::kRounds; ++round) { L.wd[round] = pre->wd[round]; L.wa[round] = pre->wa[round]; }
-        ups_issue_hoisted<AOFMT, FINAL, TILE_H, true>(a, tile, frame, L);
-    }
     auto &hoist_hd16 = L.hd16;
     auto &hoist_hd32 = L.hd32;
     auto &hoist_ha = L.ha;
     const bool hoist_ok = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;
     // interior tile, 16-byte loads everywhere, no second AO input: window loads first (ups_issue_interior_loads)
-    const bool window_first = PRELOADED || (!NESTED && (MEAO_X_HOT_PATH_ONLY || ups_tile_is_interior<FINAL, TILE_H>(a, tile)));
-    if constexpr (!PRELOADED)
-        if (hoist_ok && !window_first) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false>(a, tile, frame, L);
+    const bool window_first = !NESTED && (MEAO_X_HOT_PATH_ONLY || ups_tile_is_interior<FINAL, TILE_H>(a, tile));
+    if (hoist_ok && !window_first) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false>(a, tile, frame, L);
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
     // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
     const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
     if (window_first) {
         constexpr int kItems = Loads::kItems, kRounds = Loads::kRounds;
-        if constexpr (!PRELOADED && !NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H>(a, tile, frame, L);
+        if constexpr (!NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H>(a, tile, frame, L);
         auto &wd = L.wd;
         auto &wa = L.wa;
-        if constexpr (PRELOADED) asm volatile("; MEAO_MARK preloaded_fill_begin");
 #pragma unroll
         for (int round = 0; round < kRounds; ++round) {
             // an unconditional use: the compiler would otherwise sink the loads of the partial last round into
@@ -1658,7 +1590,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     clk.mark(0);         // 0: window loaded, converted, stored to LDS
     __syncthreads();
     clk.mark(1);         // 1: barrier
-    __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][1]);       // (3 kept through the blur phases: +10 % on the pass)
+    __builtin_amdgcn_s_setprio(0);       // (3 kept through the blur phases: +10 % on the pass; rising through the phases: +2 %, r03)
     hook.after_prefetch();
 
     // ---- BlurHorizontally: runs of 4 outputs; output (r, c) is centred on raw column c+2.
@@ -1694,7 +1626,6 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     clk.mark(2);         // 2: H-blur
     __syncthreads();
     clk.mark(3);         // 3: barrier
-    if constexpr (MEAO_X_UPS_PRIO_SCHEME != 0) __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][2]);
 
     // ---- BlurVertically: runs of T::kVRun outputs; output (r, c) is centred on H-blurred row
     // r+2; depths come from the same virtual column (DepthCache[... + 2], UPS:141-146).  Rows
@@ -1734,7 +1665,6 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     }
 
     // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
-    if constexpr (kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][3] != 0) __builtin_amdgcn_s_setprio(kUpsPrio[MEAO_X_UPS_PRIO_SCHEME][3]);
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
                                    : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
     const bool vec_ok = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
@@ -1807,7 +1737,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                         gd[i] = dl[rr + gy[g]][cc + gx[g]];
                         ga[i] = vb[rr + gy[g]][cc + gx[g]];
                     }
-                    res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, MEAO_X_R8_REUSE && !NESTED && !PRELOADED>(hd[e], ha[e], gd, ga, bilateral_k));
+                    res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, !NESTED>(hd[e], ha[e], gd, ga, bilateral_k));
                 }
             } else if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
                 // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than
@@ -1855,13 +1785,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             if (vec_ok) {
                 typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
                 // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
-                if constexpr (PRELOADED) {
-                    // packed NOW and pinned: left alone the compiler carries the four texels around the loop unpacked
-                    typename UpsResults<AOFMT, TILE_H>::bits_t packed = __builtin_bit_cast(typename UpsResults<AOFMT, TILE_H>::bits_t, r4);
-                    asm volatile("" : "+v"(packed));
-                    deferred->r4[pass][f] = packed;
-                }
-                else if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
+                if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
                 else *reinterpret_cast<typename AO::type4 *>(o) = r4;
             } else {
 #pragma unroll
@@ -2054,7 +1978,7 @@ __device__ __forceinline__ void upsample_two_level_tile(const UpsampleArgs &oute
 }
 
 template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(kThreads, MEAO_X_TWO_LEVEL_WAVES) void upsample_two_level_kernel(const UpsampleArgs outer, const UpsampleArgs inner)
+__global__ __launch_bounds__(kThreads, 8) void upsample_two_level_kernel(const UpsampleArgs outer, const UpsampleArgs inner)
 {
     __shared__ __attribute__((aligned(16))) float smem[UpsLds<false>::kFloats];
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x), frame = blockIdx.z;
@@ -2207,166 +2131,6 @@ __global__ __launch_bounds__(kThreads) void upsample_blend_with_next_downsample_
     const IssueCarriedLoads issue = {d, v, mine, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.z)};
     upsample_tile_checked<AOFMT, RTNE, false, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z, issue);
     if (mine) downsample_tile_finish<RTNE, true, DIV>(d, blockIdx.x, blockIdx.z, v);
-}
-
-// ---- experiment (MEAO_X_UPS_PERSISTENT): the full-resolution pass as persistent workgroups ------------------
-// gridDim.x = 7 workgroups per CU (a multiple of 8, so a workgroup's ids id, id + gridDim.x, ... stay on its XCD);
-// xcd_contiguous over the whole batch gives every XCD a contiguous range of (frame, tile) pairs.
-// Hook of the persistent kernels: the loads of the workgroup's NEXT (interior) tile go out in front of this tile's
-// bilateral phase -- a whole phase before they are needed, and in front of this tile's stores (vmcnt retires in order:
-// loads issued behind the stores would wait for the stores' round trip to HBM).
-template <int AOFMT, bool FINAL, int TILE_H>
-struct IssueNextTileLoads {
-    static constexpr bool kBeforeBilateral = true;
-    static constexpr bool kGroupReciprocals = true;
-    static constexpr bool kEstimateR8 = true;
-    const UpsampleArgs &a;
-    UpsLoads<AOFMT, FINAL, TILE_H> &next;
-    bool active;
-    int tile, frame;
-    const UpsResults<AOFMT, TILE_H> &pending;        // the previous tile's output, stored once this tile's window is in LDS
-    bool has_pending;
-    int ptile, pframe;
-    uint32_t *ticket_counter;                         // MEAO_X_UPS_PERSISTENT == 3: thread 0 draws the ticket of the tile after next here ...
-    int &drawn;                                       // ... and reads it a whole tile later (the atomic's round trip stays off the path)
-    __device__ __forceinline__ void after_prefetch() const
-    {
-        if (has_pending) ups_store_results<AOFMT, FINAL, TILE_H>(a, ptile, pframe, pending);
-        if (ticket_counter && threadIdx.x == 0) drawn = static_cast<int>(atomicAdd(ticket_counter, 1u));
-    }
-    __device__ __forceinline__ void before_bilateral() const
-    {
-        if (active) ups_issue_interior_loads<AOFMT, FINAL, TILE_H, true>(a, tile, frame, next);
-    }
-};
-
-template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(kThreads, 7) void upsample_final_persistent_kernel(const UpsampleArgs a, int frames)
-{
-    __shared__ __attribute__((aligned(16))) float smem[UpsLds<true>::kFloats];
-    const int per_frame = a.tiles_x * a.tiles_y, total = per_frame * frames;
-#if MEAO_X_PHASE_CLOCKS
-    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    constexpr int kTileH = ups_tile_h(true);
-    typedef UpsLoads<AOFMT, true, kTileH> Loads;
-    // frames whose downsample pass saw hostile depth take the IEEE-division bodies (no prefetching across them)
-    uint64_t hostile_mask = 0;
-    if constexpr (DIV == DIV_EXACT_RCP) {
-        const int lane = threadIdx.x & 63;
-        hostile_mask = __builtin_amdgcn_ballot_w64(lane < frames && __builtin_nontemporal_load(a.hostile + lane) == a.generation);
-    }
-    auto interior = [&](int tile, int frame) {
-        return ups_tile_is_interior<true, kTileH>(a, tile) && !(hostile_mask >> frame & 1u);
-    };
-#if MEAO_X_UPS_PERSISTENT == 3
-    // Tickets.  The SIMDs issue oldest-wave-first: with a fixed share per workgroup the seven workgroups of a CU finish
-    // one after the other (100 .. 254 us in a 250 us launch, tools/wg_log.py) and the CU spends the second half of the
-    // launch half empty.  Workgroups are dealt to the CUs round-robin (blockIdx mod the number of CUs: measured), so the
-    // seven workgroups {c, c + groups, ...} share CU c: they draw the tiles c, c + groups, c + 2 groups, ... from one counter
-    // (7 clients per counter: no contention) until the CU's share is gone, whoever gets there first.
-    // Thread 0 draws the ticket of the tile after next behind this tile's first barrier and publishes it in LDS before the
-    // end-of-tile barrier.  The last workgroup to finish zeroes the counters for the next launch.
-    __shared__ int s_ticket;
-    const int groups = gridDim.x / 7, group = blockIdx.x % groups;        // gridDim.x = 7 x CUs (launcher)
-    uint32_t *const counter = a.tickets + group;
-    auto id_of = [&](int ticket) { return ticket < 0 ? total : group + groups * ticket; };     // groups % 8 == 0: the XCD of an id is the group's
-    if (threadIdx.x == 0) s_ticket = static_cast<int>(atomicAdd(counter, 1u));
-    __syncthreads();
-    int id = id_of(__builtin_amdgcn_readfirstlane(s_ticket));        // uniform: keep everything derived from it in SGPRs
-    __syncthreads();
-    if (threadIdx.x == 0) s_ticket = static_cast<int>(atomicAdd(counter, 1u));
-    __syncthreads();
-    int nid = id_of(__builtin_amdgcn_readfirstlane(s_ticket));
-    __syncthreads();
-#else
-    int id = blockIdx.x, nid = id + gridDim.x;
-#endif
-    Loads cur, nxt;
-    UpsResults<AOFMT, kTileH> pend, out;      // `out` is written at the end of a tile, `pend` stored (and dead) early in the next one
-    bool fast = false, has_pending = false;
-    int tile = 0, frame = 0, ptile = 0, pframe = 0;
-    // (a frame-major id -> tile map and a staggered start of the seven workgroups of a CU changed nothing:
-    // profiles/r03_ab_persistent_map_stagger.jsonl)
-    auto decode = [&](int i, int &t, int &f) {
-        const int g = xcd_contiguous(i, total);
-        f = g / per_frame;
-        t = g - f * per_frame;
-    };
-    if (id < total) {
-        decode(id, tile, frame);
-        fast = interior(tile, frame);
-        if (fast) ups_issue_interior_loads<AOFMT, true, kTileH, true>(a, tile, frame, cur);
-    }
-    [[maybe_unused]] int wg_tiles = 0;
-    PhaseClock loop_clk(16);        // 16: from the end-of-tile barrier to the call of the next tile; 17: the tile; 18: its end-of-tile barrier
-    while (id < total) {
-#if MEAO_X_UPS_PERSISTENT == 3
-        int drawn = -1;                                                      // -1: nothing drawn (the pool is known to be empty)
-        uint32_t *const draw_from = nid < total ? counter : nullptr;         // stop drawing once a ticket was out of range
-#else
-        int drawn = -1;
-        uint32_t *const draw_from = nullptr;
-#endif
-        int ntile = 0, nframe = 0;
-        bool nfast = false;
-        if (nid < total) {
-            decode(nid, ntile, nframe);
-            nfast = interior(ntile, nframe);
-        }
-        loop_clk.mark(0);
-        ++wg_tiles;
-        if (fast) {
-            const IssueNextTileLoads<AOFMT, true, kTileH> hook = {a, nxt, nfast, ntile, nframe, pend, has_pending, ptile, pframe, draw_from, drawn};
-            upsample_tile<AOFMT, RTNE, true, DIV, false, IssueNextTileLoads<AOFMT, true, kTileH>, kTileH, true>(a, smem, tile, frame, hook, &cur, &out);
-            pend = out;
-            has_pending = true; ptile = tile; pframe = frame;
-        } else {
-            if (has_pending) ups_store_results<AOFMT, true, kTileH>(a, ptile, pframe, pend);
-            has_pending = false;
-            if (draw_from && threadIdx.x == 0) drawn = static_cast<int>(atomicAdd(draw_from, 1u));
-            if (hostile_mask >> frame & 1u) upsample_tile<AOFMT, RTNE, true, DIV_IEEE>(a, smem, tile, frame);
-            else upsample_tile<AOFMT, RTNE, true, DIV>(a, smem, tile, frame);
-            if (nfast) ups_issue_interior_loads<AOFMT, true, kTileH, true>(a, ntile, nframe, nxt);
-        }
-#if MEAO_X_UPS_PERSISTENT == 3
-        if (threadIdx.x == 0) s_ticket = drawn;
-#endif
-        loop_clk.mark(1);
-        __syncthreads();       // the next tile's fill overwrites what slower waves still read
-        loop_clk.mark(2);
-#if MEAO_X_UPS_PERSISTENT == 3
-        const int nnid = id_of(__builtin_amdgcn_readfirstlane(s_ticket));
-        __syncthreads();       // ... and thread 0 overwrites s_ticket at the top of the next tile
-#endif
-        cur = nxt;
-        id = nid; tile = ntile; frame = nframe; fast = nfast;
-#if MEAO_X_UPS_PERSISTENT == 3
-        nid = nnid;
-#else
-        nid = id + gridDim.x;
-#endif
-    }
-    if (has_pending) ups_store_results<AOFMT, true, kTileH>(a, ptile, pframe, pend);
-#if MEAO_X_PHASE_CLOCKS
-    if (threadIdx.x == 0 && blockIdx.x < 4096) {
-        g_wg_log[blockIdx.x * 4 + 0] = wg_t0;
-        g_wg_log[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-        g_wg_log[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
-        g_wg_log[blockIdx.x * 4 + 3] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 0xFu) |     // HW_REG_XCC_ID
-                                       (static_cast<unsigned long long>(wg_tiles) << 8);
-    }
-#endif
-#if MEAO_X_UPS_PERSISTENT == 3
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(a.tickets + kTicketWords - 1, 1u) == gridDim.x - 1) {        // every other workgroup has drawn its last ticket
-            for (int k = 0; k < groups; ++k) a.tickets[k] = 0;
-            a.tickets[kTicketWords - 1] = 0;
-            __threadfence();
-        }
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2839,32 +2603,9 @@ hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hi
     return launch_render_any<true>(a, ao_format, frames, s);
 }
 
-// workgroups of a persistent launch: 7 per CU (what the 22.8 KB of LDS per workgroup allow), a multiple of 8
-[[maybe_unused]] static int persistent_grid(int total)
-{
-    static int cus[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev = dev < 0 || dev >= 64 ? 0 : dev;
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    const int want = cus[dev] * 7 / 8 * 8;
-    return total < want ? (total + 7) / 8 * 8 : want;
-}
-
 template <int AOFMT, bool RTNE, int DIV>
 static void launch_upsample_t(const UpsampleArgs &a, bool final_pass, dim3 grid, hipStream_t s)
 {
-#if MEAO_X_UPS_PERSISTENT
-    if (final_pass && a.tile_h != kUpsTileHSmall) {
-        const int frames = static_cast<int>(grid.z), total = a.tiles_x * a.tiles_y * frames;
-        upsample_final_persistent_kernel<AOFMT, RTNE, DIV><<<dim3(persistent_grid(total)), dim3(kThreads), 0, s>>>(a, frames);
-        return;
-    }
-#endif
     if (final_pass && a.tile_h == kUpsTileHSmall) upsample_final_small_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else if (final_pass) upsample_kernel<AOFMT, RTNE, true, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else upsample_kernel<AOFMT, RTNE, false, DIV><<<grid, dim3(kThreads), 0, s>>>(a);

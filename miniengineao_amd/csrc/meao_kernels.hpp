@@ -105,9 +105,7 @@ struct UpsampleArgs {
     int32_t vec_ok;            // hw % 4 == 0 and, in the final pass, every dst pointer aligned for 4-texel stores
     const uint32_t *hostile;   // as in RenderArgs
     uint32_t generation;
-    uint32_t *tickets;         // kTicketWords zeroed words: [group] next tile ticket of persistent launches, [kTicketWords - 1] finished workgroups (self-resetting)
 };
-constexpr int kTicketWords = 1025;
 
 // ---------------------------------------------------------------------------------------
 // TiledDepth<level> materialisation for the debug views (Downsample1/2 atlas stores)

@@ -52,7 +52,7 @@ names = ["0 window load+fill", "1 barrier", "2 H-blur", "3 barrier", "4 V-blur",
 res = {"workload": a.workload, "pipeline": a.pipeline, "pass_us": {nm: round(ms[k] * 1e3, 1) for k, nm in enumerate(_lib.PASS_NAMES) if ms[k] > 0}}
 names16 = ["0 loop top (decode next, ...)", "1 the tile", "2 end-of-tile barrier"] + ["-"] * 5
 names24 = ["0 window load+fill", "1 barrier", "2 iteration 0", "3 iteration 1", "4 iteration 2", "5 iteration 3", "-", "-"]
-for base, label in ((0, "full_resolution_pass"), (8, "blend_passes"), (16, "persistent_loop"), (24, "render")):
+for base, label in ((0, "full_resolution_pass"), (8, "blend_passes"), (24, "render")):
     tot, tab = 0.0, {}
     for p, nm in enumerate(names16 if base == 16 else names24 if base == 24 else names):
         cnt = buf[32 + base + p]
