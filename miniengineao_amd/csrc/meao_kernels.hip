@@ -1781,7 +1781,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                     bilateral_k);
                 res[e] = AO::template encode<RTNE>(v);
             }
-            ao_t *o = vec_ok ? at_byte_offset(dst, static_cast<uint32_t>(hy * hw + hx0) * static_cast<uint32_t>(sizeof(ao_t))) : dst + hrow;
+            ao_t *o = dst + hrow;
             if (vec_ok) {
                 typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
                 // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
