@@ -69,6 +69,10 @@ for k in range(count):
         d_in = [torch.from_numpy(raw_bytes.copy()).cuda() for _ in range(2)]
         d_out = [torch.zeros((h, w), dtype=torch.uint8 if s.ao_format == 0 else torch.int16, device="cuda") for _ in range(2)]
         pin, pout = [t.data_ptr() for t in d_in], [t.data_ptr() for t in d_out]
+        if k % 2 == 0:      # half of these cases: the announced downsample pass on the side stream, random gate / shape / split
+            from miniengineao_amd import _lib
+            gate, shape = int(rng.integers(1, 5)), int(rng.integers(0, 5))
+            ao.debug_set(_lib.DEBUG_DS_SIDE_STREAM, gate + 10 * shape + 1000 * int(rng.integers(0, 10)))
         ao.prefetch_device(pin)
         ao.execute_device(pin, pout)
         ao.execute_device(pin, pout)
