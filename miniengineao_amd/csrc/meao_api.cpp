@@ -433,10 +433,11 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
                 tiles32 += ((p.mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p.mip[l].h + kRenTileH - 1) / kRenTileH);
             if (n * tiles32 <= ctx->render_small_max_tiles) tile_h = kRenTileHSmall;
         }
-        rn.tile_h = tile_h;
-        // producer / consumer experiment: 96 x 32 tiles (only the plain interleaved checker-set launch of a call with many tiles)
+        // producer / consumer experiment: 96 x 32 (render_pc = 1) or 96 x 48 (2) tiles (only the plain interleaved checker-set launch of a call with many tiles)
         const bool pc = allow_small && !wide && ctx->render_pc != 0 && tile_h == kRenTileH && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE;
         rn.tile_w = pc ? 96 : (wide ? kWideTileW : ren_tile_w(c.sample_set == MEAO_SAMPLES_EXHAUSTIVE));
+        if (pc && ctx->render_pc == 2) tile_h = 48;
+        rn.tile_h = tile_h;
         for (int l = first; l <= last; ++l) {
             if (wide && !level_has_hq(c.num_levels, c.hq_levels, l)) continue;
             RenderLevelArgs &L = rn.level[count++];
@@ -1347,7 +1348,7 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
-    case MEAO_DEBUG_RENDER_PRODUCER_CONSUMER: ctx->render_pc = value != 0; break;
+    case MEAO_DEBUG_RENDER_PRODUCER_CONSUMER: ctx->render_pc = value < 0 || value > 2 ? 0 : value; break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
         if (value < 0 || value % 10 > 4 || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
             return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");

@@ -1031,11 +1031,12 @@ __global__ __launch_bounds__(ren_tile_w(EXH) * 4, EXH ? 1 : 8) void render_kerne
 // window buffer while waves 12..15 fill the other buffer with tile k + 1; one workgroup barrier per tile.  Tiles are 96 x 32
 // (24 blocks of 32 x 4 = two per compute wave; window 128 x 64 floats = 32 KB, two buffers = 64 KB per workgroup).  Per SIMD:
 // six compute waves and two loader waves that issue ~10 % of the instructions.  Same arithmetic, same bits.
-constexpr int kPcTileW = 96, kPcLdsW = kPcTileW + 2 * kRenApron, kPcLdsH = kRenTileH + 2 * kRenApron;
+constexpr int kPcTileW = 96, kPcLdsW = kPcTileW + 2 * kRenApron;
 constexpr int kPcComputeWaves = 12, kPcLoaderWaves = 4, kPcThreads = 64 * (kPcComputeWaves + kPcLoaderWaves);
 
 struct PcTile { int frame, level, X0, Y0; };
 
+template <int TILE_H>
 __device__ __forceinline__ PcTile pc_decode(const RenderArgs &a, int id, int total)
 {
     const int g = xcd_contiguous(id, total);
@@ -1049,62 +1050,67 @@ __device__ __forceinline__ PcTile pc_decode(const RenderArgs &a, int id, int tot
     const RenderLevelArgs &L = a.level[t.level];
     b -= L.block_begin;
     t.X0 = (b % L.tiles_x) * kPcTileW;
-    t.Y0 = (b / L.tiles_x) * kRenTileH;
+    t.Y0 = (b / L.tiles_x) * TILE_H;
     return t;
 }
 
-// the window fill of render_tile, by the 256 lanes of the loader waves (t = 0..255): eight 16-byte loads in flight per lane
-template <bool RTNE>
+// where quad q of the window comes from: index of its first texel in the level (-1: all padding) and whether a 16-byte load covers it
+template <int TILE_H>
+__device__ __forceinline__ void pc_quad_source(const RenderLevelArgs &L, const PcTile &T, int q, bool vec_ok, int &row_at, bool &whole)
+{
+    constexpr int kQuadsX = kPcLdsW / 4;
+    const int qx = q % kQuadsX, qy = q / kQuadsX;
+    const int px0 = clampi((T.X0 >> 2) - (kRenApron >> 2) + qx, 0, L.sw - 1) * 4;
+    const int vy = T.Y0 - kRenApron + qy;
+    const int py = clampi(vy >> 2, 0, L.sh - 1) * 4 + (vy & 3);
+    row_at = py < L.lh ? py * L.lw + px0 : -1;
+    whole = py < L.lh && vec_ok && px0 + 3 < L.lw;
+}
+
+// the window fill of render_tile, by the 256 lanes of the loader waves (t = 0..255): all of a lane's 16-byte loads in flight at once
+// (the quads' sources are computed again behind the loads instead of being kept: the kernel has 64 VGPRs for everyone)
+template <bool RTNE, int TILE_H>
 __device__ __forceinline__ void pc_fill(const RenderArgs &a, const PcTile &T, float *tile, int t)
 {
     const RenderLevelArgs &L = a.level[T.level];
-    const int lw = L.lw, lh = L.lh;
+    const int lw = L.lw;
     const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, T.frame);
     const float pad = through_f16<RTNE>(L.pad_value);
     const bool vec_ok = (lw & 3) == 0;
-    constexpr int kLanes = 64 * kPcLoaderWaves, kQuadsX = kPcLdsW / 4, kQuads = kQuadsX * kPcLdsH, kRounds = kQuads / kLanes;
+    constexpr int kLanes = 64 * kPcLoaderWaves, kQuadsX = kPcLdsW / 4, kQuads = kQuadsX * (TILE_H + 2 * kRenApron), kRounds = kQuads / kLanes;
     static_assert(kQuads % kLanes == 0, "every loader lane fills the same number of quads");
-    constexpr int kInFlight = 4;          // loads in flight per lane (the loaders have a whole tile's arithmetic of time; 64 VGPRs for everyone)
-    static_assert(kRounds % kInFlight == 0, "");
-#pragma unroll 1
-    for (int r0 = 0; r0 < kRounds; r0 += kInFlight) {
-        float4v raw[kInFlight];
-        int row_at[kInFlight];
-        bool whole[kInFlight];
+    float4v raw[kRounds];
 #pragma unroll
-        for (int r = 0; r < kInFlight; ++r) {
-            const int q = t + (r0 + r) * kLanes;
-            const int qx = q % kQuadsX, qy = q / kQuadsX;
-            const int px0 = clampi((T.X0 >> 2) - (kRenApron >> 2) + qx, 0, L.sw - 1) * 4;
-            const int vy = T.Y0 - kRenApron + qy;
-            const int py = clampi(vy >> 2, 0, L.sh - 1) * 4 + (vy & 3);
-            row_at[r] = py < lh ? py * lw + px0 : -1;
-            whole[r] = py < lh && vec_ok && px0 + 3 < lw;
-            if (whole[r]) raw[r] = *reinterpret_cast<const float4v *>(src + row_at[r]);
-        }
+    for (int r = 0; r < kRounds; ++r) {
+        int row_at; bool whole;
+        pc_quad_source<TILE_H>(L, T, t + r * kLanes, vec_ok, row_at, whole);
+        if (whole) raw[r] = *reinterpret_cast<const float4v *>(at_byte_offset(src, static_cast<uint32_t>(row_at) * 4u));
+    }
+    int t2 = t;
+    asm volatile("" : "+v"(t2));          // recompute below
 #pragma unroll
-        for (int r = 0; r < kInFlight; ++r) {
-            const int q = t + (r0 + r) * kLanes;
-            const int qx = q % kQuadsX, qy = q / kQuadsX;
-            float4v v = {pad, pad, pad, pad};
-            if (whole[r]) {
-                const float2v lo = through_f16_pair<RTNE>(raw[r].x, raw[r].y), hi = through_f16_pair<RTNE>(raw[r].z, raw[r].w);
-                v = float4v{lo.x, lo.y, hi.x, hi.y};
-            } else if (row_at[r] >= 0) {
-                const float *row = src + row_at[r];
-                const int px0 = row_at[r] % lw;
-                if (px0 + 0 < lw) v.x = through_f16<RTNE>(row[0]);
-                if (px0 + 1 < lw) v.y = through_f16<RTNE>(row[1]);
-                if (px0 + 2 < lw) v.z = through_f16<RTNE>(row[2]);
-                if (px0 + 3 < lw) v.w = through_f16<RTNE>(row[3]);
-            }
-            *reinterpret_cast<float4v *>(&tile[qy * kPcLdsW + qx * 4]) = v;
+    for (int r = 0; r < kRounds; ++r) {
+        const int q = t2 + r * kLanes;
+        int row_at; bool whole;
+        pc_quad_source<TILE_H>(L, T, q, vec_ok, row_at, whole);
+        float4v v = {pad, pad, pad, pad};
+        if (whole) {
+            const float2v lo = through_f16_pair<RTNE>(raw[r].x, raw[r].y), hi = through_f16_pair<RTNE>(raw[r].z, raw[r].w);
+            v = float4v{lo.x, lo.y, hi.x, hi.y};
+        } else if (row_at >= 0) {
+            const float *row = src + row_at;
+            const int px0 = row_at % lw;
+            if (px0 + 0 < lw) v.x = through_f16<RTNE>(row[0]);
+            if (px0 + 1 < lw) v.y = through_f16<RTNE>(row[1]);
+            if (px0 + 2 < lw) v.z = through_f16<RTNE>(row[2]);
+            if (px0 + 3 < lw) v.w = through_f16<RTNE>(row[3]);
         }
+        *reinterpret_cast<float4v *>(&tile[(q / kQuadsX) * kPcLdsW + (q % kQuadsX) * 4]) = v;
     }
 }
 
-// the texel loop of render_tile for compute wave `cwave` (0..11): two 32 x 4 blocks of the 96 x 32 tile
-template <int AOFMT, bool RTNE, int DIV>
+// the texel loop of render_tile for compute wave `cwave` (0..11): TILE_H / 16 blocks of 32 x 4 texels of the 96 x TILE_H tile
+template <int AOFMT, bool RTNE, int DIV, int TILE_H>
 __device__ __forceinline__ void pc_compute(const RenderArgs &a, const PcTile &T, const float *tile, int cwave, int lane)
 {
     typedef AoTexel<AOFMT> AO;
@@ -1113,8 +1119,8 @@ __device__ __forceinline__ void pc_compute(const RenderArgs &a, const PcTile &T,
     typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, T.frame);
     const bool pair_store = ((lw & 1) == 0);
     const TermConstants<false> terms(L);
-    constexpr int kBlocksX = kPcTileW / 32, kIterations = kBlocksX * (kRenTileH / 4) / kPcComputeWaves;
-    static_assert(kIterations * kPcComputeWaves == kBlocksX * (kRenTileH / 4), "the tile's blocks divide evenly among the compute waves");
+    constexpr int kBlocksX = kPcTileW / 32, kIterations = kBlocksX * (TILE_H / 4) / kPcComputeWaves;
+    static_assert(kIterations * kPcComputeWaves == kBlocksX * (TILE_H / 4), "the tile's blocks divide evenly among the compute waves");
 #pragma unroll 1
     for (int k = 0; k < kIterations; ++k) {
         const int blk = k * kPcComputeWaves + cwave;
@@ -1138,10 +1144,11 @@ __device__ __forceinline__ void pc_compute(const RenderArgs &a, const PcTile &T,
     }
 }
 
-template <int AOFMT, bool RTNE, int DIV>
+template <int AOFMT, bool RTNE, int DIV, int TILE_H>
 __global__ __launch_bounds__(kPcThreads, 8) void render_pc_kernel(const RenderArgs a, int frames)
 {
-    __shared__ __attribute__((aligned(16))) float window[2][kPcLdsH * kPcLdsW];
+    constexpr int kWindow = (TILE_H + 2 * kRenApron) * kPcLdsW;
+    __shared__ __attribute__((aligned(16))) float window[2][kWindow];
     const int total = a.blocks_per_frame * frames;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const bool loader = wave >= kPcComputeWaves;
@@ -1149,19 +1156,19 @@ __global__ __launch_bounds__(kPcThreads, 8) void render_pc_kernel(const RenderAr
     int id = blockIdx.x;
     if (loader) {
         __builtin_amdgcn_s_setprio(3);           // the few instructions that put a window's loads in flight go first
-        if (id < total) pc_fill<RTNE>(a, pc_decode(a, id, total), window[0], t);
+        if (id < total) pc_fill<RTNE, TILE_H>(a, pc_decode<TILE_H>(a, id, total), window[0], t);
     }
     __syncthreads();
     for (int k = 0; id < total; ++k) {
         const int nid = id + gridDim.x;
         if (loader) {
-            if (nid < total) pc_fill<RTNE>(a, pc_decode(a, nid, total), window[(k + 1) & 1], t);
+            if (nid < total) pc_fill<RTNE, TILE_H>(a, pc_decode<TILE_H>(a, nid, total), window[(k + 1) & 1], t);
         } else {
-            const PcTile T = pc_decode(a, id, total);
+            const PcTile T = pc_decode<TILE_H>(a, id, total);
             bool ieee = false;
             if constexpr (DIV == DIV_EXACT_RCP) ieee = frame_is_hostile(a.hostile, a.generation, T.frame);     // wave-uniform, per frame
-            if (ieee) pc_compute<AOFMT, RTNE, DIV_IEEE>(a, T, window[k & 1], wave, lane);
-            else pc_compute<AOFMT, RTNE, DIV>(a, T, window[k & 1], wave, lane);
+            if (ieee) pc_compute<AOFMT, RTNE, DIV_IEEE, TILE_H>(a, T, window[k & 1], wave, lane);
+            else pc_compute<AOFMT, RTNE, DIV, TILE_H>(a, T, window[k & 1], wave, lane);
         }
         __syncthreads();        // tile k's buffer is free, tile k + 1's is full
         id = nid;
@@ -2727,12 +2734,13 @@ hipError_t launch_render_producer_consumer(const RenderArgs &a, int ao_format, i
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const int total = a.blocks_per_frame * frames;
     const dim3 grid(std::min((2 * cus) / 8 * 8, (total + 7) / 8 * 8)), block(kPcThreads);
-#define MEAO_PC(AOFMT) \
-    if (a.f16_rtne) render_pc_kernel<AOFMT, true, DIV_IEEE><<<grid, block, 0, s>>>(a, frames); \
-    else if (a.exact_rcp_div == 2) render_pc_kernel<AOFMT, false, DIV_FAST><<<grid, block, 0, s>>>(a, frames); \
-    else if (a.exact_rcp_div) render_pc_kernel<AOFMT, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a, frames); \
-    else render_pc_kernel<AOFMT, false, DIV_IEEE><<<grid, block, 0, s>>>(a, frames)
-    if (ao_format == MEAO_AO_R8) { MEAO_PC(MEAO_AO_R8); } else { MEAO_PC(MEAO_AO_F16); }
+#define MEAO_PC(AOFMT, H) \
+    if (a.f16_rtne) render_pc_kernel<AOFMT, true, DIV_IEEE, H><<<grid, block, 0, s>>>(a, frames); \
+    else if (a.exact_rcp_div == 2) render_pc_kernel<AOFMT, false, DIV_FAST, H><<<grid, block, 0, s>>>(a, frames); \
+    else if (a.exact_rcp_div) render_pc_kernel<AOFMT, false, DIV_EXACT_RCP, H><<<grid, block, 0, s>>>(a, frames); \
+    else render_pc_kernel<AOFMT, false, DIV_IEEE, H><<<grid, block, 0, s>>>(a, frames)
+    if (a.tile_h == 48) { if (ao_format == MEAO_AO_R8) { MEAO_PC(MEAO_AO_R8, 48); } else { MEAO_PC(MEAO_AO_F16, 48); } }
+    else if (ao_format == MEAO_AO_R8) { MEAO_PC(MEAO_AO_R8, 32); } else { MEAO_PC(MEAO_AO_F16, 32); }
 #undef MEAO_PC
     return hipGetLastError();
 }

@@ -357,7 +357,7 @@ def test_both_render_tilings_are_bit_exact(oracle, small_tiles, variant, w, h, b
              L.DEBUG_FINAL_SMALL_MAX_TILES: max(small_tiles, 0),     # final pass: 64 x 32 / 64 x 64 tiles
              L.DEBUG_DS_SMALL_MAX_TILES: max(small_tiles, 0)}        # downsample pass: 128 x 8 / 128 x 32 tiles
     if small_tiles < 0:
-        debug[L.DEBUG_RENDER_PRODUCER_CONSUMER] = 1
+        debug[L.DEBUG_RENDER_PRODUCER_CONSUMER] = 1 + (batch & 1)       # 96 x 32 or 96 x 48 tiles
     s = H.settings(oracle, w, h, **variant)
     frames = [synth.make("S2", w, h, seed=70 + f) for f in range(batch)]
     frames[0] = H.hostile_frame(w, h, 78, density=0.01)
