@@ -82,7 +82,6 @@ struct meao_ctx {
     // it), 2 = in front of L2->L1, 3 = in front of the coarse blend launch, 4 = in front of render; shape 0 = 16 loads
     // per lane in flight, 120 VGPRs declared, 1 = 16 loads, 2 = 8 loads, 3 = 4 loads (the stand-alone pass's tile).
     int ds_side_stream = 0;
-    int render_pc = 0;                 // MEAO_DEBUG_RENDER_PRODUCER_CONSUMER: the interleaved render pass as persistent producer / consumer workgroups (experiment)
     hipStream_t side_stream = nullptr;
     hipEvent_t side_gate = nullptr, side_done = nullptr;
     bool side_pending = false;         // a side-stream downsample was issued and no later execute has ordered itself behind it yet
@@ -433,10 +432,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
                 tiles32 += ((p.mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p.mip[l].h + kRenTileH - 1) / kRenTileH);
             if (n * tiles32 <= ctx->render_small_max_tiles) tile_h = kRenTileHSmall;
         }
-        // producer / consumer experiment: 96 x 32 (render_pc = 1) or 96 x 48 (2) tiles (only the plain interleaved checker-set launch of a call with many tiles)
-        const bool pc = allow_small && !wide && ctx->render_pc != 0 && tile_h == kRenTileH && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE;
-        rn.tile_w = pc ? 96 : (wide ? kWideTileW : ren_tile_w(c.sample_set == MEAO_SAMPLES_EXHAUSTIVE));
-        if (pc && ctx->render_pc == 2) tile_h = 48;
         rn.tile_h = tile_h;
         for (int l = first; l <= last; ++l) {
             if (wide && !level_has_hq(c.num_levels, c.hq_levels, l)) continue;
@@ -446,7 +441,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             L.dst = slot_ptr<void>(ctx, wide ? ctx->off_hq[l - 1] : ctx->off_occ[l - 1]);
             L.lw = p.mip[l].w; L.lh = p.mip[l].h;
             L.sw = p.mip[l + 2].w; L.sh = p.mip[l + 2].h;
-            const int tile_w = rn.tile_w;
+            const int tile_w = wide ? kWideTileW : ren_tile_w(c.sample_set == MEAO_SAMPLES_EXHAUSTIVE);
             L.tiles_x = (L.lw + tile_w - 1) / tile_w;
             L.tiles_y = (L.lh + tile_h - 1) / tile_h;
             L.block_begin = blocks;
@@ -595,9 +590,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             MEAO_HIP(ctx, launch_render_with_composite(render_args(1, c.num_levels, false), ctx->pending_comp, c.ao_format, n, stream));
             ctx->pending_comp.frames = 0;
         } else {
-            const RenderArgs rn = render_args(1, c.num_levels, false, true);
-            if (rn.tile_w == 96) MEAO_HIP(ctx, launch_render_producer_consumer(rn, c.ao_format, n, stream));
-            else MEAO_HIP(ctx, launch_render(rn, c.ao_format, n, stream));
+            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false, true), c.ao_format, n, stream));
         }
         MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
     }
@@ -1348,7 +1341,6 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
-    case MEAO_DEBUG_RENDER_PRODUCER_CONSUMER: ctx->render_pc = value < 0 || value > 2 ? 0 : value; break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
         if (value < 0 || value % 10 > 4 || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
             return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");

@@ -1023,158 +1023,10 @@ __global__ __launch_bounds__(ren_tile_w(EXH) * 4, EXH ? 1 : 8) void render_kerne
 // the hand-overs per texel -- measured 170.2 vs 166.2 us per 16 frames at 4K, profiles/r04_ab_render_tile_128x64.jsonl: the
 // barrier of sixteen waves and a hand-over that idles half a CU cost more than the smaller apron saves.  With 96 x 32 (r03),
 // 64 x 32 (r01) and the dynamic blocks (r03) that closes the tile-shape question: render runs at 2.98 cycles per VALU
-// instruction, the hand-over of a full CU's LDS is what separates it from the 2.4-2.55 of its loop, and no shape removes it.)
-// ---- experiment (meao_debug_set MEAO_DEBUG_RENDER_PRODUCER_CONSUMER): render as persistent producer / consumer workgroups ----
-// What separates render_kernel from the issue rate of its loop is the hand-over of a workgroup's LDS window: the CU's LDS and
-// wave slots are both full, so a successor can only start loading when a whole workgroup has drained (29 % of a slot's time).
-// Here a workgroup never hands over: 1024 threads stay resident (two workgroups per CU), waves 0..11 evaluate tile k from one
-// window buffer while waves 12..15 fill the other buffer with tile k + 1; one workgroup barrier per tile.  Tiles are 96 x 32
-// (24 blocks of 32 x 4 = two per compute wave; window 128 x 64 floats = 32 KB, two buffers = 64 KB per workgroup).  Per SIMD:
-// six compute waves and two loader waves that issue ~10 % of the instructions.  Same arithmetic, same bits.
-constexpr int kPcTileW = 96, kPcLdsW = kPcTileW + 2 * kRenApron;
-constexpr int kPcComputeWaves = 12, kPcLoaderWaves = 4, kPcThreads = 64 * (kPcComputeWaves + kPcLoaderWaves);
-
-struct PcTile { int frame, level, X0, Y0; };
-
-template <int TILE_H>
-__device__ __forceinline__ PcTile pc_decode(const RenderArgs &a, int id, int total)
-{
-    const int g = xcd_contiguous(id, total);
-    PcTile t;
-    t.frame = g / a.blocks_per_frame;
-    int b = g - t.frame * a.blocks_per_frame;
-    t.level = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-        if (k < a.num_levels && b >= a.level[k].block_begin) t.level = k;
-    const RenderLevelArgs &L = a.level[t.level];
-    b -= L.block_begin;
-    t.X0 = (b % L.tiles_x) * kPcTileW;
-    t.Y0 = (b / L.tiles_x) * TILE_H;
-    return t;
-}
-
-// where quad q of the window comes from: index of its first texel in the level (-1: all padding) and whether a 16-byte load covers it
-template <int TILE_H>
-__device__ __forceinline__ void pc_quad_source(const RenderLevelArgs &L, const PcTile &T, int q, bool vec_ok, int &row_at, bool &whole)
-{
-    constexpr int kQuadsX = kPcLdsW / 4;
-    const int qx = q % kQuadsX, qy = q / kQuadsX;
-    const int px0 = clampi((T.X0 >> 2) - (kRenApron >> 2) + qx, 0, L.sw - 1) * 4;
-    const int vy = T.Y0 - kRenApron + qy;
-    const int py = clampi(vy >> 2, 0, L.sh - 1) * 4 + (vy & 3);
-    row_at = py < L.lh ? py * L.lw + px0 : -1;
-    whole = py < L.lh && vec_ok && px0 + 3 < L.lw;
-}
-
-// the window fill of render_tile, by the 256 lanes of the loader waves (t = 0..255): all of a lane's 16-byte loads in flight at once
-// (the quads' sources are computed again behind the loads instead of being kept: the kernel has 64 VGPRs for everyone)
-template <bool RTNE, int TILE_H>
-__device__ __forceinline__ void pc_fill(const RenderArgs &a, const PcTile &T, float *tile, int t)
-{
-    const RenderLevelArgs &L = a.level[T.level];
-    const int lw = L.lw;
-    const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, T.frame);
-    const float pad = through_f16<RTNE>(L.pad_value);
-    const bool vec_ok = (lw & 3) == 0;
-    constexpr int kLanes = 64 * kPcLoaderWaves, kQuadsX = kPcLdsW / 4, kQuads = kQuadsX * (TILE_H + 2 * kRenApron), kRounds = kQuads / kLanes;
-    static_assert(kQuads % kLanes == 0, "every loader lane fills the same number of quads");
-    float4v raw[kRounds];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        int row_at; bool whole;
-        pc_quad_source<TILE_H>(L, T, t + r * kLanes, vec_ok, row_at, whole);
-        if (whole) raw[r] = *reinterpret_cast<const float4v *>(at_byte_offset(src, static_cast<uint32_t>(row_at) * 4u));
-    }
-    int t2 = t;
-    asm volatile("" : "+v"(t2));          // recompute below
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const int q = t2 + r * kLanes;
-        int row_at; bool whole;
-        pc_quad_source<TILE_H>(L, T, q, vec_ok, row_at, whole);
-        float4v v = {pad, pad, pad, pad};
-        if (whole) {
-            const float2v lo = through_f16_pair<RTNE>(raw[r].x, raw[r].y), hi = through_f16_pair<RTNE>(raw[r].z, raw[r].w);
-            v = float4v{lo.x, lo.y, hi.x, hi.y};
-        } else if (row_at >= 0) {
-            const float *row = src + row_at;
-            const int px0 = row_at % lw;
-            if (px0 + 0 < lw) v.x = through_f16<RTNE>(row[0]);
-            if (px0 + 1 < lw) v.y = through_f16<RTNE>(row[1]);
-            if (px0 + 2 < lw) v.z = through_f16<RTNE>(row[2]);
-            if (px0 + 3 < lw) v.w = through_f16<RTNE>(row[3]);
-        }
-        *reinterpret_cast<float4v *>(&tile[(q / kQuadsX) * kPcLdsW + (q % kQuadsX) * 4]) = v;
-    }
-}
-
-// the texel loop of render_tile for compute wave `cwave` (0..11): TILE_H / 16 blocks of 32 x 4 texels of the 96 x TILE_H tile
-template <int AOFMT, bool RTNE, int DIV, int TILE_H>
-__device__ __forceinline__ void pc_compute(const RenderArgs &a, const PcTile &T, const float *tile, int cwave, int lane)
-{
-    typedef AoTexel<AOFMT> AO;
-    const RenderLevelArgs &L = a.level[T.level];
-    const int lw = L.lw, lh = L.lh;
-    typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, T.frame);
-    const bool pair_store = ((lw & 1) == 0);
-    const TermConstants<false> terms(L);
-    constexpr int kBlocksX = kPcTileW / 32, kIterations = kBlocksX * (TILE_H / 4) / kPcComputeWaves;
-    static_assert(kIterations * kPcComputeWaves == kBlocksX * (TILE_H / 4), "the tile's blocks divide evenly among the compute waves");
-#pragma unroll 1
-    for (int k = 0; k < kIterations; ++k) {
-        const int blk = k * kPcComputeWaves + cwave;
-        const int txl = (blk % kBlocksX) * 16 + (lane & 15), ly = (blk / kBlocksX) * 4 + (lane >> 4);
-        const int X = T.X0 + 2 * txl, Y = T.Y0 + ly;
-        if (X < lw && Y < lh) {
-            const float *centre = &tile[(ly + kRenApron) * kPcLdsW + 2 * txl + kRenApron];
-            const float2v c = *reinterpret_cast<const float2v *>(centre);
-            const float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-            const float2v out = accumulate_terms_pipelined<4 * kPcLdsW, 4, 1>(terms, centre, inv_depth);
-            typename AO::type *p = dst + static_cast<size_t>(Y) * lw + X;
-            const typename AO::type e0 = AO::template encode<RTNE>(out.x), e1 = AO::template encode<RTNE>(out.y);
-            if (pair_store) {
-                typename AO::type2 pr; pr.x = e0; pr.y = e1;
-                *reinterpret_cast<typename AO::type2 *>(p) = pr;
-            } else {
-                p[0] = e0;
-                if (X + 1 < lw) p[1] = e1;
-            }
-        }
-    }
-}
-
-template <int AOFMT, bool RTNE, int DIV, int TILE_H>
-__global__ __launch_bounds__(kPcThreads, 8) void render_pc_kernel(const RenderArgs a, int frames)
-{
-    constexpr int kWindow = (TILE_H + 2 * kRenApron) * kPcLdsW;
-    __shared__ __attribute__((aligned(16))) float window[2][kWindow];
-    const int total = a.blocks_per_frame * frames;
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const bool loader = wave >= kPcComputeWaves;
-    const int t = static_cast<int>(threadIdx.x) - 64 * kPcComputeWaves;
-    int id = blockIdx.x;
-    if (loader) {
-        __builtin_amdgcn_s_setprio(3);           // the few instructions that put a window's loads in flight go first
-        if (id < total) pc_fill<RTNE, TILE_H>(a, pc_decode<TILE_H>(a, id, total), window[0], t);
-    }
-    __syncthreads();
-    for (int k = 0; id < total; ++k) {
-        const int nid = id + gridDim.x;
-        if (loader) {
-            if (nid < total) pc_fill<RTNE, TILE_H>(a, pc_decode<TILE_H>(a, nid, total), window[(k + 1) & 1], t);
-        } else {
-            const PcTile T = pc_decode<TILE_H>(a, id, total);
-            bool ieee = false;
-            if constexpr (DIV == DIV_EXACT_RCP) ieee = frame_is_hostile(a.hostile, a.generation, T.frame);     // wave-uniform, per frame
-            if (ieee) pc_compute<AOFMT, RTNE, DIV_IEEE, TILE_H>(a, T, window[k & 1], wave, lane);
-            else pc_compute<AOFMT, RTNE, DIV, TILE_H>(a, T, window[k & 1], wave, lane);
-        }
-        __syncthreads();        // tile k's buffer is free, tile k + 1's is full
-        id = nid;
-    }
-}
-
+// instruction, the hand-over of a full CU's LDS is what separates it from the 2.4-2.55 of its loop, and no shape removes it.
+// Nor does taking the hand-over away: persistent 1024-thread workgroups whose four loader waves fill the next tile's window while
+// twelve compute waves evaluate the current one (two window buffers, one barrier per tile) run at 209-220 us -- the barrier of
+// sixteen waves per tile costs more than the hand-over did: profiles/r04_ab_render_producer_consumer.jsonl.)
 // One or two small frames per call (fewer 128 x 32 tiles than CUs): 128 x 8 tiles, four times the workgroups,
 // one texel-loop iteration each -- the call waits for one workgroup's serial time, not for throughput.
 template <int AOFMT, bool RTNE, int DIV>
@@ -2723,26 +2575,6 @@ static hipError_t launch_render_any(const RenderArgs &a, int ao_format, int fram
 hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s)
 {
     return launch_render_any<false>(a, ao_format, frames, s);
-}
-
-// persistent producer / consumer form (experiment): `a` built for 96 x 32 tiles; two workgroups of 1024 threads per CU
-hipError_t launch_render_producer_consumer(const RenderArgs &a, int ao_format, int frames, hipStream_t s)
-{
-    if (a.exhaustive || a.tile_w != kPcTileW) return hipErrorInvalidValue;
-    int dev = 0, cus = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    const int total = a.blocks_per_frame * frames;
-    const dim3 grid(std::min((2 * cus) / 8 * 8, (total + 7) / 8 * 8)), block(kPcThreads);
-#define MEAO_PC(AOFMT, H) \
-    if (a.f16_rtne) render_pc_kernel<AOFMT, true, DIV_IEEE, H><<<grid, block, 0, s>>>(a, frames); \
-    else if (a.exact_rcp_div == 2) render_pc_kernel<AOFMT, false, DIV_FAST, H><<<grid, block, 0, s>>>(a, frames); \
-    else if (a.exact_rcp_div) render_pc_kernel<AOFMT, false, DIV_EXACT_RCP, H><<<grid, block, 0, s>>>(a, frames); \
-    else render_pc_kernel<AOFMT, false, DIV_IEEE, H><<<grid, block, 0, s>>>(a, frames)
-    if (a.tile_h == 48) { if (ao_format == MEAO_AO_R8) { MEAO_PC(MEAO_AO_R8, 48); } else { MEAO_PC(MEAO_AO_F16, 48); } }
-    else if (ao_format == MEAO_AO_R8) { MEAO_PC(MEAO_AO_R8, 32); } else { MEAO_PC(MEAO_AO_F16, 32); }
-#undef MEAO_PC
-    return hipGetLastError();
 }
 
 template <int AOFMT, bool RTNE, int DIV>

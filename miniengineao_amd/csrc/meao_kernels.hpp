@@ -68,7 +68,6 @@ struct RenderArgs {
     int32_t f16_rtne;
     int32_t exact_rcp_div;
     int32_t exhaustive;    // SAMPLE_EXHAUSTIVELY: 12 terms instead of 7
-    int32_t tile_w;        // columns of a tile `level[]` was built for: ren_tile_w(), or 96 for the producer / consumer experiment
     int32_t tile_h;        // kRenTileH, or kRenTileHSmall (interleaved checker-set kernel only): the tiling `level[]` was built for
     const uint32_t *hostile;   // per frame, written by the downsample pass that produced `src`
     uint32_t generation;       // hostile[frame] == generation -> IEEE-division body for that frame
@@ -124,7 +123,6 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
 hipError_t launch_downsample_side(const DownsampleArgs &a, int frames, bool pad_vgprs, hipStream_t s);
 hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
-hipError_t launch_render_producer_consumer(const RenderArgs &a, int ao_format, int frames, hipStream_t s);     // experiment, a.tile_w == 96
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
 // Two blend passes in one launch: `inner` (e.g. L4 -> L3) is evaluated per tile of `outer` (L3 -> L2) for the

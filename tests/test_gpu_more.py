@@ -345,19 +345,16 @@ def test_every_blend_launch_structure_is_bit_exact(oracle, mode, w, h, batch):
         ao.close()
 
 
-@pytest.mark.parametrize("small_tiles", [0, 1000000, -1])
+@pytest.mark.parametrize("small_tiles", [0, 1000000])
 @pytest.mark.parametrize("variant", [dict(), dict(ao_format=1, f16_rounding=1), dict(num_levels=2)])
-@pytest.mark.parametrize("w,h,batch", [(203, 117, 2), (512, 300, 1), (131, 77, 3), (1283, 721, 2)])
+@pytest.mark.parametrize("w,h,batch", [(203, 117, 2), (512, 300, 1), (131, 77, 3)])
 def test_both_render_tilings_are_bit_exact(oracle, small_tiles, variant, w, h, batch):
     """Calls with few tiles use 128 x 8 render tiles (render_small_kernel) and 64 x 32 tiles in the final
     upsample pass (upsample_final_small_kernel), larger ones 128 x 32 and 64 x 64; the thresholds are forced
-    either way here (meao_debug_set).  -1: the persistent producer / consumer render launch (96 x 32 tiles,
-    MEAO_DEBUG_RENDER_PRODUCER_CONSUMER)."""
-    debug = {L.DEBUG_RENDER_SMALL_MAX_TILES: max(small_tiles, 0),
-             L.DEBUG_FINAL_SMALL_MAX_TILES: max(small_tiles, 0),     # final pass: 64 x 32 / 64 x 64 tiles
-             L.DEBUG_DS_SMALL_MAX_TILES: max(small_tiles, 0)}        # downsample pass: 128 x 8 / 128 x 32 tiles
-    if small_tiles < 0:
-        debug[L.DEBUG_RENDER_PRODUCER_CONSUMER] = 1 + (batch & 1)       # 96 x 32 or 96 x 48 tiles
+    either way here (meao_debug_set)."""
+    debug = {L.DEBUG_RENDER_SMALL_MAX_TILES: small_tiles,
+             L.DEBUG_FINAL_SMALL_MAX_TILES: small_tiles,     # final pass: 64 x 32 / 64 x 64 tiles
+             L.DEBUG_DS_SMALL_MAX_TILES: small_tiles}        # downsample pass: 128 x 8 / 128 x 32 tiles
     s = H.settings(oracle, w, h, **variant)
     frames = [synth.make("S2", w, h, seed=70 + f) for f in range(batch)]
     frames[0] = H.hostile_frame(w, h, 78, density=0.01)
