@@ -714,6 +714,8 @@ def main() -> int:
                                  sample_set=_lib.SAMPLES_EXHAUSTIVE if args.exhaustive else _lib.SAMPLES_CHECKER,
                                  numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT, **kw)
             c.intensity = intensity
+            if args.side_stream and kw.get("pipelined"):
+                c.debug_set(_lib.DEBUG_DS_SIDE_STREAM, args.side_stream)
             return c
         lat_iters = 50
         single = {}
