@@ -116,7 +116,7 @@ typedef enum meao_pass {
                                 * window of Combined3 it reads; Combined3 is still written): no launch of its
                                 * own, meao_get_pass_times reports 0 here and the joint time under UPSAMPLE_2 */
     MEAO_PASS_UPSAMPLE_2 = 3,  /* Upsample.main_blendout L3 -> L2             (AO.cs:529).  Small calls (frames x
-                                * 64x32 tiles of L1 <= 512, e.g. one 1080p frame) evaluate it and L4 -> L3 inside
+                                * 64x32 tiles of L1 <= 1024, e.g. one 4K frame or up to four 1080p frames) evaluate it and L4 -> L3 inside
                                 * the L2 -> L1 launch: 0 here and under UPSAMPLE_3, the joint time under UPSAMPLE_1 */
     MEAO_PASS_UPSAMPLE_1 = 4,  /* Upsample.main_blendout L2 -> L1             (AO.cs:530) */
     MEAO_PASS_UPSAMPLE_0 = 5,  /* Upsample.main          L1 -> L0 result      (AO.cs:531) */

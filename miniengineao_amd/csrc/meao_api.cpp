@@ -72,9 +72,10 @@ struct meao_ctx {
     // them (tests, A/B runs) -- the library reads no environment variables.
     bool fuse_coarse_blend = true;
     int ds_small_max_tiles = 1024;     // stand-alone downsample pass: calls with at most this many 128x32 tiles use 128x8 tiles
-    int final_small_max_tiles = 512;   // plain final pass: calls with at most this many 64x64 tiles use 64x32 tiles
+    int final_small_max_tiles = 2048;  // plain final pass: calls with at most this many 64x64 tiles (one 4K frame: 2040) use 64x32 tiles (r04 sweep: 60.3 vs 60.8 us)
     int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
-    int nested_max_tiles = 512;        // calls with at most this many L2->L1 tiles (frames x tiles) run the three blend passes as one launch
+    int nested_max_tiles = 1024;       // calls with at most this many L2->L1 tiles (frames x tiles; one 4K frame: 1020) run the three blend passes as one launch
+                                       // (with the round-4 blend_window_into_lds: 55.9 vs 56.6 us per pipelined 4K frame, a tie unpipelined; 512 before)
     int ds_share_in_blend = 0;         // percent of the carried (next batch's) downsample tiles that ride in the L2->L1 blend launch instead of the last kernel
     // MEAO_DEBUG_DS_SIDE_STREAM (0 = off): the announced next batch's downsample pass as its OWN kernel on a second,
     // low-priority stream of the context, gated behind a point of this call's launch sequence, instead of riding inside
