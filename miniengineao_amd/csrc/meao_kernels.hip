@@ -66,6 +66,9 @@
 #define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
 #endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the
                                 // static instruction counts of the ISA are the dynamic ones of (almost) every workgroup
+#ifndef MEAO_X_DSR_DIAG
+#define MEAO_X_DSR_DIAG 0       // timing diagnostics of the downsample rows carried by render (WRONG results): 1 = loads only, 2 = arithmetic + stores only
+#endif
 #ifndef MEAO_X_PHASE_CLOCKS
 #define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py),
 #endif                          // the render launch logs start / end / CU of every workgroup (tools/render_wg_log.py)
@@ -2432,7 +2435,7 @@ struct CarriedDownsampleRows {
     int frame;
     bool active;                    // this workgroup has a tile, this lane a column inside the frame
     int y0, wave;                   // first row of the lane, its wave (uniform)
-    uint32_t x0, t0;                // first column; texel index of (x0, y0)
+    uint32_t x0;                    // first column of the lane
     float4v q[2];
     static __device__ __forceinline__ int first_pass(int k) { return k < 2 ? 2 * k : 2 + k; }      // rows per iteration: 2, 2, 1, 1
     static __device__ __forceinline__ int passes_in(int k) { return k < 2 ? 2 : 1; }
@@ -2444,7 +2447,6 @@ struct CarriedDownsampleRows {
         const int tile_x = tile % d.tiles_x, tile_y = tile / d.tiles_x;
         x0 = static_cast<uint32_t>(tile_x) * kDsTileW + (tid & 31u) * 4u;
         y0 = tile_y * kDsInRenderTileH + wave + 8 * static_cast<int>((tid >> 5) & 1u);
-        t0 = static_cast<uint32_t>(y0) * static_cast<uint32_t>(d.w[0]) + x0;
         active = tile < tiles && frame < d.frames && x0 < static_cast<uint32_t>(d.w[0]);
     }
     // The pass's uniform arguments are read from the kernel-argument segment again in every begin() / end(): left alone the compiler
@@ -2456,18 +2458,46 @@ struct CarriedDownsampleRows {
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
         return *reinterpret_cast<const DownsampleArgs *>(reinterpret_cast<const char *>(&d) + zero);
     }
+    // what a row needs of the pass's arguments, read in one go (a handful of wide scalar loads, one wait)
+    struct RowArgs {
+        uint32_t W, w1, w2, w3, w4;
+        int H;
+        float zp0, zp1, sky_depth;
+        uint32_t generation;
+        const float *depth;
+        uint16_t *linear;
+        float *low1, *low2, *low3, *low4;
+        uint32_t *hostile;
+    };
+    __device__ __forceinline__ RowArgs row_args(bool stores) const
+    {
+        const DownsampleArgs &a = args_now();
+        RowArgs r;
+        r.W = static_cast<uint32_t>(a.w[0]); r.H = a.h[0];
+        r.depth = static_cast<const float *>(a.depth[frame]);
+        if (stores) {
+            r.w1 = a.w[1]; r.w2 = a.w[2]; r.w3 = a.w[3]; r.w4 = a.w[4];
+            r.zp0 = a.zp0; r.zp1 = a.zp1; r.sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
+            r.generation = a.generation;
+            r.hostile = a.hostile + frame;
+            r.linear = frame_ptr(a.linear, a.frame_stride, frame);
+            r.low1 = frame_ptr(a.low[0], a.frame_stride, frame); r.low2 = frame_ptr(a.low[1], a.frame_stride, frame);
+            r.low3 = frame_ptr(a.low[2], a.frame_stride, frame); r.low4 = frame_ptr(a.low[3], a.frame_stride, frame);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return static_cast<uint32_t>(__umul24(a, b)) + c; }    // v_mad_u32_u24: operands < 2^24
     __device__ __forceinline__ void begin(int k)
     {
         if (!active) return;
-        const DownsampleArgs &d = args_now();
-        const float *__restrict__ depth = static_cast<const float *>(d.depth[frame]);
-        const uint32_t W = static_cast<uint32_t>(d.w[0]);
-        const int H = d.h[0], p0 = first_pass(k);
+        const RowArgs A = row_args(false);
+        const int p0 = first_pass(k);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j < passes_in(k)) {
-                const int y = min(y0 + 16 * (p0 + j), H - 1);          // rows past the frame re-read its last row (never used)
-                q[j] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(depth, (static_cast<uint32_t>(y) * W + x0) * 4u)));
+                const uint32_t y = static_cast<uint32_t>(min(y0 + 16 * (p0 + j), A.H - 1));          // rows past the frame re-read its last row (never used)
+                if constexpr (MEAO_X_DSR_DIAG == 2) { q[j] = float4v{0.25f, 0.5f, 0.125f, 0.75f}; continue; }
+                q[j] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(A.depth, mad24(y, A.W, x0) * 4u)));
             }
         }
         __builtin_amdgcn_sched_barrier(0);        // the loads stay here; their first use is behind the texel arithmetic
@@ -2476,17 +2506,19 @@ struct CarriedDownsampleRows {
     {
         if (!active) return;
         __builtin_amdgcn_sched_barrier(0);
-        const DownsampleArgs &d = args_now();
-        const int H = d.h[0], p0 = first_pass(k);
+        const RowArgs A = row_args(true);
+        const int p0 = first_pass(k);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            if (j < passes_in(k) && y0 + 16 * (p0 + j) < H) finish_row(d, p0 + j, q[j]);
+            if (j < passes_in(k) && y0 + 16 * (p0 + j) < A.H) {
+                if constexpr (MEAO_X_DSR_DIAG == 1) asm volatile("" : : "v"(q[j]));
+                else finish_row(A, static_cast<uint32_t>(y0 + 16 * (p0 + j)), q[j]);
+            }
     }
-    __device__ __forceinline__ void finish_row(const DownsampleArgs &d, int p, float4v row)
+    __device__ __forceinline__ void finish_row(const RowArgs &A, uint32_t y, float4v row) const
     {
         asm volatile("" : "+v"(row));             // opaque here: nothing derived from the loaded words moves up to the load
-        const float zp0 = d.zp0, zp1 = d.zp1;
-        const float sky_depth = d.reversed_z != 0 ? 0.0f : 1.0f;
+        const float zp0 = A.zp0, zp1 = A.zp1, sky_depth = A.sky_depth;
         const float v[4] = {row.x, row.y, row.z, row.w};
         float lin[4];
         if constexpr (DIV == DIV_EXACT_RCP) {
@@ -2510,14 +2542,12 @@ struct CarriedDownsampleRows {
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[e], zp0, zp1, sky_depth);
-                d.hostile[frame] = d.generation;     // racing stores of the same value
+                *A.hostile = A.generation;           // racing stores of the same value
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[e], zp0, zp1, sky_depth);
         }
-        const uint32_t W = static_cast<uint32_t>(d.w[0]), up = static_cast<uint32_t>(p);
-        const uint32_t t = t0 + up * 16u * W;
         typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
         uint2v h;                                                                // LinearZ[st] = dist (DS1:46)
         if constexpr (RTNE) {
@@ -2527,17 +2557,16 @@ struct CarriedDownsampleRows {
             h.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[0], lin[1]));
             h.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[2], lin[3]));
         }
-        __builtin_nontemporal_store(h, reinterpret_cast<uint2v *>(at_byte_offset(frame_ptr(d.linear, d.frame_stride, frame), t * 2u)));
+        __builtin_nontemporal_store(h, reinterpret_cast<uint2v *>(at_byte_offset(A.linear, mad24(y, A.W, x0) * 2u)));
         if ((wave & 1) == 0) {                                                   // even rows (wave-uniform): DS2x (DS1:64-70)
-            const uint32_t w1 = d.w[1], y = static_cast<uint32_t>(y0) + 16u * up;
-            __builtin_nontemporal_store(float2v{lin[0], lin[2]}, reinterpret_cast<float2v *>(at_byte_offset(
-                frame_ptr(d.low[0], d.frame_stride, frame), ((y >> 1) * w1 + (x0 >> 1)) * 4u)));
+            __builtin_nontemporal_store(float2v{lin[0], lin[2]},
+                                        reinterpret_cast<float2v *>(at_byte_offset(A.low1, mad24(y >> 1, A.w1, x0 >> 1) * 4u)));
             if ((wave & 3) == 0) {                                               // rows 0, 4 (+ 8) of the pass: DS4x (DS1:73-77)
-                *at_byte_offset(frame_ptr(d.low[1], d.frame_stride, frame), ((y >> 2) * static_cast<uint32_t>(d.w[2]) + (x0 >> 2)) * 4u) = lin[0];
+                *at_byte_offset(A.low2, mad24(y >> 2, A.w2, x0 >> 2) * 4u) = lin[0];
                 if (wave == 0 && (x0 & 7u) == 0) {                               // rows 0, 8: DS8x (DS2:35-40)
-                    *at_byte_offset(frame_ptr(d.low[2], d.frame_stride, frame), ((y >> 3) * static_cast<uint32_t>(d.w[3]) + (x0 >> 3)) * 4u) = lin[0];
+                    *at_byte_offset(A.low3, mad24(y >> 3, A.w3, x0 >> 3) * 4u) = lin[0];
                     if ((y & 15u) == 0 && (x0 & 15u) == 0)                       // row 0: DS16x (DS2:43-49)
-                        *at_byte_offset(frame_ptr(d.low[3], d.frame_stride, frame), ((y >> 4) * static_cast<uint32_t>(d.w[4]) + (x0 >> 4)) * 4u) = lin[0];
+                        *at_byte_offset(A.low4, mad24(y >> 4, A.w4, x0 >> 4) * 4u) = lin[0];
                 }
             }
         }

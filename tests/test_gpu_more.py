@@ -684,6 +684,6 @@ def test_next_downsample_inside_the_render_launch(oracle, variant, w, h, batch):
                     for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
                         ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
                         assert ok, (H.NAMES[i], f, int(bad.sum()))
-        assert ao.hostile_frames() == 1 << (batch - 1)
+        assert ao.hostile_frames() == (1 << (batch - 1) if not variant.get("f16_rounding") else 0)    # the flags exist in the exact-division mode only
     finally:
         ao.close()
