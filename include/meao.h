@@ -404,8 +404,6 @@ typedef enum meao_debug_key {
     MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4, MEAO_DEBUG_FAIL_NEXT_ALLOCS = 5,
     MEAO_DEBUG_DS_SHARE_IN_BLEND = 6,  /* percent (0..100) of the next batch's downsample tiles (meao_prefetch_batch) carried by
                                         * the L2 -> L1 blend launch instead of the last kernel */
-    MEAO_DEBUG_DS_IN_RENDER = 8,       /* 1 = the announced batch's downsample pass (meao_prefetch_batch) rides in the render launch's texel loop
-                                        * instead of in the last upsample kernel (f32 depth, 16-byte aligned rows; anything else keeps the default) */
     MEAO_DEBUG_DS_SIDE_STREAM = 7      /* 0 = off.  gate + 10 * shape: the announced batch's downsample pass runs as its own kernel on a
                                         * second, low-priority stream of the context, released when the call's stream reaches `gate`
                                         * (1 = the full-resolution upsample launch, 2 = L2 -> L1, 3 = the coarse blend launch, 4 = render);

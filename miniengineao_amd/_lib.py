@@ -44,7 +44,7 @@ LAUNCH_DIRECT, LAUNCH_GRAPH = 0, 1
 DEBUG_OCCLUSION_HQ1 = 18
 # meao_debug_key
 (DEBUG_FUSE_COARSE_BLEND, DEBUG_NESTED_MAX_TILES, DEBUG_RENDER_SMALL_MAX_TILES, DEBUG_FINAL_SMALL_MAX_TILES,
- DEBUG_DS_SMALL_MAX_TILES, DEBUG_FAIL_NEXT_ALLOCS, DEBUG_DS_SHARE_IN_BLEND, DEBUG_DS_SIDE_STREAM, DEBUG_DS_IN_RENDER) = range(9)
+ DEBUG_DS_SMALL_MAX_TILES, DEBUG_FAIL_NEXT_ALLOCS, DEBUG_DS_SHARE_IN_BLEND, DEBUG_DS_SIDE_STREAM) = range(8)
 POOL_PATH_SAME_DEVICE, POOL_PATH_PEER_DIRECT, POOL_PATH_STAGED = 0, 1, 2
 NUM_BUFFERS = 21
 

@@ -83,7 +83,6 @@ struct meao_ctx {
     // it), 2 = in front of L2->L1, 3 = in front of the coarse blend launch, 4 = in front of render; shape 0 = 16 loads
     // per lane in flight, 120 VGPRs declared, 1 = 16 loads, 2 = 8 loads, 3 = 4 loads (the stand-alone pass's tile).
     int ds_side_stream = 0;
-    int ds_in_render = 0;              // MEAO_DEBUG_DS_IN_RENDER: the announced batch's downsample pass rides in the RENDER launch's texel loop
     hipStream_t side_stream = nullptr;
     hipEvent_t side_gate = nullptr, side_done = nullptr;
     bool side_pending = false;         // a side-stream downsample was issued and no later execute has ordered itself behind it yet
@@ -592,30 +591,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             MEAO_HIP(ctx, launch_render_with_composite(render_args(1, c.num_levels, false), ctx->pending_comp, c.ao_format, n, stream));
             ctx->pending_comp.frames = 0;
         } else {
-            const RenderArgs rn = render_args(1, c.num_levels, false, true);
-            // MEAO_DEBUG_DS_IN_RENDER: the announced batch's downsample pass in this launch's texel loop (128 x 96 tiles, one per
-            // render workgroup) instead of in the last kernel -- render is VALU-bound with HBM idle
-            bool carried = false;
-            if (ctx->ds_in_render && ctx->next_n > 0 && ctx->next_n <= n && !side.active && !capturing && rn.tile_h == kRenTileH &&
-                c.sample_set != MEAO_SAMPLES_EXHAUSTIVE && c.depth_format == MEAO_DEPTH_F32) {
-                const int other = 1 - ctx->ds_cur;
-                DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, other, 0);
-                ds.row_passes = kDsInRenderRows / 16;
-                ds.tiles_y = (p.mip[0].h + kDsInRenderRows - 1) / kDsInRenderRows;
-                ds.tile_end = ds.tiles_x * ds.tiles_y;
-                if (ds.vec_ok && ds.tiles_x * ds.tiles_y <= rn.blocks_per_frame) {
-                    ctx->set_gen[other] = next_generation();
-                    ds.generation = ctx->set_gen[other];
-                    MEAO_HIP(ctx, launch_render_with_downsample(rn, ds, c.ao_format, n, stream));
-                    ctx->ready_n = ctx->next_n;
-                    ctx->ready_set = other;
-                    ctx->ready_stream = stream;
-                    std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
-                    ctx->next_n = 0;
-                    carried = true;
-                }
-            }
-            if (!carried) MEAO_HIP(ctx, launch_render(rn, c.ao_format, n, stream));
+            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false, true), c.ao_format, n, stream));
         }
         MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
     }
@@ -1366,7 +1342,6 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
     case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
-    case MEAO_DEBUG_DS_IN_RENDER: ctx->ds_in_render = value != 0; break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
         if (value < 0 || value % 10 > 4 || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
             return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");

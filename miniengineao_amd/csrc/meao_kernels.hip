@@ -66,9 +66,6 @@
 #define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
 #endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the
                                 // static instruction counts of the ISA are the dynamic ones of (almost) every workgroup
-#ifndef MEAO_X_DSR_DIAG
-#define MEAO_X_DSR_DIAG 0       // timing diagnostics of the downsample rows carried by render (WRONG results): 1 = loads only, 2 = arithmetic + stores only
-#endif
 #ifndef MEAO_X_PHASE_CLOCKS
 #define MEAO_X_PHASE_CLOCKS 0   // diagnostic build: upsample tiles stamp s_memrealtime at their phase boundaries (tools/phase_clocks.py),
 #endif                          // the render launch logs start / end / CU of every workgroup (tools/render_wg_log.py)
@@ -2417,177 +2414,6 @@ __global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_with_composit
     render_tile<AOFMT, RTNE, DIV, false>(a, tile, frame, block, carried);
 }
 
-// ---- the render pass carrying the downsample pass of the NEXT batch (meao_debug_set MEAO_DEBUG_DS_IN_RENDER) -------------------
-// Render is bound by VALU issue and leaves HBM idle for its whole 170 us per 16 frames; the downsample pass is 61 MB of pure
-// streaming per frame.  A render workgroup (512 lanes, four texel-loop iterations) carries one 128 x 96 downsample tile: six
-// 4-texel rows per lane, their 16-byte loads issued at the top of an iteration (two rows in iterations 0 and 1, one in 2 and 3)
-// and linearized / stored at its end, two microseconds of sample arithmetic later.  The number of such tiles in a frame and the
-// number of render workgroups per frame (all levels) are both W x H / 12 300, so the two grids match one to one (690 tiles on
-// 692 workgroups at 4K).  The arithmetic is the lean form of downsample_side_tile: rows are dealt so that a row's parity is
-// wave-uniform (wave w of the eight takes rows w and w + 8 of every 16-row pass), the range test is two unsigned min / max chains,
-// one 32-bit offset per buffer: ~8 VALU instructions per texel, +12 % on render's own.  (Round 3 carried the 18-instruction
-// tile here and lost: 0.55-0.7 us per percent of the pass; LABNOTES.)
-constexpr int kDsInRenderPasses = 6, kDsInRenderTileH = 16 * kDsInRenderPasses;
-
-template <bool RTNE, int DIV>
-struct CarriedDownsampleRows {
-    const DownsampleArgs &d;
-    int frame;
-    bool active;                    // this workgroup has a tile, this lane a column inside the frame
-    int y0, wave;                   // first row of the lane, its wave (uniform)
-    uint32_t x0;                    // first column of the lane
-    float4v q[2];
-    static __device__ __forceinline__ int first_pass(int k) { return k < 2 ? 2 * k : 2 + k; }      // rows per iteration: 2, 2, 1, 1
-    static __device__ __forceinline__ int passes_in(int k) { return k < 2 ? 2 : 1; }
-    __device__ __forceinline__ CarriedDownsampleRows(const DownsampleArgs &d_, int tile, int frame_) : d(d_), frame(frame_)
-    {
-        const uint32_t tid = threadIdx.x;
-        wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
-        const int tiles = d.tiles_x * d.tiles_y;
-        const int tile_x = tile % d.tiles_x, tile_y = tile / d.tiles_x;
-        x0 = static_cast<uint32_t>(tile_x) * kDsTileW + (tid & 31u) * 4u;
-        y0 = tile_y * kDsInRenderTileH + wave + 8 * static_cast<int>((tid >> 5) & 1u);
-        active = tile < tiles && frame < d.frames && x0 < static_cast<uint32_t>(d.w[0]);
-    }
-    // The pass's uniform arguments are read from the kernel-argument segment again in every begin() / end(): left alone the compiler
-    // hoists those loads out of the texel loop and then spills the SGPRs that hold them across it (89 spill slots, v_readlane /
-    // v_writelane pairs inside the loop).  The zero is opaque, the address space of `d` is not.
-    __device__ __forceinline__ const DownsampleArgs &args_now() const
-    {
-        uint32_t zero;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-        return *reinterpret_cast<const DownsampleArgs *>(reinterpret_cast<const char *>(&d) + zero);
-    }
-    // what a row needs of the pass's arguments, read in one go (a handful of wide scalar loads, one wait)
-    struct RowArgs {
-        uint32_t W, w1, w2, w3, w4;
-        int H;
-        float zp0, zp1, sky_depth;
-        uint32_t generation;
-        const float *depth;
-        uint16_t *linear;
-        float *low1, *low2, *low3, *low4;
-        uint32_t *hostile;
-    };
-    __device__ __forceinline__ RowArgs row_args(bool stores) const
-    {
-        const DownsampleArgs &a = args_now();
-        RowArgs r;
-        r.W = static_cast<uint32_t>(a.w[0]); r.H = a.h[0];
-        r.depth = static_cast<const float *>(a.depth[frame]);
-        if (stores) {
-            r.w1 = a.w[1]; r.w2 = a.w[2]; r.w3 = a.w[3]; r.w4 = a.w[4];
-            r.zp0 = a.zp0; r.zp1 = a.zp1; r.sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
-            r.generation = a.generation;
-            r.hostile = a.hostile + frame;
-            r.linear = frame_ptr(a.linear, a.frame_stride, frame);
-            r.low1 = frame_ptr(a.low[0], a.frame_stride, frame); r.low2 = frame_ptr(a.low[1], a.frame_stride, frame);
-            r.low3 = frame_ptr(a.low[2], a.frame_stride, frame); r.low4 = frame_ptr(a.low[3], a.frame_stride, frame);
-        }
-        return r;
-    }
-    static __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return static_cast<uint32_t>(__umul24(a, b)) + c; }    // v_mad_u32_u24: operands < 2^24
-    __device__ __forceinline__ void begin(int k)
-    {
-        if (!active) return;
-        const RowArgs A = row_args(false);
-        const int p0 = first_pass(k);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j < passes_in(k)) {
-                const uint32_t y = static_cast<uint32_t>(min(y0 + 16 * (p0 + j), A.H - 1));          // rows past the frame re-read its last row (never used)
-                if constexpr (MEAO_X_DSR_DIAG == 2) { q[j] = float4v{0.25f, 0.5f, 0.125f, 0.75f}; continue; }
-                q[j] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(A.depth, mad24(y, A.W, x0) * 4u)));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);        // the loads stay here; their first use is behind the texel arithmetic
-    }
-    __device__ __forceinline__ void end(int k)
-    {
-        if (!active) return;
-        __builtin_amdgcn_sched_barrier(0);
-        const RowArgs A = row_args(true);
-        const int p0 = first_pass(k);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (j < passes_in(k) && y0 + 16 * (p0 + j) < A.H) {
-                if constexpr (MEAO_X_DSR_DIAG == 1) asm volatile("" : : "v"(q[j]));
-                else finish_row(A, static_cast<uint32_t>(y0 + 16 * (p0 + j)), q[j]);
-            }
-    }
-    __device__ __forceinline__ void finish_row(const RowArgs &A, uint32_t y, float4v row) const
-    {
-        asm volatile("" : "+v"(row));             // opaque here: nothing derived from the loaded words moves up to the load
-        const float zp0 = A.zp0, zp1 = A.zp1, sky_depth = A.sky_depth;
-        const float v[4] = {row.x, row.y, row.z, row.w};
-        float lin[4];
-        if constexpr (DIV == DIV_EXACT_RCP) {
-            float den[4];
-            uint32_t bits[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { den[e] = mad(zp0, v[e], zp1); bits[e] = __builtin_bit_cast(uint32_t, den[e]); }
-            const uint32_t lo = min(min(min(bits[0], bits[1]), bits[2]), bits[3]), hi = max(max(max(bits[0], bits[1]), bits[2]), bits[3]);
-            if (__builtin_expect(lo >= 0x35800000u && hi <= 0x4B800000u, 1)) {       // all four in [2^-20, 2^24] (nice_denominator)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float r = __builtin_amdgcn_rcpf(den[e]);
-                    lin[e] = mad(mad(-den[e], r, 1.0f), r, r);                  // rcp_strict: DS1:40
-                }
-                const bool far = (v[0] == sky_depth) | (v[1] == sky_depth) | (v[2] == sky_depth) | (v[3] == sky_depth);
-                if (__builtin_expect(far, 0)) {                                 // DS1:41-45
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lin[e] = v[e] == sky_depth ? 1e5f : lin[e];
-                    asm volatile("" : "+v"(lin[0]), "+v"(lin[1]), "+v"(lin[2]), "+v"(lin[3]));
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[e], zp0, zp1, sky_depth);
-                *A.hostile = A.generation;           // racing stores of the same value
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[e], zp0, zp1, sky_depth);
-        }
-        typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
-        uint2v h;                                                                // LinearZ[st] = dist (DS1:46)
-        if constexpr (RTNE) {
-            h.x = f32_to_f16_bits<true>(lin[0]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[1])) << 16);
-            h.y = f32_to_f16_bits<true>(lin[2]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[3])) << 16);
-        } else {
-            h.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[0], lin[1]));
-            h.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[2], lin[3]));
-        }
-        __builtin_nontemporal_store(h, reinterpret_cast<uint2v *>(at_byte_offset(A.linear, mad24(y, A.W, x0) * 2u)));
-        if ((wave & 1) == 0) {                                                   // even rows (wave-uniform): DS2x (DS1:64-70)
-            __builtin_nontemporal_store(float2v{lin[0], lin[2]},
-                                        reinterpret_cast<float2v *>(at_byte_offset(A.low1, mad24(y >> 1, A.w1, x0 >> 1) * 4u)));
-            if ((wave & 3) == 0) {                                               // rows 0, 4 (+ 8) of the pass: DS4x (DS1:73-77)
-                *at_byte_offset(A.low2, mad24(y >> 2, A.w2, x0 >> 2) * 4u) = lin[0];
-                if (wave == 0 && (x0 & 7u) == 0) {                               // rows 0, 8: DS8x (DS2:35-40)
-                    *at_byte_offset(A.low3, mad24(y >> 3, A.w3, x0 >> 3) * 4u) = lin[0];
-                    if ((y & 15u) == 0 && (x0 & 15u) == 0)                       // row 0: DS16x (DS2:43-49)
-                        *at_byte_offset(A.low4, mad24(y >> 4, A.w4, x0 >> 4) * 4u) = lin[0];
-                }
-            }
-        }
-    }
-};
-
-template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_with_next_downsample_kernel(const RenderArgs a, const DownsampleArgs d)
-{
-    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(false) + 2 * kRenApron)];
-    const int frame = blockIdx.y, block = xcd_contiguous(blockIdx.x, gridDim.x);
-    const CarriedDownsampleRows<RTNE, DIV> carried(d, static_cast<int>(blockIdx.x), frame);
-    if constexpr (DIV == DIV_EXACT_RCP) {
-        if (frame_is_hostile(a.hostile, a.generation, frame)) {
-            render_tile<AOFMT, RTNE, DIV_IEEE, false>(a, tile, frame, block, carried);
-            return;
-        }
-    }
-    render_tile<AOFMT, RTNE, DIV, false>(a, tile, frame, block, carried);
-}
-
 // which = 4: rcp_strict, 5: div_const<3>, div_const<9>, 6: div_strict on hashed operand pairs
 __device__ __forceinline__ bool in_exact_range(float x, float lo, float hi)
 {
@@ -2772,24 +2598,6 @@ hipError_t launch_render_with_composite(const RenderArgs &a, const CompositeBatc
         else if (a.exact_rcp_div) launch_render_composite_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, c, grid, s);
         else launch_render_composite_t<MEAO_AO_F16, false, DIV_IEEE>(a, c, grid, s);
     }
-    return hipGetLastError();
-}
-
-// a: the plain interleaved checker-set launch (128 x 32 tiles); d: 128 x 96 tiles, d.tiles_x * d.tiles_y <= a.blocks_per_frame,
-// d.frames <= frames, f32 depth with 16-byte aligned rows (the caller checks; anything else keeps the pass in the last kernel)
-hipError_t launch_render_with_downsample(const RenderArgs &a, const DownsampleArgs &d, int ao_format, int frames, hipStream_t s)
-{
-    if (a.exhaustive || a.tile_h != kRenTileH || d.vec_ok == 0 || d.depth_format != MEAO_DEPTH_F32 ||
-        d.tiles_x * d.tiles_y > a.blocks_per_frame || d.frames > frames)
-        return hipErrorInvalidValue;
-    const dim3 grid(a.blocks_per_frame, frames, 1), block(ren_tile_w(false) * 4);
-#define MEAO_RD(AOFMT) \
-    if (a.f16_rtne) render_with_next_downsample_kernel<AOFMT, true, DIV_IEEE><<<grid, block, 0, s>>>(a, d); \
-    else if (a.exact_rcp_div == 2) render_with_next_downsample_kernel<AOFMT, false, DIV_FAST><<<grid, block, 0, s>>>(a, d); \
-    else if (a.exact_rcp_div) render_with_next_downsample_kernel<AOFMT, false, DIV_EXACT_RCP><<<grid, block, 0, s>>>(a, d); \
-    else render_with_next_downsample_kernel<AOFMT, false, DIV_IEEE><<<grid, block, 0, s>>>(a, d)
-    if (ao_format == MEAO_AO_R8) { MEAO_RD(MEAO_AO_R8); } else { MEAO_RD(MEAO_AO_F16); }
-#undef MEAO_RD
     return hipGetLastError();
 }
 

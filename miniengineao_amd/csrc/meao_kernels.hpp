@@ -123,9 +123,6 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
 hipError_t launch_downsample_side(const DownsampleArgs &a, int frames, bool pad_vgprs, hipStream_t s);
 hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
-// Render.main_interleaved of this batch carrying the downsample pass of the next one in its texel loop (128 x 96 downsample tiles).
-hipError_t launch_render_with_downsample(const RenderArgs &a, const DownsampleArgs &d, int ao_format, int frames, hipStream_t s);
-constexpr int kDsInRenderRows = 96;             // rows of a downsample tile carried by a render workgroup
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
 // Two blend passes in one launch: `inner` (e.g. L4 -> L3) is evaluated per tile of `outer` (L3 -> L2) for the

@@ -648,42 +648,3 @@ def test_next_downsample_on_the_side_stream(oracle, mode, w, h, batch):
     finally:
         ao.close()
 
-
-
-@pytest.mark.parametrize("variant", [dict(), dict(ao_format=1), dict(f16_rounding=1), dict(num_levels=2)])
-@pytest.mark.parametrize("w,h,batch", [(512, 256, 2), (1280, 720, 3), (644, 364, 2), (640, 131, 1), (3840, 2160, 1)])
-def test_next_downsample_inside_the_render_launch(oracle, variant, w, h, batch):
-    """MEAO_DEBUG_DS_IN_RENDER: the announced batch's downsample pass rides in the render launch's texel loop (one 128 x 96
-    tile per render workgroup: six 4-texel rows per lane, loaded at the top of a loop iteration and linearized / stored at
-    its end).  Five steps without a host synchronisation, a hostile frame, a mispredicted announcement, frames whose tile
-    count exceeds the render workgroups (640 x 131: the pass stays in the last kernel): every buffer against the oracle."""
-    import torch
-    dev = torch.device("cuda", 0)
-    s = H.settings(oracle, w, h, **variant)
-    seqs = [[synth.make("S2", w, h, seed=300 + 10 * k + f) for f in range(batch)] for k in range(5)]
-    seqs[1][batch - 1] = H.hostile_frame(w, h, 78, density=0.002)
-    dd = [[torch.from_numpy(f).to(dev) for f in b] for b in seqs]
-    dt = torch.uint8 if s.ao_format == 0 else torch.int16
-    out = [[torch.zeros((h, w), dtype=dt, device=dev) for _ in b] for b in seqs]
-    st = torch.cuda.current_stream(dev).cuda_stream
-    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_IN_RENDER: 1})
-    announce = {0: 1, 1: 2, 2: 4, 3: None, 4: 1}          # step 2 announces set 4 but set 3 arrives
-    try:
-        for k in range(5):
-            if announce[k] is not None:
-                ao.prefetch_device([t.data_ptr() for t in dd[announce[k]]])
-            ao.execute_device([t.data_ptr() for t in dd[k]], [t.data_ptr() for t in out[k]], st)
-        ao.execute_device([t.data_ptr() for t in dd[1]], [t.data_ptr() for t in out[1]], st)      # consumes the set carried by step 4
-        torch.cuda.synchronize(dev)
-        for k in range(5):
-            for f in range(batch):
-                want = oracle.run(seqs[k][f], s, result_only=(k != 1))
-                ok, bad = H.nan_aware_equal(out[k][f].cpu().numpy().view(want["result"].dtype), want["result"])
-                assert ok, (k, f, int(bad.sum()))
-                if k == 1:          # every intermediate of the consumer of a carried set (incl. the hostile frame)
-                    for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
-                        ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
-                        assert ok, (H.NAMES[i], f, int(bad.sum()))
-        assert ao.hostile_frames() == (1 << (batch - 1) if not variant.get("f16_rounding") else 0)    # the flags exist in the exact-division mode only
-    finally:
-        ao.close()
