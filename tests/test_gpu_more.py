@@ -648,3 +648,47 @@ def test_next_downsample_on_the_side_stream(oracle, mode, w, h, batch):
     finally:
         ao.close()
 
+
+
+def test_side_stream_downsample_survives_resize_params_and_destroy(oracle):
+    """The side-stream kernel of an announced batch may still be running when the host changes its mind: a property change
+    (drops the announcement), a resize (frees the arena it writes) and a destroy right behind the carrying execute must all be
+    safe, and the next results right."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h, batch = 1920, 1080, 4
+    s = H.settings(oracle, w, h)
+    frames = [synth.make("S2", w, h, seed=910 + f) for f in range(batch)]
+    dd = [torch.from_numpy(f).to(dev) for f in frames]
+    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(batch)]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    dp, op = [t.data_ptr() for t in dd], [t.data_ptr() for t in out]
+    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_SIDE_STREAM: 4})
+    try:
+        ao.prefetch_device(dp)
+        ao.execute_device(dp, op, st)              # side kernel for the announced batch is in flight now
+        ao.intensity = 0.5                         # meao_set_params: the announcement is void
+        s2 = H.settings(oracle, w, h, intensity=0.5)
+        ao.prefetch_device(dp)
+        ao.execute_device(dp, op, st)              # own downsample pass into the set the stale side kernel was writing
+        ao.execute_device(dp, op, st)              # consumer of the second side kernel
+        torch.cuda.synchronize(dev)
+        for f in (0, batch - 1):
+            assert np.array_equal(out[f].cpu().numpy(), oracle.run(frames[f], s2, result_only=True)["result"]), f
+        ao.prefetch_device(dp)
+        ao.execute_device(dp, op, st)
+        ao.resize(w - 64, h - 32)                  # frees the arena the side kernel may still be writing
+        s3 = H.settings(oracle, w - 64, h - 32, intensity=0.5)
+        ao.projection00 = s3.proj00
+        small = [np.ascontiguousarray(f[:h - 32, :w - 64]) for f in frames[:2]]
+        got = ao.render_batch(small)
+        for f in range(2):
+            assert np.array_equal(got[f], oracle.run(small[f], s3, result_only=True)["result"]), f
+        dsm = [torch.from_numpy(f).to(dev) for f in small]
+        osm = [torch.zeros((h - 32, w - 64), dtype=torch.uint8, device=dev) for _ in small]
+        ao.prefetch_device([t.data_ptr() for t in dsm])
+        ao.execute_device([t.data_ptr() for t in dsm], [t.data_ptr() for t in osm], st)
+    finally:
+        ao.close()                                 # destroy with a side kernel in flight
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(osm[1].cpu().numpy(), oracle.run(small[1], s3, result_only=True)["result"])
