@@ -537,19 +537,46 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(const DownsampleAr
 // Same bits as downsample_tile (tests/test_gpu_more.py::test_next_downsample_on_the_side_stream, hostile frames included).
 // PAD_VGPRS: the kernel declares 120 VGPRs whatever it uses, so that exactly one of its workgroups fits next to seven
 // upsample workgroups and the registers a finishing upsample workgroup frees (56) can only go to the next upsample one.
-template <bool RTNE, int DIV, int PASSES, bool FULL>
-__device__ __forceinline__ void downsample_side_tile(const DownsampleArgs &a, int tile, int frame)
+// lane geometry of the lean tile: rows w and w + 4 of every 8-row pass for wave w (a row's parity is wave-uniform)
+struct LeanDsLane {
+    int wave, row, y0;
+    uint32_t x0;
+    __device__ __forceinline__ LeanDsLane(const DownsampleArgs &a, int tile, int passes)
+    {
+        const uint32_t tid = threadIdx.x;
+        wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
+        const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+        x0 = static_cast<uint32_t>(tile_x) * kDsTileW + (tid & 31u) * 4u;
+        row = wave + 4 * static_cast<int>((tid >> 5) & 1u);
+        y0 = tile_y * (passes * kDsRowsPerPass) + row;
+    }
+};
+
+// FULL: every row of the tile is inside the frame (otherwise rows past it re-read its last row and are never used)
+template <int PASSES, bool FULL>
+__device__ __forceinline__ void downsample_lean_load(const DownsampleArgs &a, int tile, int frame, float4v (&q)[PASSES])
 {
-    const uint32_t tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
-    const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+    const LeanDsLane L(a, tile, PASSES);
     const uint32_t W = static_cast<uint32_t>(a.w[0]);
-    const int H = a.h[0];
-    const uint32_t x0 = static_cast<uint32_t>(tile_x) * kDsTileW + (tid & 31u) * 4u;
-    const int row = wave + 4 * static_cast<int>((tid >> 5) & 1u);              // rows w, w + 4 of each pass: parity is wave-uniform
-    const int y0 = tile_y * (PASSES * kDsRowsPerPass) + row;
-    if (x0 >= W) return;
+    if (L.x0 >= W) return;
     const float *__restrict__ depth = static_cast<const float *>(a.depth[frame]);
+    const uint32_t t0 = static_cast<uint32_t>(L.y0) * W + L.x0, t_step = 8u * W;       // texel index of (x0, y0 + 8k) is t0 + k * 8W
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+        uint32_t t = t0 + static_cast<uint32_t>(k) * t_step;
+        if constexpr (!FULL) t = static_cast<uint32_t>(min(L.y0 + 8 * k, a.h[0] - 1)) * W + L.x0;
+        q[k] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(depth, t * 4u)));
+    }
+}
+
+template <bool RTNE, int DIV, int PASSES, bool FULL>
+__device__ __forceinline__ void downsample_lean_finish(const DownsampleArgs &a, int tile, int frame, const float4v (&q)[PASSES])
+{
+    const LeanDsLane L(a, tile, PASSES);
+    const int wave = L.wave, row = L.row, y0 = L.y0;
+    const uint32_t x0 = L.x0, W = static_cast<uint32_t>(a.w[0]);
+    const int H = a.h[0];
+    if (x0 >= W) return;
     uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
     float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
     float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
@@ -558,16 +585,7 @@ __device__ __forceinline__ void downsample_side_tile(const DownsampleArgs &a, in
     const float zp0 = a.zp0, zp1 = a.zp1;
     const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
     const uint32_t w1 = a.w[1], w2 = a.w[2], w3 = a.w[3], w4 = a.w[4];
-
-    // texel index of (x0, y0 + 8k) is t0 + k * 8W.  FULL: every row of the tile is inside the frame
     const uint32_t t0 = static_cast<uint32_t>(y0) * W + x0, t_step = 8u * W;
-    float4v q[PASSES];
-#pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-        uint32_t t = t0 + static_cast<uint32_t>(k) * t_step;
-        if constexpr (!FULL) t = static_cast<uint32_t>(min(y0 + 8 * k, H - 1)) * W + x0;      // re-reads the last row; never used
-        q[k] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(depth, t * 4u)));
-    }
     const uint32_t o1 = (static_cast<uint32_t>(y0 >> 1) * w1 + (x0 >> 1)) * 4u, o2 = (static_cast<uint32_t>(y0 >> 2) * w2 + (x0 >> 2)) * 4u;
     const uint32_t o3 = (static_cast<uint32_t>(y0 >> 3) * w3 + (x0 >> 3)) * 4u, o4 = (static_cast<uint32_t>(y0 >> 4) * w4 + (x0 >> 4)) * 4u;
 #pragma unroll
@@ -627,6 +645,14 @@ __device__ __forceinline__ void downsample_side_tile(const DownsampleArgs &a, in
             }
         }
     }
+}
+
+template <bool RTNE, int DIV, int PASSES, bool FULL>
+__device__ __forceinline__ void downsample_side_tile(const DownsampleArgs &a, int tile, int frame)
+{
+    float4v q[PASSES];
+    downsample_lean_load<PASSES, FULL>(a, tile, frame, q);
+    downsample_lean_finish<RTNE, DIV, PASSES, FULL>(a, tile, frame, q);
 }
 
 template <bool RTNE, int DIV, int PASSES, bool PAD_VGPRS>
@@ -2080,6 +2106,26 @@ struct IssueCarriedLoads {
 };
 
 
+// The same for the lean tile (downsample_lean_load / _finish: wave-uniform row parity, ~8 VALU instructions per texel instead of ~18):
+// what the last kernel of a pipelined step carries since round 4 (270 vs 275 us per 16 frames, profiles/r04_ab_fused_lean_tile.jsonl).
+// With the lean tile the UNORM8 estimate and the grouped reciprocals still lose here: 305 and 288 us.
+struct IssueCarriedLoadsLean {
+    static constexpr bool kBeforeBilateral = true;
+    static constexpr bool kGroupReciprocals = false;
+    static constexpr bool kEstimateR8 = false;
+    const DownsampleArgs &d;
+    float4v (&q)[kDsTileH / kDsRowsPerPass];
+    bool mine, full;
+    int tile, frame;
+    __device__ __forceinline__ void after_prefetch() const {}
+    __device__ __forceinline__ void before_bilateral() const
+    {
+        if (!mine) return;
+        if (full) downsample_lean_load<kDsTileH / kDsRowsPerPass, true>(d, tile, frame, q);
+        else downsample_lean_load<kDsTileH / kDsRowsPerPass, false>(d, tile, frame, q);
+    }
+};
+
 // Upsample.main of this batch carrying the downsample pass of the NEXT batch (meao_prefetch_batch):
 // the final upsample is VALU-bound (five exact divides per texel) and leaves HBM idle, the
 // downsample is pure streaming with ~2 VALU ops per byte -- inside one kernel the streaming hides
@@ -2114,10 +2160,15 @@ __global__ __launch_bounds__(kThreads, 7) void upsample_final_with_next_downsamp
     // (tiles below d.tile_begin were carried by an earlier launch of this call: a blend pass, MEAO_DEBUG_DS_SHARE_IN_BLEND)
     const bool mine = blockIdx.x >= static_cast<unsigned>(d.tile_begin) && blockIdx.x < static_cast<unsigned>(ds_tiles) &&
                       blockIdx.z < static_cast<unsigned>(d.frames);
-    float v[kDsTileH / kDsRowsPerPass][4];
-    const IssueCarriedLoads issue = {d, v, mine, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.z)};
+    constexpr int kPasses = kDsTileH / kDsRowsPerPass;
+    float4v q[kPasses];
+    const bool full = (static_cast<int>(blockIdx.x) / d.tiles_x + 1) * kDsTileH <= d.h[0];
+    const IssueCarriedLoadsLean issue = {d, q, mine, full, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.z)};
     upsample_tile_checked<AOFMT, RTNE, true, DIV>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z, issue);
-    if (mine) downsample_tile_finish<RTNE, true, DIV>(d, blockIdx.x, blockIdx.z, v);
+    if (mine) {
+        if (full) downsample_lean_finish<RTNE, DIV, kPasses, true>(d, blockIdx.x, blockIdx.z, q);
+        else downsample_lean_finish<RTNE, DIV, kPasses, false>(d, blockIdx.x, blockIdx.z, q);
+    }
     // (loading the carried tile behind the first barrier and finishing it in FRONT of the bilateral phase frees 10 VGPRs there
     // and is 5 % slower: profiles/r03_ab_fused_ds_finished_before_bilateral.jsonl)
 }
