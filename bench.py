@@ -94,8 +94,8 @@ def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
                       f"median; C oracle (oracle/meao_oracle.c) row-parallel on {cores} threads",
             "seconds_per_frame": round(med, 4),
             "thread_scaling": round(single / med, 1),
-            "note": "a reported baseline, never a target: the port is row-parallel per pass with a barrier between passes and "
-                    f"scales {single / med:.1f}x on {cores} threads (memory-bound passes, short rows per thread); "
+            "note": "a reported baseline, never a target: the port is row-parallel per pass (persistent thread pool drawing chunks "
+                    f"of rows, a join between the ~25 passes of a frame) and scales {single / med:.1f}x on {cores} threads; "
                     "kernel quality is judged by the roofline fraction, not by the GPU / CPU ratio"}
 
 

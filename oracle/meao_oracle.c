@@ -235,27 +235,78 @@ void meao_oracle_upsample_constants(const meao_oracle_desc *d, int32_t low_level
 /* row-parallel driver                                                       */
 
 typedef void (*row_fn)(void *arg, int y0, int y1);
-typedef struct { row_fn fn; void *arg; int y0, y1; } row_job;
-static void *row_thread(void *p) { row_job *j = (row_job *)p; j->fn(j->arg, j->y0, j->y1); return NULL; }
+
+/* A persistent pool of worker threads that draw chunks of rows from a shared counter.  (The first form spawned and joined
+ * its threads in every one of the ~25 row passes of a frame: at 128-256 threads the spawns cost as much as the arithmetic, and
+ * passes with fewer than two rows per thread -- every coarse level -- ran on one core.  That made the reported CPU baseline
+ * 8-9x a single core on a 256-thread host.)  One call at a time uses the pool (pool_call); results do not depend on the
+ * schedule: every output row is a pure function of the pass's inputs. */
+enum { MAXT = 256 };
+static struct {
+    pthread_mutex_t call, mu;
+    pthread_cond_t work, done;
+    pthread_t tid[MAXT];
+    int workers;                    /* threads created so far */
+    int generation, participants;   /* job number; workers 0 .. participants - 2 take part in it */
+    int running;                    /* participants still drawing or executing chunks */
+    row_fn fn; void *arg; int rows, chunk;
+    volatile int next;              /* first row nobody has drawn yet */
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+             {0}, 0, 0, 0, 0, NULL, NULL, 0, 1, 0 };
+
+static void pool_draw_chunks(void)
+{
+    for (;;) {
+        const int y0 = __atomic_fetch_add(&g_pool.next, g_pool.chunk, __ATOMIC_RELAXED);
+        if (y0 >= g_pool.rows) break;
+        const int y1 = y0 + g_pool.chunk < g_pool.rows ? y0 + g_pool.chunk : g_pool.rows;
+        g_pool.fn(g_pool.arg, y0, y1);
+    }
+}
+
+static void *pool_worker(void *p)
+{
+    const int id = (int)(intptr_t)p;
+    int seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.generation == seen) pthread_cond_wait(&g_pool.work, &g_pool.mu);
+        seen = g_pool.generation;
+        if (id >= g_pool.participants - 1) continue;            /* not part of this job */
+        pthread_mutex_unlock(&g_pool.mu);
+        pool_draw_chunks();
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.running == 0) pthread_cond_signal(&g_pool.done);
+    }
+    return NULL;
+}
 
 static void par_rows(int nthreads, int rows, row_fn fn, void *arg)
 {
-    enum { MAXT = 128 };
     if (nthreads > MAXT) nthreads = MAXT;
-    if (nthreads <= 1 || rows < 2 * nthreads) { fn(arg, 0, rows); return; }
-    pthread_t tid[MAXT]; row_job job[MAXT]; int spawned[MAXT];
-    for (int t = 0; t < nthreads; t++) {
-        job[t].fn = fn; job[t].arg = arg;
-        job[t].y0 = (int)((long long)rows * t / nthreads);
-        job[t].y1 = (int)((long long)rows * (t + 1) / nthreads);
+    if (nthreads > rows) nthreads = rows;
+    if (nthreads <= 1) { fn(arg, 0, rows); return; }
+    pthread_mutex_lock(&g_pool.call);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.workers < nthreads - 1) {                      /* grow the pool on demand; a failed spawn just leaves fewer workers */
+        if (pthread_create(&g_pool.tid[g_pool.workers], NULL, pool_worker, (void *)(intptr_t)g_pool.workers) != 0) break;
+        pthread_detach(g_pool.tid[g_pool.workers]);
+        ++g_pool.workers;
     }
-    for (int t = 1; t < nthreads; t++)
-        spawned[t] = pthread_create(&tid[t], NULL, row_thread, &job[t]) == 0;
-    fn(arg, job[0].y0, job[0].y1);
-    for (int t = 1; t < nthreads; t++) {
-        if (spawned[t]) pthread_join(tid[t], NULL);
-        else fn(arg, job[t].y0, job[t].y1);
-    }
+    const int participants = (g_pool.workers < nthreads - 1 ? g_pool.workers : nthreads - 1) + 1;
+    g_pool.fn = fn; g_pool.arg = arg; g_pool.rows = rows; g_pool.next = 0;
+    g_pool.chunk = rows / (4 * participants) > 0 ? rows / (4 * participants) : 1;
+    g_pool.participants = participants;
+    g_pool.running = participants;
+    ++g_pool.generation;
+    pthread_cond_broadcast(&g_pool.work);
+    pthread_mutex_unlock(&g_pool.mu);
+    pool_draw_chunks();                                          /* the caller is participant number one */
+    pthread_mutex_lock(&g_pool.mu);
+    --g_pool.running;
+    while (g_pool.running > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_pool.call);
 }
 
 /* ------------------------------------------------------------------------ */
