@@ -23,6 +23,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -244,15 +245,23 @@ typedef void (*row_fn)(void *arg, int y0, int y1);
 enum { MAXT = 256 };
 static struct {
     pthread_mutex_t call, mu;
-    pthread_cond_t work, done;
+    pthread_cond_t work;
     pthread_t tid[MAXT];
     int workers;                    /* threads created so far */
-    int generation, participants;   /* job number; workers 0 .. participants - 2 take part in it */
-    int running;                    /* participants still drawing or executing chunks */
-    row_fn fn; void *arg; int rows, chunk;
-    volatile int next;              /* first row nobody has drawn yet */
-} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
-             {0}, 0, 0, 0, 0, NULL, NULL, 0, 1, 0 };
+    int sleepers;                   /* workers blocked on `work` (under mu) */
+    row_fn fn; void *arg; int rows, chunk, participants;      /* the job: published before `generation` moves */
+    /* the three words the threads hammer, one cache line each */
+    volatile int generation __attribute__((aligned(64)));     /* job number */
+    volatile int next __attribute__((aligned(64)));           /* first row nobody has drawn yet */
+    volatile int running __attribute__((aligned(64)));        /* participants that have not finished the job */
+} g_pool = { .call = PTHREAD_MUTEX_INITIALIZER, .mu = PTHREAD_MUTEX_INITIALIZER, .work = PTHREAD_COND_INITIALIZER, .chunk = 1 };
+
+static inline void cpu_relax(void)
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
 
 static void pool_draw_chunks(void)
 {
@@ -264,19 +273,27 @@ static void pool_draw_chunks(void)
     }
 }
 
+/* Between the passes of a frame (a millisecond apart) the workers spin on the job number; only after ~100 us without work do
+ * they block on the condition variable.  (Waking 255 sleepers through one mutex for each of a frame's ~40 row passes took longer
+ * than the passes themselves.) */
 static void *pool_worker(void *p)
 {
     const int id = (int)(intptr_t)p;
     int seen = 0;
-    pthread_mutex_lock(&g_pool.mu);
     for (;;) {
-        while (g_pool.generation == seen) pthread_cond_wait(&g_pool.work, &g_pool.mu);
-        seen = g_pool.generation;
-        if (id >= g_pool.participants - 1) continue;            /* not part of this job */
-        pthread_mutex_unlock(&g_pool.mu);
+        int spins = 0;
+        while (__atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE) == seen) {
+            if (++spins < 20000) { cpu_relax(); continue; }
+            pthread_mutex_lock(&g_pool.mu);
+            ++g_pool.sleepers;
+            while (__atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE) == seen) pthread_cond_wait(&g_pool.work, &g_pool.mu);
+            --g_pool.sleepers;
+            pthread_mutex_unlock(&g_pool.mu);
+        }
+        seen = __atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE);
+        if (id >= g_pool.participants - 1) continue;            /* not part of this job (the caller waits for its participants only) */
         pool_draw_chunks();
-        pthread_mutex_lock(&g_pool.mu);
-        if (--g_pool.running == 0) pthread_cond_signal(&g_pool.done);
+        __atomic_sub_fetch(&g_pool.running, 1, __ATOMIC_ACQ_REL);
     }
     return NULL;
 }
@@ -287,25 +304,25 @@ static void par_rows(int nthreads, int rows, row_fn fn, void *arg)
     if (nthreads > rows) nthreads = rows;
     if (nthreads <= 1) { fn(arg, 0, rows); return; }
     pthread_mutex_lock(&g_pool.call);
-    pthread_mutex_lock(&g_pool.mu);
     while (g_pool.workers < nthreads - 1) {                      /* grow the pool on demand; a failed spawn just leaves fewer workers */
         if (pthread_create(&g_pool.tid[g_pool.workers], NULL, pool_worker, (void *)(intptr_t)g_pool.workers) != 0) break;
         pthread_detach(g_pool.tid[g_pool.workers]);
         ++g_pool.workers;
     }
     const int participants = (g_pool.workers < nthreads - 1 ? g_pool.workers : nthreads - 1) + 1;
-    g_pool.fn = fn; g_pool.arg = arg; g_pool.rows = rows; g_pool.next = 0;
+    g_pool.fn = fn; g_pool.arg = arg; g_pool.rows = rows;
     g_pool.chunk = rows / (4 * participants) > 0 ? rows / (4 * participants) : 1;
     g_pool.participants = participants;
-    g_pool.running = participants;
-    ++g_pool.generation;
-    pthread_cond_broadcast(&g_pool.work);
+    __atomic_store_n(&g_pool.next, 0, __ATOMIC_RELAXED);
+    __atomic_store_n(&g_pool.running, participants, __ATOMIC_RELAXED);
+    __atomic_store_n(&g_pool.generation, g_pool.generation + 1, __ATOMIC_RELEASE);      /* publishes the job */
+    pthread_mutex_lock(&g_pool.mu);
+    if (g_pool.sleepers > 0) pthread_cond_broadcast(&g_pool.work);
     pthread_mutex_unlock(&g_pool.mu);
     pool_draw_chunks();                                          /* the caller is participant number one */
-    pthread_mutex_lock(&g_pool.mu);
-    --g_pool.running;
-    while (g_pool.running > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
-    pthread_mutex_unlock(&g_pool.mu);
+    __atomic_sub_fetch(&g_pool.running, 1, __ATOMIC_ACQ_REL);
+    for (int spins = 0; __atomic_load_n(&g_pool.running, __ATOMIC_ACQUIRE) > 0; ++spins)
+        if (spins < 20000) cpu_relax(); else sched_yield();
     pthread_mutex_unlock(&g_pool.call);
 }
 
