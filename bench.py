@@ -74,7 +74,7 @@ def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
     bounded sample of the same workload: whole frames of this workload, median of <=8 after
     one warm-up, stopping early once ~budget_s of CPU time is spent."""
     O, s = oracle_settings(w, h, cam, intensity, ao_format)
-    cores = os.cpu_count() or 1
+    cores = O.host_cores()           # affinity mask capped by the cgroup CPU quota: what this process can really use
     times = []
     t_begin = time.perf_counter()
     O.run(depth, s, nthreads=cores, result_only=True)       # warm-up
@@ -90,8 +90,10 @@ def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
     single = time.perf_counter() - t0
     return {"value": round(w * h / med / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "single_core_value": round(w * h / single / 1e6, 3),
+            "host_logical_cpus": os.cpu_count(),
             "sample": f"{len(times)} timed full {w}x{h} frame(s) of the bench workload after 1 warm-up, "
-                      f"median; C oracle (oracle/meao_oracle.c) row-parallel on {cores} threads",
+                      f"median; C oracle (oracle/meao_oracle.c) row-parallel on {cores} threads = the CPUs this process may use "
+                      f"(affinity mask capped by the cgroup quota; the host shows {os.cpu_count()} logical CPUs)",
             "seconds_per_frame": round(med, 4),
             "thread_scaling": round(single / med, 1),
             "note": "a reported baseline, never a target: the port is row-parallel per pass (persistent thread pool drawing chunks "
@@ -274,7 +276,7 @@ class Workload:
         if frames_vs_oracle > 0 and not self.fast:
             O, s = oracle_settings(self.w, self.h, self.cam, self.intensity, self.ao_format, self.hq_levels, self.exhaustive)
             order = list(dict.fromkeys([0, self.B - 1] + list(range(self.B))))      # first, last, then the rest
-            threads = max(1, (os.cpu_count() or 1) // max(self.world, 1))
+            threads = max(1, O.host_cores() // max(self.world, 1))
             for f in sorted(order[:frames_vs_oracle]):
                 want = O.run(self.frames[f], s, nthreads=threads, result_only=True)["result"]
                 validated += 1
@@ -400,7 +402,7 @@ def measure_pool(args, G, B=None, ramp_s=0.080, side_stream=None) -> dict:
     if args.validate_frames != 0 and not args.fast_numerics:
         O, s = oracle_settings(w, h, cam, intensity, ao_format)
         for g in sorted({m for m in range(G)} | {n - 1 - m for m in range(G)}):
-            want = O.run(frames[g], s, nthreads=os.cpu_count() or 1, result_only=True)["result"]
+            want = O.run(frames[g], s, nthreads=O.host_cores(), result_only=True)["result"]
             validated += 1
             mismatched += int(not np.array_equal(host[g].view(want.dtype), want))
     paths = {f"member{m}->device{devices[0]}": ["same_device", "peer_direct", "staged"][pool.gather_path(m, devices[0])] for m in range(G)}

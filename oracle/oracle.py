@@ -180,6 +180,30 @@ def _buffers(arrs) -> Buffers:
     return b
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread host
+    may own 16 of them -- `os.cpu_count()` still says 256, and 256 busy threads on a 16-CPU quota run slower than 16)."""
+    import math
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:                                                     # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:                                                 # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def run(depth: np.ndarray, s: Settings, nthreads: int = 1, emulate_hlsl: bool = False,
         result_only: bool = False):
     """Run the oracle; returns dict name -> array (all 17 buffers, or just 'result')."""

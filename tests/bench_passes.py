@@ -60,7 +60,7 @@ if a.check:
                    intensity=intensity, ao_format=ao_format)
     ok = True
     for f in sorted({0, B - 1}):
-        want = O.run(frames[f], s, nthreads=os.cpu_count(), result_only=True)["result"]
+        want = O.run(frames[f], s, nthreads=O.host_cores(), result_only=True)["result"]
         ok = ok and bool(np.array_equal(out[f].cpu().numpy().view(want.dtype), want))
     res["ok"] = ok
 res["tag"] = (a.tag or os.path.basename(os.environ.get("MEAO_LIB_PATH", "product"))) + (f"+share{a.ds_share}" if a.ds_share else "") + \

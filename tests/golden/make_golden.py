@@ -63,7 +63,7 @@ def main():
     for name, (w, h, kind, seed, cam, over) in LARGE.items():
         depth = make_depth(kind, w, h, seed, cam)
         s = H.settings(O, w, h, cam=cam, **over)
-        out = O.run(depth, s, nthreads=os.cpu_count() or 1, result_only=True)
+        out = O.run(depth, s, nthreads=O.host_cores(), result_only=True)
         sums[name] = {"depth": H.checksum(depth), "result": H.checksum(out["result"]),
                       "mean_ao": round(float(out["result"].mean()) / 255.0, 6)}
     with open(os.path.join(HERE, "golden_checksums.json"), "w") as f:

@@ -32,7 +32,7 @@ def test_oracle_reproduces_full_size_checksums(oracle, name):
     w, h, kind, seed, cam, over = G.LARGE[name]
     depth = G.make_depth(kind, w, h, seed, cam)
     assert H.checksum(depth) == SUMS[name]["depth"]
-    out = oracle.run(depth, H.settings(oracle, w, h, cam=cam, **over), nthreads=os.cpu_count() or 1,
+    out = oracle.run(depth, H.settings(oracle, w, h, cam=cam, **over), nthreads=oracle.host_cores(),
                      result_only=True)["result"]
     assert H.checksum(out) == SUMS[name]["result"]
 

@@ -192,7 +192,7 @@ def test_8k_fp16_full_frame(oracle):
     w, h = 7680, 4320
     depth = synth.make("S2", w, h)
     s = H.settings(oracle, w, h, ao_format=1)
-    want = oracle.run(depth, s, nthreads=os.cpu_count() or 8, result_only=True)["result"]
+    want = oracle.run(depth, s, nthreads=oracle.host_cores(), result_only=True)["result"]
     ao = H.component(s)
     try:
         got = ao.render(depth)
