@@ -335,14 +335,18 @@ MEAO_API int32_t meao_composite_flush(meao_ctx *ctx, meao_stream stream);
 MEAO_API int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable);
 MEAO_API int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *out_samples);
 
-/* ---- multi-GPU: a pool of contexts, one per device, driven by one host thread -------------------
+/* ---- multi-GPU: a pool of contexts, one per device, called from one host thread ------------------
  * The path shards across independent frames only (the reference keeps no temporal state,
  * AO.cs:291-308): frame f of a batch goes to member f mod G, every member owns a complete context
  * and a stream on its device, there is no data-path exchange (SURVEY.md 8e / DESIGN.md 7).  This is
  * what an in-process host (the C# component) binds; bench.py's one-process-per-GPU launch over
  * torch.distributed / RCCL is the other way to the same partition.
  * devices: num_devices HIP ordinals (repeats allowed: several members on one device), or NULL for
- * 0..num_devices-1 modulo the visible device count.  cfg.device is ignored; cfg.max_batch is per member. */
+ * 0..num_devices-1 modulo the visible device count.  cfg.device is ignored; cfg.max_batch is per member.
+ * A pool, like a context, is used by one caller thread at a time.  Inside, DEVICE batches are enqueued by one worker
+ * thread per member (started by the first such batch, joined by meao_pool_destroy): a member's 4-5 launches cost
+ * 10-14 us of host time, and eight members fed one after the other cannot keep up with one 4K frame per GPU
+ * (tools/pool_enqueue_cost.py).  A member's context is only ever touched by one thread at a time. */
 typedef struct meao_pool meao_pool;
 MEAO_API int32_t meao_pool_create(const meao_config *cfg, const int32_t *devices, int32_t num_devices,
                                   meao_pool **out_pool);
@@ -356,9 +360,8 @@ MEAO_API const char *meao_pool_last_error(const meao_pool *pool);
 /* meao_set_params on every member. */
 MEAO_API int32_t meao_pool_set_params(meao_pool *pool, const meao_params *p);
 /* Every meao_pool_* call leaves the calling thread's current HIP device as it found it.  If a member
- * fails in the middle of a call the members before it have already been given their work (their
- * launches are in flight and complete normally); the call returns the failing member's status and
- * meao_pool_last_error names it. */
+ * fails, the other members have still been given their work (their launches are in flight and complete
+ * normally); the call returns the first failing member's status and meao_pool_last_error names it. */
 /* n <= max_batch * members frames; frame f runs on member f mod G, each member's share as one batched
  * launch sequence on its own stream.  DEVICE pointers of frame f must be resident on
  * meao_pool_device_of_frame(f); the call is then asynchronous (meao_pool_synchronize).  HOST pointers
