@@ -62,6 +62,9 @@
 #ifndef MEAO_X_UPS_EXACT_R8
 #define MEAO_X_UPS_EXACT_R8 0      // 1 = every UNORM8 bilateral result through the full exact-division sequence (the round-2 form) instead of
 #endif                             // bilateral_upsample_r8: L1->L0 176 -> 196 us, L2->L1 54 -> 57 us (profiles/r03_ab_verified_r8_bilateral.txt)
+#ifndef MEAO_X_BIL_WHOLE_TILE
+#define MEAO_X_BIL_WHOLE_TILE 1    // 0 = no separate copy of the bilateral phase for tiles that lie wholly inside the frame (the round-3 form):
+#endif                             // last kernel 296 -> 272 us, step 570 -> 551 us (profiles/r04_ab_bilateral_arms.jsonl)
 #ifndef MEAO_X_HOT_PATH_ONLY
 #define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
 #endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the
@@ -1309,6 +1312,7 @@ __device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_dept
 // has to stay in registers for the rare path (the nested kernels have none to spare).
 constexpr float kR8Margin = 0x1p-10f;
 
+// (v_cvt_pk_u8_f32, which would convert and pack in one instruction, does not truncate like v_cvt_u32_f32: tried in round 4.)
 template <bool GROUPED, bool REUSE = false>
 __device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float hi_ao, const float (&d)[4], const float (&a)[4],
                                                           const BilateralConsts &k)
@@ -1474,6 +1478,7 @@ struct NoHook {
     static constexpr bool kBeforeBilateral = false;
     static constexpr bool kGroupReciprocals = true;      // bilateral_upsample_grouped
     static constexpr bool kEstimateR8 = true;            // bilateral_upsample_r8
+    static constexpr bool kReuseEstimate = true;         // ... whose exact path starts from the estimate's reciprocals
     __device__ __forceinline__ void after_prefetch() const {}
     __device__ __forceinline__ void before_bilateral() const {}
 };
@@ -1696,17 +1701,21 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
                                    : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
-    const bool vec_ok = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
+    const bool vec_ok_frame = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
     // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
     constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
     const int tx = tid & 15;
     const int hx0 = HX0 + 4 * tx;
-    if (hx0 >= hw) return;
+    // WHOLE: the tile lies inside the frame and its rows take 4-texel loads and stores -- no lane or row of it is masked
+    auto bilateral_phase = [&](auto whole_tile) {
+    constexpr bool WHOLE = decltype(whole_tile)::value;
+    const bool vec_ok = WHOLE || vec_ok_frame;
+    if (!WHOLE && hx0 >= hw) return;
 #pragma unroll       // the hoisted operands live in registers: static indices
     for (int pass = 0; pass < kTileH / 32; ++pass) {
         const int ty = (tid >> 4) + 16 * pass;
         const int hy0 = HY0 + 2 * ty;
-        if (hy0 >= hh) return;
+        if (!WHOLE && hy0 >= hh) return;
 
         float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
 #pragma unroll
@@ -1722,7 +1731,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const int hy = hy0 + f;
-            if (hy >= hh) break;
+            if (!WHOLE && hy >= hh) break;
             const size_t hrow = static_cast<size_t>(hy) * hw + hx0;
             float hd[4], ha[4] = {1.0f, 1.0f, 1.0f, 1.0f};                  // HiSSAOs = 1 in "main" (UPS:222)
             if constexpr (FINAL) {
@@ -1766,7 +1775,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                         gd[i] = dl[rr + gy[g]][cc + gx[g]];
                         ga[i] = vb[rr + gy[g]][cc + gx[g]];
                     }
-                    res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, !NESTED>(hd[e], ha[e], gd, ga, bilateral_k));
+                    res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, !NESTED && Hook::kReuseEstimate>(hd[e], ha[e], gd, ga, bilateral_k));
                 }
             } else if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
                 // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than
@@ -1824,6 +1833,12 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         }
         clk.mark(6 + pass);  // 6, 7: bilateral pass 0 / 1 (64-row tiles) incl. its stores being issued
     }
+    };
+    // (the copy exists for clean frames only: the IEEE-division bodies of a hostile frame are four times as long)
+    if (MEAO_X_BIL_WHOLE_TILE && DIV == DIV_EXACT_RCP && vec_ok_frame && HX0 + kUpsTileW <= hw && HY0 + kTileH <= hh)
+        bilateral_phase(std::true_type());
+    else
+        bilateral_phase(std::false_type());
 }
 
 // One blend pass (Upsample.main_blendout) evaluated for an arbitrary window of its OUTPUT level, into LDS:
@@ -2096,6 +2111,7 @@ struct IssueCarriedLoads {
     static constexpr bool kBeforeBilateral = true;
     static constexpr bool kGroupReciprocals = false;     // the kernels that carry a downsample tile are short of registers: A/B +3 %
     static constexpr bool kEstimateR8 = false;           // ... and wait on memory, not on VALU issue: 10 % fewer instructions, +4 us
+    static constexpr bool kReuseEstimate = false;
     const DownsampleArgs &d;
     float (&v)[kDsTileH / kDsRowsPerPass][4];
     bool mine;
@@ -2108,11 +2124,13 @@ struct IssueCarriedLoads {
 
 // The same for the lean tile (downsample_lean_load / _finish: wave-uniform row parity, ~8 VALU instructions per texel instead of ~18):
 // what the last kernel of a pipelined step carries since round 4 (270 vs 275 us per 16 frames, profiles/r04_ab_fused_lean_tile.jsonl).
-// With the lean tile the UNORM8 estimate and the grouped reciprocals still lose here: 305 and 288 us.
 struct IssueCarriedLoadsLean {
     static constexpr bool kBeforeBilateral = true;
-    static constexpr bool kGroupReciprocals = false;
-    static constexpr bool kEstimateR8 = false;
+    // Forms of the bilateral texel (A/B with the whole-tile copy of the phase, profiles/r04_ab_fused_bilateral_forms.jsonl; before that
+    // copy existed both lost here): exact sequences 272 us, UNORM8 estimate 257, grouped reciprocals 264, both 256 us per 16 frames.
+    static constexpr bool kGroupReciprocals = true;
+    static constexpr bool kEstimateR8 = true;
+    static constexpr bool kReuseEstimate = false;        // (70 of the 72 VGPRs that seven workgroups per CU allow: reuse spills)
     const DownsampleArgs &d;
     float4v (&q)[kDsTileH / kDsRowsPerPass];
     bool mine, full;
