@@ -1834,8 +1834,9 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         clk.mark(6 + pass);  // 6, 7: bilateral pass 0 / 1 (64-row tiles) incl. its stores being issued
     }
     };
-    // (the copy exists for clean frames only: the IEEE-division bodies of a hostile frame are four times as long)
-    if (MEAO_X_BIL_WHOLE_TILE && DIV == DIV_EXACT_RCP && vec_ok_frame && HX0 + kUpsTileW <= hw && HY0 + kTileH <= hh)
+    // (the copy exists for clean frames only -- the IEEE-division bodies of a hostile frame are four times as long -- and not in the
+    // nested launches, which have no registers for it: 3 spilled VGPRs in the two-level kernel, no gain measured there)
+    if (MEAO_X_BIL_WHOLE_TILE && !NESTED && DIV == DIV_EXACT_RCP && vec_ok_frame && HX0 + kUpsTileW <= hw && HY0 + kTileH <= hh)
         bilateral_phase(std::true_type());
     else
         bilateral_phase(std::false_type());
