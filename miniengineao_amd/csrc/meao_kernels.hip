@@ -738,18 +738,26 @@ struct TermConstants {
     static constexpr int kTerms = EXH ? 12 : 7;
     float inv_thickness[kTerms], front_depth[kTerms], weight[kTerms];
     float reject_fadeoff, intensity;
-    __device__ __forceinline__ explicit TermConstants(const RenderLevelArgs &src)
+    // All scalar loads first, then ONE statement that pins the values (a volatile asm per term made the compiler wait for each
+    // term's loads before it issued the next ones: eight dependent scalar-memory round trips per workgroup, right behind the
+    // window barrier).  render_tile calls this once its window loads are in flight, so the scalar loads' latency hides behind theirs.
+    __device__ __forceinline__ TermConstants() {}
+    __device__ __forceinline__ explicit TermConstants(const RenderLevelArgs &src) { load(src); }
+    __device__ __forceinline__ void load(const RenderLevelArgs &src)
     {
 #pragma unroll
         for (int t = 0; t < kTerms; ++t) {
             inv_thickness[t] = src.inv_thickness[t];
             front_depth[t] = src.front_depth[t];
             weight[t] = src.weight[t];
-            asm volatile("" : "+s"(inv_thickness[t]), "+s"(front_depth[t]), "+s"(weight[t]));   // stay in SGPRs
         }
         reject_fadeoff = src.reject_fadeoff;
         intensity = src.intensity;
-        asm volatile("" : "+s"(reject_fadeoff), "+s"(intensity));
+#define MEAO_PIN3(T) "+s"(inv_thickness[T]), "+s"(front_depth[T]), "+s"(weight[T])
+        asm volatile("" : MEAO_PIN3(0), MEAO_PIN3(1), MEAO_PIN3(2), MEAO_PIN3(3), MEAO_PIN3(4), MEAO_PIN3(5), MEAO_PIN3(6),
+                          "+s"(reject_fadeoff), "+s"(intensity));                       // stay in SGPRs
+        if constexpr (EXH) asm volatile("" : MEAO_PIN3(7), MEAO_PIN3(8), MEAO_PIN3(9), MEAO_PIN3(10), MEAO_PIN3(11));
+#undef MEAO_PIN3
     }
 };
 
@@ -927,6 +935,9 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
 
     PhaseClock clk(24);      // 24: window loaded, converted, in LDS; 25: barrier; 26..29: texel-loop iterations
     __builtin_amdgcn_s_setprio(3);
+    TermConstants<EXH> terms_storage;
+    const TermConstants<EXH> &terms = terms_storage;
+    typename AO::type *__restrict__ dst;
     // ---- stage the (64+32) x (32+32) window.  Window texel (vx,vy) (level coordinates, may
     // be outside the level) belongs to slice (vx&3, vy&3), slice texel (vx>>2, vy>>2); the
     // reference clamps the slice texel per slice (REN:118 Gather + clamp sampler) and finds
@@ -954,6 +965,10 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
             whole[r] = mine && py < lh && vec_ok && px0 + 3 < lw;
             if (whole[r]) raw[r] = *reinterpret_cast<const float4v *>(src + row_at[r]);
         }
+        // (the texel loop's constants: fetched while the window loads are in flight, see TermConstants)
+        terms_storage.load(L);
+        dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
+        asm volatile("" : "+s"(dst));
         // Phase 2: the f16 round trip the atlas store applies, then one 16-byte LDS store per quad
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
@@ -980,9 +995,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     __builtin_amdgcn_s_setprio(0);
 
     // ---- each lane: a texel pair (X, X+1) in each of the TILE_H / 8 iterations
-    typename AO::type *__restrict__ dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
     const bool pair_store = ((lw & 1) == 0);
-    const TermConstants<EXH> terms(L);
     // a wave covers a compact 32 x 4 block (16 lanes x 4 rows) of the tile in each of the 4 iterations
     constexpr int kBlocksX = kRenTileW / 32, kWaves = kRenThreads / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1522,6 +1535,11 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const ao_t *__restrict__ lo_ao2 = a.lo_ao2 ? frame_ptr(static_cast<const ao_t *>(a.lo_ao2), a.frame_stride, frame) : nullptr;
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
     const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
+    // (fetched here, not where the bilateral phase first stores: a.dst[frame] is a scalar load whose latency would sit right
+    // behind the last barrier)
+    ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
+                                   : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
+    asm volatile("" : "+s"(dst));
 
     PhaseClock clk(FINAL ? 0 : 8);
     __builtin_amdgcn_s_setprio(3);
@@ -1699,8 +1717,6 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     }
 
     // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
-    ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
-                                   : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
     const bool vec_ok_frame = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
     // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
     constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
