@@ -1323,7 +1323,7 @@ __device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_dept
 // REUSE: the exact path starts from the estimate's x and 1 / x (14 instructions fewer on that path, 5 - 8 VGPRs more live across
 // the branch); without it the whole exact sequence is run again from an opaque copy of the depth, so that nothing of the estimate
 // has to stay in registers for the rare path (the nested kernels have none to spare).
-constexpr float kR8Margin = 0x1p-10f;
+constexpr float kR8Margin = 0x1p-10f;     // (1.25 * 2^-11, still above the bound, measured the same: profiles/r04_ab_r8_margin.jsonl)
 
 // (v_cvt_pk_u8_f32, which would convert and pack in one instruction, does not truncate like v_cvt_u32_f32: tried in round 4.)
 template <bool GROUPED, bool REUSE = false>
