@@ -1724,131 +1724,131 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const int hx0 = HX0 + 4 * tx;
     // WHOLE: the tile lies inside the frame and its rows take 4-texel loads and stores -- no lane or row of it is masked
     auto bilateral_phase = [&](auto whole_tile) {
-    constexpr bool WHOLE = decltype(whole_tile)::value;
-    const bool vec_ok = WHOLE || vec_ok_frame;
-    if (!WHOLE && hx0 >= hw) return;
+        constexpr bool WHOLE = decltype(whole_tile)::value;
+        const bool vec_ok = WHOLE || vec_ok_frame;
+        if (!WHOLE && hx0 >= hw) return;
 #pragma unroll       // the hoisted operands live in registers: static indices
-    for (int pass = 0; pass < kTileH / 32; ++pass) {
-        const int ty = (tid >> 4) + 16 * pass;
-        const int hy0 = HY0 + 2 * ty;
-        if (!WHOLE && hy0 >= hh) return;
+        for (int pass = 0; pass < kTileH / 32; ++pass) {
+            const int ty = (tid >> 4) + 16 * pass;
+            const int hy0 = HY0 + 2 * ty;
+            if (!WHOLE && hy0 >= hh) return;
 
-        float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
+            float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-            const float2v v0 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx]);
-            const float2v v1 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx + 2]);
-            const float2v d0 = *reinterpret_cast<const float2v *>(&dep_at(ty + rr + 2, 2 * tx + 2));
-            const float2v d1 = *reinterpret_cast<const float2v *>(&dep_at(ty + rr + 2, 2 * tx + 4));
-            vb[rr][0] = v0.x; vb[rr][1] = v0.y; vb[rr][2] = v1.x; vb[rr][3] = v1.y;
-            dl[rr][0] = d0.x; dl[rr][1] = d0.y; dl[rr][2] = d1.x; dl[rr][3] = d1.y;
-        }
+            for (int rr = 0; rr < 3; ++rr) {
+                const float2v v0 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx]);
+                const float2v v1 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx + 2]);
+                const float2v d0 = *reinterpret_cast<const float2v *>(&dep_at(ty + rr + 2, 2 * tx + 2));
+                const float2v d1 = *reinterpret_cast<const float2v *>(&dep_at(ty + rr + 2, 2 * tx + 4));
+                vb[rr][0] = v0.x; vb[rr][1] = v0.y; vb[rr][2] = v1.x; vb[rr][3] = v1.y;
+                dl[rr][0] = d0.x; dl[rr][1] = d0.y; dl[rr][2] = d1.x; dl[rr][3] = d1.y;
+            }
 
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const int hy = hy0 + f;
-            if (!WHOLE && hy >= hh) break;
-            const size_t hrow = static_cast<size_t>(hy) * hw + hx0;
-            float hd[4], ha[4] = {1.0f, 1.0f, 1.0f, 1.0f};                  // HiSSAOs = 1 in "main" (UPS:222)
-            if constexpr (FINAL) {
-                const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
-                if (vec_ok) {
-                    const ushort4v q = hoist_hd16[pass][f];
-                    hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
-                    hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
+            for (int f = 0; f < 2; ++f) {
+                const int hy = hy0 + f;
+                if (!WHOLE && hy >= hh) break;
+                const size_t hrow = static_cast<size_t>(hy) * hw + hx0;
+                float hd[4], ha[4] = {1.0f, 1.0f, 1.0f, 1.0f};                  // HiSSAOs = 1 in "main" (UPS:222)
+                if constexpr (FINAL) {
+                    const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
+                    if (vec_ok) {
+                        const ushort4v q = hoist_hd16[pass][f];
+                        hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
+                        hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hd[e] = (hx0 + e < hw) ? f16_bits_to_f32(p[e]) : 1.0f;
+                    }
                 } else {
+                    const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
+                    const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
+                    if (vec_ok) {
+                        const float4v d4 = hoist_hd32[pass][f];
+                        const typename AO::type4 a4 = hoist_ha[pass][f];
+                        hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
+                        ha[0] = AO::decode(a4.x); ha[1] = AO::decode(a4.y);
+                        ha[2] = AO::decode(a4.z); ha[3] = AO::decode(a4.w);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hd[e] = (hx0 + e < hw) ? f16_bits_to_f32(p[e]) : 1.0f;
+                        for (int e = 0; e < 4; ++e) {
+                            hd[e] = (hx0 + e < hw) ? p[e] : 1.0f;
+                            ha[e] = (hx0 + e < hw) ? AO::decode(q[e]) : 1.0f;
+                        }
+                    }
                 }
-            } else {
-                const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
-                const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
-                if (vec_ok) {
-                    const float4v d4 = hoist_hd32[pass][f];
-                    const typename AO::type4 a4 = hoist_ha[pass][f];
-                    hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
-                    ha[0] = AO::decode(a4.x); ha[1] = AO::decode(a4.y);
-                    ha[2] = AO::decode(a4.z); ha[3] = AO::decode(a4.w);
-                } else {
+                ao_t res[4];
+                if constexpr (!MEAO_X_UPS_EXACT_R8 && Hook::kEstimateR8 && DIV == DIV_EXACT_RCP && AOFMT == MEAO_AO_R8) {
+                    // UNORM8 storage: the code from the uncorrected reciprocals wherever that provably is the reference's code
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        hd[e] = (hx0 + e < hw) ? p[e] : 1.0f;
-                        ha[e] = (hx0 + e < hw) ? AO::decode(q[e]) : 1.0f;
-                    }
-                }
-            }
-            ao_t res[4];
-            if constexpr (!MEAO_X_UPS_EXACT_R8 && Hook::kEstimateR8 && DIV == DIV_EXACT_RCP && AOFMT == MEAO_AO_R8) {
-                // UNORM8 storage: the code from the uncorrected reciprocals wherever that provably is the reference's code
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // as below
-                    const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
-                    float gd[4], ga[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int g = (comp + i) & 3;
-                        gd[i] = dl[rr + gy[g]][cc + gx[g]];
-                        ga[i] = vb[rr + gy[g]][cc + gx[g]];
-                    }
-                    res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, !NESTED && Hook::kReuseEstimate>(hd[e], ha[e], gd, ga, bilateral_k));
-                }
-            } else if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
-                // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than
-                // one that follows another (tools/ubench_issue.hip "bilateral mix": 3.81 -> 3.55 cycles per instruction).  A/B:
-                // L2->L1 65 -> 58.5 us, L1->L0 202.5 -> 199.2 us; two texels per group: the same (profiles/r03_ab_rcp_group*.jsonl).
-                constexpr int kGroup = 1;             // texels whose reciprocals are issued together
-#pragma unroll
-                for (int e0 = 0; e0 < 4; e0 += kGroup) {
-                    float gd[kGroup][4], ga[kGroup][4], ghd[kGroup], gha[kGroup], gout[kGroup];
-#pragma unroll
-                    for (int t = 0; t < kGroup; ++t) {
-                        const int e = e0 + t;
-                        const int cc = ((e + 1) >> 1) + 1, rr = f + 1;
+                        const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // as below
                         const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+                        float gd[4], ga[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int g = (comp + i) & 3;
-                            gd[t][i] = dl[rr + gy[g]][cc + gx[g]];
-                            ga[t][i] = vb[rr + gy[g]][cc + gx[g]];
+                            gd[i] = dl[rr + gy[g]][cc + gx[g]];
+                            ga[i] = vb[rr + gy[g]][cc + gx[g]];
                         }
-                        ghd[t] = hd[e]; gha[t] = ha[e];
+                        res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, !NESTED && Hook::kReuseEstimate>(hd[e], ha[e], gd, ga, bilateral_k));
                     }
-                    bilateral_upsample_grouped<kGroup>(ghd, gha, gd, ga, bilateral_k, gout);
+                } else if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
+                    // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than
+                    // one that follows another (tools/ubench_issue.hip "bilateral mix": 3.81 -> 3.55 cycles per instruction).  A/B:
+                    // L2->L1 65 -> 58.5 us, L1->L0 202.5 -> 199.2 us; two texels per group: the same (profiles/r03_ab_rcp_group*.jsonl).
+                    constexpr int kGroup = 1;             // texels whose reciprocals are issued together
 #pragma unroll
-                    for (int t = 0; t < kGroup; ++t) res[e0 + t] = AO::template encode<RTNE>(gout[t]);
+                    for (int e0 = 0; e0 < 4; e0 += kGroup) {
+                        float gd[kGroup][4], ga[kGroup][4], ghd[kGroup], gha[kGroup], gout[kGroup];
+#pragma unroll
+                        for (int t = 0; t < kGroup; ++t) {
+                            const int e = e0 + t;
+                            const int cc = ((e + 1) >> 1) + 1, rr = f + 1;
+                            const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int g = (comp + i) & 3;
+                                gd[t][i] = dl[rr + gy[g]][cc + gx[g]];
+                                ga[t][i] = vb[rr + gy[g]][cc + gx[g]];
+                            }
+                            ghd[t] = hd[e]; gha[t] = ha[e];
+                        }
+                        bilateral_upsample_grouped<kGroup>(ghd, gha, gd, ga, bilateral_k, gout);
+#pragma unroll
+                        for (int t = 0; t < kGroup; ++t) res[e0 + t] = AO::template encode<RTNE>(gout[t]);
+                    }
+                } else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // hi texel (4tx+e, 2ty+f) is written by dispatch thread D = ((hx+1)>>1, (hy+1)>>1)
+                    // through Gather component comp (UPS:229-232); its taps are rotated by comp.
+                    const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // D in vb/dl coordinates
+                    const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+                    const int g0 = comp & 3, g1 = (comp + 1) & 3, g2 = (comp + 2) & 3, g3 = (comp + 3) & 3;
+                    const float v = bilateral_upsample<DIV>(
+                        hd[e], ha[e],
+                        dl[rr + gy[g0]][cc + gx[g0]], dl[rr + gy[g1]][cc + gx[g1]],
+                        dl[rr + gy[g2]][cc + gx[g2]], dl[rr + gy[g3]][cc + gx[g3]],
+                        vb[rr + gy[g0]][cc + gx[g0]], vb[rr + gy[g1]][cc + gx[g1]],
+                        vb[rr + gy[g2]][cc + gx[g2]], vb[rr + gy[g3]][cc + gx[g3]],
+                        bilateral_k);
+                    res[e] = AO::template encode<RTNE>(v);
                 }
-            } else
+                ao_t *o = dst + hrow;
+                if (vec_ok) {
+                    typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
+                    // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
+                    if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
+                    else *reinterpret_cast<typename AO::type4 *>(o) = r4;
+                } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // hi texel (4tx+e, 2ty+f) is written by dispatch thread D = ((hx+1)>>1, (hy+1)>>1)
-                // through Gather component comp (UPS:229-232); its taps are rotated by comp.
-                const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // D in vb/dl coordinates
-                const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
-                const int g0 = comp & 3, g1 = (comp + 1) & 3, g2 = (comp + 2) & 3, g3 = (comp + 3) & 3;
-                const float v = bilateral_upsample<DIV>(
-                    hd[e], ha[e],
-                    dl[rr + gy[g0]][cc + gx[g0]], dl[rr + gy[g1]][cc + gx[g1]],
-                    dl[rr + gy[g2]][cc + gx[g2]], dl[rr + gy[g3]][cc + gx[g3]],
-                    vb[rr + gy[g0]][cc + gx[g0]], vb[rr + gy[g1]][cc + gx[g1]],
-                    vb[rr + gy[g2]][cc + gx[g2]], vb[rr + gy[g3]][cc + gx[g3]],
-                    bilateral_k);
-                res[e] = AO::template encode<RTNE>(v);
+                    for (int e = 0; e < 4; ++e)
+                        if (hx0 + e < hw) o[e] = res[e];
+                }
             }
-            ao_t *o = dst + hrow;
-            if (vec_ok) {
-                typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
-                // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
-                if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
-                else *reinterpret_cast<typename AO::type4 *>(o) = r4;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (hx0 + e < hw) o[e] = res[e];
-            }
+            clk.mark(6 + pass);  // 6, 7: bilateral pass 0 / 1 (64-row tiles) incl. its stores being issued
         }
-        clk.mark(6 + pass);  // 6, 7: bilateral pass 0 / 1 (64-row tiles) incl. its stores being issued
-    }
     };
     // (the copy exists for clean frames only -- the IEEE-division bodies of a hostile frame are four times as long -- and not in the
     // nested launches, which have no registers for it: 3 spilled VGPRs in the two-level kernel, no gain measured there)
