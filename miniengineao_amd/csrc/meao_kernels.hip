@@ -1410,7 +1410,9 @@ struct UpsLoads {
     typename AO::type4 wa[kRounds];
     ushort4v hd16[kPasses][2];
     float4v hd32[kPasses][2];
-    typename AO::type4 ha[kPasses][2];
+    // four AO texels as ONE integer: a <4 x i8> value is split into bytes where it is loaded, which puts the wait for it there
+    typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type ao_bits_t;
+    ao_bits_t ha[kPasses][2];
 };
 
 template <bool FINAL, int TILE_H>
@@ -1447,7 +1449,7 @@ __device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, int til
                 } else {
                     L.hd32[pass][f] = *reinterpret_cast<const float4v *>(at_byte_offset(
                         frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame), hrow * 4u));
-                    L.ha[pass][f] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(
+                    L.ha[pass][f] = *reinterpret_cast<const typename UpsLoads<AOFMT, FINAL, TILE_H>::ao_bits_t *>(at_byte_offset(
                         frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame), hrow * static_cast<uint32_t>(sizeof(ao_t))));
                 }
             }
@@ -1706,9 +1708,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             if constexpr (FINAL) {
                 asm volatile("" : : "v"(hoist_hd16[pass][0]), "v"(hoist_hd16[pass][1]));
             } else {
-                typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type bits_t;
-                asm volatile("" : : "v"(hoist_hd32[pass][0]), "v"(hoist_hd32[pass][1]),
-                             "v"(__builtin_bit_cast(bits_t, hoist_ha[pass][0])), "v"(__builtin_bit_cast(bits_t, hoist_ha[pass][1])));
+                asm volatile("" : : "v"(hoist_hd32[pass][0]), "v"(hoist_hd32[pass][1]), "v"(hoist_ha[pass][0]), "v"(hoist_ha[pass][1]));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1717,6 +1717,15 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     }
 
     // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
+    if constexpr (!FINAL) {
+        // The hoisted AO quads (one integer each, UpsLoads) pass through an opaque statement HERE, behind the last barrier: their
+        // decoding otherwise moves up to the window phase -- `s_waitcnt vmcnt(0)` in front of the first barrier, i.e. the latency
+        // the hoisting was meant to hide (round 4: ISA of the L2->L1 kernel).
+#pragma unroll
+        for (int pass = 0; pass < kPasses; ++pass)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) asm volatile("" : "+v"(hoist_ha[pass][f]));
+    }
     const bool vec_ok_frame = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
     // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
     constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
@@ -1765,10 +1774,10 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                     const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
                     if (vec_ok) {
                         const float4v d4 = hoist_hd32[pass][f];
-                        const typename AO::type4 a4 = hoist_ha[pass][f];
+                        const typename Loads::ao_bits_t a4 = hoist_ha[pass][f];
                         hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
-                        ha[0] = AO::decode(a4.x); ha[1] = AO::decode(a4.y);
-                        ha[2] = AO::decode(a4.z); ha[3] = AO::decode(a4.w);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ha[e] = AO::decode(static_cast<ao_t>(a4 >> (8 * sizeof(ao_t) * e)));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
