@@ -74,11 +74,8 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out_pa
 # Experimental arms of meao_kernels.hip (MEAO_X_* switches) that are kept in the source: name -> -D flags
 VARIANTS = {
     "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],          # diagnostic: phase stamps, render residency log
-    "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],
-    "bil_vc": ["-DMEAO_X_BIL_VGPR_CONSTS=1"],
-    "bil_wt": ["-DMEAO_X_BIL_WHOLE_TILE=1"],
-    "bil_vcwt": ["-DMEAO_X_BIL_VGPR_CONSTS=1", "-DMEAO_X_BIL_WHOLE_TILE=1"],
-    "bil_all": ["-DMEAO_X_BIL_VGPR_CONSTS=1", "-DMEAO_X_BIL_WHOLE_TILE=1", "-DMEAO_X_BIL_PACK_U8=1"],         # every UNORM8 bilateral result through the exact-division sequences (cross-check of the estimate)
+    "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],         # every UNORM8 bilateral result through the exact-division sequences (cross-check of the estimate)
+    "nowt": ["-DMEAO_X_BIL_WHOLE_TILE=0"],          # without the unmasked copy of the bilateral phase (the round-3 form of the upsample tile)
 }
 
 
