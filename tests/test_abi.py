@@ -213,3 +213,15 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle", text, re.M), f
+
+
+def test_every_variant_arm_names_a_switch_of_the_kernel_source():
+    """build.VARIANTS may only carry -D flags whose macro exists in meao_kernels.hip (an arm whose switch has been removed
+    builds a copy of the product under another name: four such arms once travelled through an evidence round)."""
+    import re
+    from miniengineao_amd import build
+    src = open(os.path.join(os.path.dirname(build.__file__), "csrc", "meao_kernels.hip")).read()
+    for name, flags in build.VARIANTS.items():
+        for flag in flags:
+            macro = re.match(r"-D(\w+)", flag).group(1)
+            assert re.search(r"#\s*ifndef\s+%s\b" % macro, src), f"variant {name}: {macro} is not a switch of meao_kernels.hip"
