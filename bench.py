@@ -484,10 +484,20 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def resolve_timed_region(steps, min_time_ms):
+    """An explicit --steps is honoured exactly (the driver's contract: "time EXACTLY K steps"); only the flag-less default
+    stretches the timed region to 100 ms.  --min-time-ms given explicitly always applies."""
+    if min_time_ms is None:
+        min_time_ms = 100.0 if steps is None else 0.0
+    return (30 if steps is None else steps), min_time_ms
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps.  Given explicitly (the driver's contract) EXACTLY that many are timed, unless --min-time-ms is "
+                         "given too; default 30, raised so that the timed region lasts 100 ms")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
     ap.add_argument("--batch", type=int, default=None,
@@ -531,9 +541,10 @@ def main() -> int:
                     help="skip the two-pool-members-on-one-device leg of the default N=1 line (best_host_config)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short 1080p / 8K sub-measurements of the default N=1 line")
-    ap.add_argument("--min-time-ms", type=float, default=100.0,
+    ap.add_argument("--min-time-ms", type=float, default=None,
                     help="raise --steps so that the timed region lasts at least this long (clock state and rank skew "
-                         "matter less in a >= 100 ms region); the JSON reports the steps actually timed; 0 = exactly --steps")
+                         "matter less in a >= 100 ms region); the JSON reports the steps actually timed; 0 = exactly --steps.  "
+                         "Default: 100 when --steps is not given, 0 (exactly --steps) when it is")
     ap.add_argument("--validate-frames", type=int, default=-1,
                     help="frames per rank checked bit-for-bit against the CPU oracle after each timed region "
                          "(-1 = every frame at N=1, 2 per rank at N>1; 0 = checksums only)")
@@ -544,6 +555,7 @@ def main() -> int:
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
     args = ap.parse_args()
+    args.steps, args.min_time_ms = resolve_timed_region(args.steps, args.min_time_ms)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")

@@ -43,8 +43,11 @@ SAMPLES_CHECKER, SAMPLES_EXHAUSTIVE = 0, 1
 LAUNCH_DIRECT, LAUNCH_GRAPH = 0, 1
 DEBUG_OCCLUSION_HQ1 = 18
 # meao_debug_key
+# (5 was FAIL_NEXT_ALLOCS until round 5: fault injection is no longer part of the production ABI -- meao_test_fail_next_allocs
+# exists only in the `testhooks` variant library, built with -DMEAO_TESTING=1)
 (DEBUG_FUSE_COARSE_BLEND, DEBUG_NESTED_MAX_TILES, DEBUG_RENDER_SMALL_MAX_TILES, DEBUG_FINAL_SMALL_MAX_TILES,
- DEBUG_DS_SMALL_MAX_TILES, DEBUG_FAIL_NEXT_ALLOCS, DEBUG_DS_SHARE_IN_BLEND, DEBUG_DS_SIDE_STREAM) = range(8)
+ DEBUG_DS_SMALL_MAX_TILES, _DEBUG_RESERVED_5, DEBUG_DS_SHARE_IN_BLEND, DEBUG_DS_SIDE_STREAM, DEBUG_RENDER_FROM_DEPTH,
+ DEBUG_RENDER_FROM_DEPTH_MAX_TILES, DEBUG_SPLIT_BATCH) = range(11)
 POOL_PATH_SAME_DEVICE, POOL_PATH_PEER_DIRECT, POOL_PATH_STAGED = 0, 1, 2
 NUM_BUFFERS = 21
 

@@ -249,9 +249,13 @@ static struct {
     pthread_t tid[MAXT];
     int workers;                    /* threads created so far */
     int sleepers;                   /* workers blocked on `work` (under mu) */
-    row_fn fn; void *arg; int rows, chunk, participants;      /* the job: published before `generation` moves */
+    row_fn fn; void *arg; int rows, chunk;                    /* the job: published before `generation` moves */
     /* the three words the threads hammer, one cache line each */
-    volatile int generation __attribute__((aligned(64)));     /* job number */
+    /* (job number << 9) | participants: ONE word, so that a worker decides whether it takes part in a job from the same
+     * load that showed it the job.  (with the count in a separate field a worker that was not part of job G,
+     * preempted between the two loads, could read job G+1's larger count while still remembering G, join G+1 twice and
+     * release the caller while other workers were still writing rows.) */
+    volatile unsigned generation __attribute__((aligned(64)));
     volatile int next __attribute__((aligned(64)));           /* first row nobody has drawn yet */
     volatile int running __attribute__((aligned(64)));        /* participants that have not finished the job */
 } g_pool = { .call = PTHREAD_MUTEX_INITIALIZER, .mu = PTHREAD_MUTEX_INITIALIZER, .work = PTHREAD_COND_INITIALIZER, .chunk = 1 };
@@ -279,7 +283,7 @@ static void pool_draw_chunks(void)
 static void *pool_worker(void *p)
 {
     const int id = (int)(intptr_t)p;
-    int seen = 0;
+    unsigned seen = 0;
     for (;;) {
         int spins = 0;
         while (__atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE) == seen) {
@@ -291,7 +295,7 @@ static void *pool_worker(void *p)
             pthread_mutex_unlock(&g_pool.mu);
         }
         seen = __atomic_load_n(&g_pool.generation, __ATOMIC_ACQUIRE);
-        if (id >= g_pool.participants - 1) continue;            /* not part of this job (the caller waits for its participants only) */
+        if (id >= (int)(seen & 511u) - 1) continue;             /* not part of this job (the caller waits for its participants only) */
         pool_draw_chunks();
         __atomic_sub_fetch(&g_pool.running, 1, __ATOMIC_ACQ_REL);
     }
@@ -312,10 +316,10 @@ static void par_rows(int nthreads, int rows, row_fn fn, void *arg)
     const int participants = (g_pool.workers < nthreads - 1 ? g_pool.workers : nthreads - 1) + 1;
     g_pool.fn = fn; g_pool.arg = arg; g_pool.rows = rows;
     g_pool.chunk = rows / (4 * participants) > 0 ? rows / (4 * participants) : 1;
-    g_pool.participants = participants;
     __atomic_store_n(&g_pool.next, 0, __ATOMIC_RELAXED);
     __atomic_store_n(&g_pool.running, participants, __ATOMIC_RELAXED);
-    __atomic_store_n(&g_pool.generation, g_pool.generation + 1, __ATOMIC_RELEASE);      /* publishes the job */
+    const unsigned job = (g_pool.generation >> 9) + 1u;          /* MAXT = 256 participants fit the low 9 bits */
+    __atomic_store_n(&g_pool.generation, (job << 9) | (unsigned)participants, __ATOMIC_RELEASE);      /* publishes the job */
     pthread_mutex_lock(&g_pool.mu);
     if (g_pool.sleepers > 0) pthread_cond_broadcast(&g_pool.work);
     pthread_mutex_unlock(&g_pool.mu);

@@ -49,7 +49,21 @@ CASES = {
                                     dict(ao_format=1, f16_rounding=1, intensity=1.3, thickness_modifier=2.0,
                                          blur_tolerance=-3.0, upsample_tolerance=-6.0, noise_filter_tolerance=-1.5), True),
     "ref_s3_64x48_sponza": (64, 48, "S3", 0, synth.SPONZA_CAMERA, dict(intensity=1.1), False),
+    # Round 5: frames whose every level spans several HIP tiles (render 128x32 / 64x16, upsample 64x64 /
+    # 64x32, downsample 128x32), with interior (whole-tile) and edge tiles; minutes of interpreter time each.
+    "ref_s2_322x182_r8": (322, 182, "S2", 31, synth.DEFAULT_CAMERA, {}, False),
+    "ref_s2_644x364_f16_rtne_convz_sky": (644, 364, "S2", 32, synth.Camera(reversed_z=False),
+                                          dict(ao_format=1, f16_rounding=1, intensity=1.15, thickness_modifier=1.7), True),
+    "ref_s2h_516x260_hostile_r8": (516, 260, "S2H", 33, synth.DEFAULT_CAMERA, {}, False),
+    # storage conversions by the independent NumPy model below instead of the oracle's C functions
+    "ref_s2_150x86_r8_numpy_codecs": (150, 86, "S2", 34, synth.DEFAULT_CAMERA, dict(intensity=0.9), True),
+    "ref_s2_134x70_f16_rtz_numpy_codecs": (134, 70, "S2", 35, synth.Camera(reversed_z=False),
+                                           dict(ao_format=1, thickness_modifier=2.5), False),
 }
+# fixtures whose UNORM8 / f16 encode-decode is NOT the oracle's (VERDICT r4 weak #1a)
+NUMPY_CODEC_CASES = ("ref_s2_150x86_r8_numpy_codecs", "ref_s2_134x70_f16_rtz_numpy_codecs")
+# frames with NaN texels: compare bit patterns with any-NaN == any-NaN (tests.helpers.nan_aware_equal)
+HOSTILE_CASES = ("ref_s2h_516x260_hostile_r8",)
 
 
 AO_CS = "/root/reference/Assets/MiniEngineAO/AmbientOcclusion.cs"
@@ -112,7 +126,39 @@ def hq_render_commands(s, it, comp, level):
             "tex": {"DepthTex": f"LowDepth{level}", "Occlusion": f"OcclusionHQ{level}"}, "const": d["const"]}
 
 
-def textures(s, cmd, result_rt):
+def numpy_codecs(f16_rounding):
+    """Storage conversions restated from the format definitions with NumPy only -- no call into oracle/
+    (VERDICT r4 weak #1a: the other fixtures' conversions are the oracle's own C functions).
+    f16: IEEE binary16 via NumPy's own float16 (round-to-nearest-even, overflow -> inf); round-toward-
+    zero = step the RTNE result one code toward zero whenever it rounded away (inf -> 65504, the clamp of
+    DESIGN.md section 2 included).  UNORM8: n / 255 in binary32; store = trunc(saturate(x) * 255 + 0.5),
+    one binary32 rounding per operation, NaN -> 0 (D3D11 float -> UNORM rule)."""
+    def f16_decode(bits):
+        return np.array([bits], np.uint16).view(np.float16).astype(np.float32)[0]
+
+    def f16_encode(v):
+        v32 = np.array([v], np.float32)
+        with np.errstate(over="ignore"):
+            h = v32.astype(np.float16)
+        bits = int(h.view(np.uint16)[0])
+        if f16_rounding == O.F16_RTZ and not np.isnan(v32[0]) and abs(np.float32(h[0])) > abs(v32[0]):
+            bits -= 1                                   # sign-magnitude: one code toward zero
+        return bits
+
+    def r8_decode(n):
+        return np.float32(int(n)) / np.float32(255)
+
+    def r8_encode(v):
+        v = np.float32(v)
+        if np.isnan(v):
+            return 0
+        c = min(max(v, np.float32(0)), np.float32(1))
+        t = np.float32(c * np.float32(255))
+        return int(np.float32(t + np.float32(0.5)))
+    return dict(decode=f16_decode, encode=f16_encode), dict(decode=r8_decode, encode=r8_encode)
+
+
+def textures(s, cmd, result_rt, independent_codecs=False):
     """Render textures exactly as the reference allocates them (names, dims, slices, formats come
     from the recorded GetTemporaryRT(Array) calls and the persistent result RT).  The only
     deviation is this project's extension: AO targets are RHalf instead of R8 when s.ao_format
@@ -122,6 +168,8 @@ def textures(s, cmd, result_rt):
                encode=lambda v: L.meao_oracle_f32_to_f16(float(v), s.f16_rounding))
     r8 = dict(decode=lambda v: np.float32(L.meao_oracle_unorm8_to_f32(int(v))),
               encode=lambda v: L.meao_oracle_f32_to_unorm8(float(v)))
+    if independent_codecs:
+        f16, r8 = numpy_codecs(s.f16_rounding)
     allocs = dict(cmd.allocs)
     allocs["AmbientOcclusion"] = (result_rt.width, result_rt.height, 1, result_rt.format._name.split(".")[-1])
     for k in s.hq_level_list():                               # this project's extra targets
@@ -164,13 +212,13 @@ def variant_dispatches(s, cmd, it, comp):
     return out
 
 
-def run_reference_shaders(depth, s, log=print):
+def run_reference_shaders(depth, s, log=print, independent_codecs=False):
     """The reference end to end: its C# decides allocations, bindings, constants and dispatch sizes,
     its HLSL does the arithmetic; both are interpreted from the source text under /root/reference."""
     assert s.depth_format == O.DEPTH_F32, "the reference runs on an RFloat depth"
     assert s.num_levels == 4, "the reference always runs 4 levels"
     src, cmd, result_rt, it, comp = record_reference_commands(s, want_interp=True)
-    arrs, tex = textures(s, cmd, result_rt)
+    arrs, tex = textures(s, cmd, result_rt, independent_codecs)
     depth_tex = HI.Texture(np.ascontiguousarray(depth, np.float32)[None])
     rev = {"UNITY_REVERSED_Z": "1"} if s.reversed_z else {}
     t0 = time.time()
@@ -205,6 +253,8 @@ def run_reference_shaders(depth, s, log=print):
 def make_depth(kind, w, h, seed, cam, sky):
     if kind == "S3":
         depth = synth.atrium(w, h, cam)
+    elif kind == "S2H":                                                # NaN / inf / denormal / negative / > 1 texels
+        depth = H.hostile_frame(w, h, seed, cam=cam, density=0.004)
     else:
         depth = synth.occluder_field(w, h, seed, n_rects=12, n_discs=12, cam=cam)
     if sky:                                                            # a block of sky texels (1e5)
@@ -220,9 +270,10 @@ def main(only=None):
         print(name)
         depth = make_depth(kind, w, h, seed, cam, sky)
         s = H.settings(O, w, h, cam=cam, **over)
-        ref, _ = run_reference_shaders(depth, s)
+        ref, _ = run_reference_shaders(depth, s, independent_codecs=name in NUMPY_CODEC_CASES)
         want = O.run(depth, s)
-        bad = [k for k in ref if not np.array_equal(ref[k], want[k])]
+        same = (lambda a, b: H.nan_aware_equal(a, b)[0]) if name in HOSTILE_CASES else np.array_equal
+        bad = [k for k in ref if not same(ref[k], want[k])]
         print("  interpreter vs oracle: %s" % ("all %d buffers identical" % len(ref) if not bad else "DIFFER: %s" % bad))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), depth=depth, **ref)
 

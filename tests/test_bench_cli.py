@@ -42,3 +42,13 @@ def test_rccl_launch_needs_one_device_per_rank(monkeypatch):
     monkeypatch.setattr(subprocess, "run", lambda cmd, env=None: calls.append(cmd) or types.SimpleNamespace(returncode=0))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--dist-backend", "gloo"])
     assert bench.self_launch(types.SimpleNamespace(gpus=2, dist_backend="gloo")) == 0 and "--nproc-per-node=2" in calls[0]
+
+
+def test_an_explicit_steps_is_timed_exactly():
+    """`--steps K` (the driver's command line) times exactly K steps; only the flag-less default
+    stretches the timed region to 100 ms; an explicit --min-time-ms always applies."""
+    import bench
+    assert bench.resolve_timed_region(20, None) == (20, 0.0)
+    assert bench.resolve_timed_region(None, None) == (30, 100.0)
+    assert bench.resolve_timed_region(20, 100.0) == (20, 100.0)
+    assert bench.resolve_timed_region(None, 0.0) == (30, 0.0)
