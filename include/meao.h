@@ -396,23 +396,29 @@ MEAO_API int32_t meao_pool_synchronize(meao_pool *pool);
  * way; this is a performance diagnostic.  Synchronises the stream of that call. */
 MEAO_API int32_t meao_hostile_frames(meao_ctx *ctx, uint64_t *out_mask);
 
-/* Launch-structure overrides and fault injection, for tests and A/B runs (the library reads no
- * environment variables).  Every structure gives bit-identical results; the defaults are what measured
- * fastest.  FUSE_COARSE_BLEND 0 = three separate blend launches; *_MAX_TILES = tile-count thresholds at or
- * below which a call uses the nested three-level blend launch / 128x8 render tiles / 64x32 final tiles /
- * 128x8 downsample tiles (0 = never); FAIL_NEXT_ALLOCS n = the next n allocations of intermediates
- * (meao_resize, first meao_prefetch_batch) fail with MEAO_ERR_OUT_OF_MEMORY. */
+/* Launch-structure overrides for tests and A/B runs (the library reads no environment variables).  Every
+ * structure gives bit-identical results; the defaults are what measured fastest.  FUSE_COARSE_BLEND 0 = three
+ * separate blend launches; *_MAX_TILES = tile-count thresholds at or below which a call uses the nested
+ * three-level blend launch / 128x8 render tiles / 64x32 final tiles / 128x8 downsample tiles (0 = never).
+ * (Key 5 was FAIL_NEXT_ALLOCS, fault injection: no longer part of this ABI -- the `testhooks` variant library built with
+ * -DMEAO_TESTING=1 exports meao_test_fail_next_allocs for the resize tests; the product returns INVALID_ARGUMENT for key 5.) */
 typedef enum meao_debug_key {
     MEAO_DEBUG_FUSE_COARSE_BLEND = 0, MEAO_DEBUG_NESTED_MAX_TILES = 1, MEAO_DEBUG_RENDER_SMALL_MAX_TILES = 2,
-    MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4, MEAO_DEBUG_FAIL_NEXT_ALLOCS = 5,
+    MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4, MEAO_DEBUG_RESERVED_5 = 5,
     MEAO_DEBUG_DS_SHARE_IN_BLEND = 6,  /* percent (0..100) of the next batch's downsample tiles (meao_prefetch_batch) carried by
                                         * the L2 -> L1 blend launch instead of the last kernel */
-    MEAO_DEBUG_DS_SIDE_STREAM = 7      /* 0 = off.  gate + 10 * shape: the announced batch's downsample pass runs as its own kernel on a
+    MEAO_DEBUG_DS_SIDE_STREAM = 7,     /* 0 = off.  gate + 10 * shape: the announced batch's downsample pass runs as its own kernel on a
                                         * second, low-priority stream of the context, released when the call's stream reaches `gate`
                                         * (1 = the full-resolution upsample launch, 2 = L2 -> L1, 3 = the coarse blend launch, 4 = render);
-                                        * shape 0..3 = loads in flight per lane {16 + 120 VGPRs declared, 16, 8, 4}; + 100 * p: stream priority
-                                        * p = 0 lowest, 1 default, 2 highest; + 1000 * s + 10000 * b: only the first s tenths of the frames
-                                        * at `gate`, the rest at gate b (default 1).  Results identical. */
+                                        * shape 0..4 = loads in flight per lane {16 + 120 VGPRs declared, 16, 8, 4, 8 + 120 VGPRs declared};
+                                        * + 100 * p: stream priority p = 0 lowest, 1 default, 2 highest; + 1000 * s + 10000 * b: only the
+                                        * first s tenths of the frames at `gate`, the rest at gate b (default 1).  Results identical. */
+    MEAO_DEBUG_RENDER_FROM_DEPTH = 8,  /* calls that run their own downsample pass (no meao_prefetch_batch), f32 depth, 36 samples: the render
+                                        * launch fills its windows from the RAW depth frame and does not wait for the downsample pass.
+                                        * 0 = never; 1 = always, both in ONE launch (the pass as extra workgroups behind the render ones);
+                                        * 2 = always, as two launches on two streams of the context joined in front of the blend launch;
+                                        * 3 (default) = form 1 for calls of at most RENDER_FROM_DEPTH_MAX_TILES render tiles */
+    MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES = 9   /* frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190); default 1024 */
 } meao_debug_key;
 MEAO_API int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value);
 

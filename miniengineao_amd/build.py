@@ -18,8 +18,16 @@ _INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmeao_hip.so")
 
-SOURCES = ["meao_plan.cpp", "meao_api.cpp", "meao_pool.cpp", "meao_kernels.hip"]
-HEADERS = ["meao_plan.hpp", "meao_kernels.hpp"]
+# The kernels are six translation units over shared device headers (meao_dev*.hpp): they compile in parallel and a
+# change to one family rebuilds one unit.  csrc/meao_kernels.hip is the same code as ONE unit (it includes the six):
+# variants that need device globals (`clocks`) and the ISA tools build that.
+KERNEL_UNITS = ["meao_k_downsample.hip", "meao_k_render.hip", "meao_k_render_depth.hip", "meao_k_upsample.hip",
+                "meao_k_upsample_nested.hip", "meao_k_upsample_fused.hip", "meao_k_misc.hip"]
+HOST_UNITS = ["meao_plan.cpp", "meao_api.cpp", "meao_pool.cpp"]
+SOURCES = HOST_UNITS + KERNEL_UNITS
+HEADERS = ["meao_plan.hpp", "meao_kernels.hpp", "meao_dev.hpp", "meao_dev_downsample.hpp", "meao_dev_render.hpp",
+           "meao_dev_upsample.hpp", "meao_dev_blend.hpp", "meao_dev_composite.hpp", "meao_kernels.hip"]
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit mad()/fma2() calls, which
 # is what makes the kernels bit-exact against the oracle.  Correctly rounded '/' and sqrt are
@@ -50,31 +58,67 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > built for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str = None) -> str:
-    """out_path + extra_flags (-DMEAO_...) build a kernel variant next to the product library (A/B runs)."""
-    if out_path is None and not force and not _stale():
-        return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra_flags, f"-I{_INCLUDE}"]
-    cmd += [os.path.join(_CSRC, s) for s in SOURCES]
-    final = out_path or LIB_PATH
-    tmp = final + ".tmp"
-    cmd += ["-o", tmp]
+def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{' '.join(cmd)}\n{proc.stdout}\n{proc.stderr}")
     if verbose and proc.stderr.strip():
         print(proc.stderr)
+
+
+def _unit_stale(src: str, obj: str) -> bool:
+    """An object is rebuilt when its source, any csrc header, meao.h or this file is newer (headers are few and shared)."""
+    if not os.path.exists(obj):
+        return True
+    built = os.path.getmtime(obj)
+    deps = [src, os.path.join(_INCLUDE, "meao.h"), os.path.abspath(__file__)]
+    deps += [os.path.join(_CSRC, h) for h in HEADERS if h.endswith(".hpp")]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str = None, unity: bool = False,
+              jobs: int = None) -> str:
+    """Compiles every unit to an object (in parallel, only the stale ones unless force) and links libmeao_hip.so.
+    out_path + extra_flags (-DMEAO_...) build a kernel variant next to the product library (A/B runs); unity=True
+    compiles the kernels as the single translation unit csrc/meao_kernels.hip."""
+    from concurrent.futures import ThreadPoolExecutor
+    if out_path is None and not force and not _stale():
+        return LIB_PATH
+    final = out_path or LIB_PATH
+    tag = "product" if out_path is None else os.path.splitext(os.path.basename(out_path))[0]
+    obj_dir = os.path.join(OBJ_DIR, tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(final), exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"] + list(extra_flags) + [f"-I{_INCLUDE}"]
+    units = HOST_UNITS + (["meao_kernels.hip"] if unity else KERNEL_UNITS)
+    flags_stamp = os.path.join(obj_dir, ".flags")
+    stamp = " ".join(compile_flags + units)
+    same_flags = os.path.exists(flags_stamp) and open(flags_stamp).read() == stamp
+    todo, objs = [], []
+    for u in units:
+        src, obj = os.path.join(_CSRC, u), os.path.join(obj_dir, u + ".o")
+        objs.append(obj)
+        if force or not same_flags or _unit_stale(src, obj):
+            todo.append([hipcc(), *compile_flags, "-c", src, "-o", obj])
+    jobs = jobs or max(1, min(len(todo), os.cpu_count() or 1))
+    if todo:
+        with ThreadPoolExecutor(jobs) as ex:
+            list(ex.map(lambda c: _run(c, verbose), todo))
+    open(flags_stamp, "w").write(stamp)
+    tmp = final + ".tmp"
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", *objs, "-o", tmp], verbose)
     os.replace(tmp, final)
     return final
 
 
 # Experimental arms of meao_kernels.hip (MEAO_X_* switches) that are kept in the source: name -> -D flags
+UNITY_VARIANTS = ("clocks",)                        # device globals shared by all kernels: one translation unit
 VARIANTS = {
     "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],          # diagnostic: phase stamps, render residency log
     "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],         # every UNORM8 bilateral result through the exact-division sequences (cross-check of the estimate)
+    "testhooks": ["-DMEAO_TESTING=1"],              # the product + meao_test_fail_next_allocs (fault injection for the resize tests; not in the product ABI)
     "nowt": ["-DMEAO_X_BIL_WHOLE_TILE=0"],          # without the unmasked copy of the bilateral phase (the round-3 form of the upsample tile)
 }
 
@@ -96,7 +140,7 @@ def build_variants(names=None, strict=False):
     def one(nf):
         path = os.path.join(out_dir, f"libmeao_{nf[0]}.so")
         try:
-            return build_lib(force=True, extra_flags=nf[1], out_path=path)
+            return build_lib(force=True, extra_flags=nf[1], out_path=path, unity=nf[0] in UNITY_VARIANTS, jobs=2)
         except RuntimeError as e:
             if strict:
                 raise

@@ -18,6 +18,10 @@ using namespace meao;
 
 namespace {
 
+#ifndef MEAO_TESTING
+#define MEAO_TESTING 0      // 1: the `testhooks` variant library -- exports meao_test_* fault injection, never the product
+#endif
+
 thread_local std::string g_last_error;   // for failures that have no context (meao_create)
 
 constexpr uint64_t kAlign = 256;
@@ -76,6 +80,14 @@ struct meao_ctx {
     int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
     int nested_max_tiles = 1024;       // calls with at most this many L2->L1 tiles (frames x tiles; one 4K frame: 1020) run the three blend passes as one launch
                                        // (with the round-4 blend_window_into_lds: 55.9 vs 56.6 us per pipelined 4K frame, a tie unpipelined; 512 before)
+    // Calls with few tiles (one frame per call, AmbientOcclusion.cs:329-347): render fills its windows from the RAW depth frame
+    // (meao_k_render_depth.hip) and no longer depends on the downsample pass.  0 = never; 1 = one launch for both (the pass as
+    // extra workgroups of the render launch); 2 = two launches on two streams, joined in front of the first blend launch (A/B arm);
+    // 3 = form 1 for calls of at most render_from_depth_max_tiles render tiles (default).  f32 depth, 36-sample set.
+    int render_from_depth = 3;
+    int render_from_depth_max_tiles = 1024;      // frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190)
+    hipStream_t rfd_stream = nullptr;            // form 2
+    hipEvent_t rfd_fork = nullptr, rfd_join = nullptr;
     int ds_share_in_blend = 0;         // percent of the carried (next batch's) downsample tiles that ride in the L2->L1 blend launch instead of the last kernel
     // MEAO_DEBUG_DS_SIDE_STREAM (0 = off): the announced next batch's downsample pass as its OWN kernel on a second,
     // low-priority stream of the context, gated behind a point of this call's launch sequence, instead of riding inside
@@ -92,7 +104,9 @@ struct meao_ctx {
     CompositeBatchArgs pending_comp{};
     hipStream_t pending_stream = nullptr;
 
-    int debug_fail_allocs = 0;         // meao_debug_set(MEAO_DEBUG_FAIL_NEXT_ALLOCS): arena allocations still to fail (tests)
+#if MEAO_TESTING
+    int debug_fail_allocs = 0;         // meao_test_fail_next_allocs: arena allocations still to fail (testhooks variant only)
+#endif
 
     const void *last_out[MEAO_MAX_BATCH] = {};   // device address of the last results (debug id 17)
     int last_frames = 0;
@@ -266,10 +280,13 @@ int reallocate(meao_ctx *ctx, const meao_config &cfg, bool two_ds_sets)
     const SlotLayout lay = layout_slot(plan, cfg, two_ds_sets);
     char *fresh = nullptr;
     hipError_t e;
-    if (ctx->debug_fail_allocs > 0) {      // fault injection (meao_debug_set, tests only)
+#if MEAO_TESTING
+    if (ctx->debug_fail_allocs > 0) {      // fault injection: exists only in the `testhooks` variant library (-DMEAO_TESTING=1)
         --ctx->debug_fail_allocs;
         e = hipErrorOutOfMemory;
-    } else {
+    } else
+#endif
+    {
         e = hipMalloc(reinterpret_cast<void **>(&fresh), lay.slot_bytes * cfg.max_batch);
     }
     if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc (intermediates)");
@@ -406,6 +423,18 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
                             std::memcmp(ctx->ready_depth, depth_dev, sizeof(void *) * n) == 0;
     ctx->ds_cur = prefetched ? ctx->ready_set : 0;
     ctx->ready_n = 0;
+    // Render straight from the raw depth (ctx->render_from_depth): 0 = no, 1 = render + downsample in one launch, 2 = two streams
+    int from_depth = 0;
+    if (!prefetched && ctx->render_from_depth != 0 && c.depth_format == MEAO_DEPTH_F32 && c.sample_set == MEAO_SAMPLES_CHECKER &&
+        ctx->pending_comp.frames == 0) {
+        int tiles32 = 0;
+        for (int l = 1; l <= c.num_levels; ++l)
+            tiles32 += ((p.mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p.mip[l].h + kRenTileH - 1) / kRenTileH);
+        if (ctx->render_from_depth == 3) from_depth = n * tiles32 <= ctx->render_from_depth_max_tiles ? 1 : 0;
+        else from_depth = ctx->render_from_depth;
+        if (from_depth == 2 && capturing) from_depth = 1;          // a captured sequence stays on one stream
+    }
+    DownsampleArgs own_ds{};
     if (!prefetched) {
         TraceRange tr(ctx, "meao:downsample");
         ctx->set_gen[ctx->ds_cur] = next_generation();
@@ -414,9 +443,21 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         // hostile frame would keep every later replay on the IEEE-division bodies.  Direct launches take a
         // fresh generation per downsample and need no clearing.
         if (capturing) MEAO_HIP(ctx, hipMemsetAsync(ctx->hostile_of(ctx->ds_cur), 0, sizeof(uint32_t) * n, stream));
-        MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, stream));
-        MEAO_HIP(ctx, launch_downsample(downsample_args(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur], true), n, stream));
-        MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, stream));
+        own_ds = downsample_args(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur], true);
+        if (from_depth == 2) {      // the render launch goes to the second stream first; both read only the caller's depth
+            if (!ctx->rfd_stream) {
+                MEAO_HIP(ctx, hipStreamCreateWithFlags(&ctx->rfd_stream, hipStreamNonBlocking));
+                MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->rfd_fork, hipEventDisableTiming));
+                MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->rfd_join, hipEventDisableTiming));
+            }
+            MEAO_HIP(ctx, hipEventRecord(ctx->rfd_fork, stream));      // behind the previous call's readers of the Occlusion buffers
+            MEAO_HIP(ctx, hipStreamWaitEvent(ctx->rfd_stream, ctx->rfd_fork, 0));
+        }
+        if (from_depth != 1) {
+            MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, stream));
+            MEAO_HIP(ctx, launch_downsample(own_ds, n, stream));
+            MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, stream));
+        }
     }
     const uint32_t *hostile = ctx->hostile_of(ctx->ds_cur);
     const uint32_t generation = ctx->set_gen[ctx->ds_cur];
@@ -583,7 +624,19 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         if (rc != MEAO_OK) return rc;
     }
     { const int rc = side_downsample_at(4); if (rc != MEAO_OK) return rc; }
-    {
+    if (from_depth != 0) {
+        // one frame per call: windows from the raw depth; form 1 carries the downsample pass as extra workgroups, form 2 runs on
+        // the second stream next to the pass and is joined here, in front of the first reader of both
+        TraceRange tr(ctx, from_depth == 1 ? "meao:render_from_depth+downsample" : "meao:render_from_depth(second stream)");
+        hipStream_t rs = from_depth == 2 ? ctx->rfd_stream : stream;
+        MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, rs));
+        MEAO_HIP(ctx, launch_render_from_depth(render_args(1, c.num_levels, false, true), own_ds, from_depth == 1, c.ao_format, n, rs));
+        MEAO_HIP(ctx, end(MEAO_PASS_RENDER, rs));
+        if (from_depth == 2) {
+            MEAO_HIP(ctx, hipEventRecord(ctx->rfd_join, rs));
+            MEAO_HIP(ctx, hipStreamWaitEvent(stream, ctx->rfd_join, 0));
+        }
+    } else {
         TraceRange tr(ctx, ctx->pending_comp.frames > 0 ? "meao:render+composite_of_previous_call" : "meao:render");
         MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
         if (ctx->pending_comp.frames > 0) {
@@ -920,6 +973,9 @@ int32_t meao_destroy(meao_ctx *ctx)
     if (ctx->side_gate) (void)hipEventDestroy(ctx->side_gate);
     if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->rfd_fork) (void)hipEventDestroy(ctx->rfd_fork);
+    if (ctx->rfd_join) (void)hipEventDestroy(ctx->rfd_join);
+    if (ctx->rfd_stream) (void)hipStreamDestroy(ctx->rfd_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     if (prev_device >= 0) (void)hipSetDevice(prev_device);
@@ -1340,7 +1396,11 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_RENDER_SMALL_MAX_TILES: ctx->render_small_max_tiles = value; break;
     case MEAO_DEBUG_FINAL_SMALL_MAX_TILES: ctx->final_small_max_tiles = value; break;
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
-    case MEAO_DEBUG_FAIL_NEXT_ALLOCS: ctx->debug_fail_allocs = value < 0 ? 0 : value; break;
+    case MEAO_DEBUG_RENDER_FROM_DEPTH:
+        if (value < 0 || value > 3) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: RENDER_FROM_DEPTH is 0..3");
+        ctx->render_from_depth = value;
+        break;
+    case MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES: ctx->render_from_depth_max_tiles = value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
         if (value < 0 || value % 10 > 4 || (value > 0 && value % 10 == 0) || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
@@ -1366,6 +1426,18 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     }
     return MEAO_OK;
 }
+
+#if MEAO_TESTING
+// Fault injection for the resize / first-announcement error paths (tests/test_gpu_more.py): the next n allocations of
+// intermediates fail with MEAO_ERR_OUT_OF_MEMORY.  Not declared in include/meao.h and not compiled into libmeao_hip.so:
+// only the `testhooks` variant library (miniengineao_amd/build.py VARIANTS, -DMEAO_TESTING=1) exports it.
+__attribute__((visibility("default"))) int32_t meao_test_fail_next_allocs(meao_ctx *ctx, int32_t n)
+{
+    if (!ctx) return MEAO_ERR_INVALID_ARGUMENT;
+    ctx->debug_fail_allocs = n < 0 ? 0 : n;
+    return MEAO_OK;
+}
+#endif
 
 int32_t meao_selftest(meao_ctx *ctx, int32_t which, uint64_t *out_mismatches)
 {

@@ -1,0 +1,737 @@
+// meao_dev_upsample.hpp -- the upsample tile (Upsample.main / main_blendout [/ main_premin*]): blur runs, bilateral forms, window loads, upsample_tile.
+#pragma once
+
+#include "meao_dev.hpp"
+
+namespace meao {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Upsample: depth-aware 5-tap separable blur of the low-res AO + bilateral 2x upsample.
+
+template <int TILE_H>
+struct UpsTile {
+    static constexpr int kLowW = kUpsTileW / 2, kLowH = TILE_H / 2;   // low-res texels under the tile: 32 x 16|32
+    static constexpr int kRawW = kLowW + 6, kRawH = kLowH + 6;       // raw taps: 38 x 22|38
+    static constexpr int kRawPitch = 40;
+    static constexpr int kBlurW = kLowW + 2, kBlurH = kLowH + 2;     // blurred texels: 34 x 18|34
+    static constexpr int kBlurPitch = 36;
+    // Run lengths are chosen so that each blur phase is ONE round over the 256 lanes (the phases are
+    // latency-bound: a second, partly filled round costs a full LDS round trip): 64-row tiles use
+    // 6 x 38 = 228 horizontal runs of 6 and 7 x 34 = 238 vertical runs of 5 (runs of 4 / 4: 342 and 306
+    // items, two rounds each); 32-row tiles 9 x 22 = 198 runs of 4 and 6 x 34 = 204 runs of 3.
+    static constexpr bool kLong = TILE_H == 64;          // A/B: -2.2 % on the full-resolution pass (220 -> 215 us per 16 frames)
+    static constexpr int kHRun = kLong ? 6 : 4, kHSegs = (kBlurW + kHRun - 1) / kHRun;
+    static constexpr int kVRun = kLong ? 5 : ((kBlurH % 3 == 0) ? 3 : 4);
+    static constexpr int kVSegs = (kBlurH + kVRun - 1) / kVRun;
+    // V-blur runs of the last segment may read (and produce) rows past the window: allocate them
+    static constexpr int kVRows = kVSegs * kVRun;                                 // rows of s_vb
+    static constexpr int kRawRows = (kVRows + 4 > kRawH) ? kVRows + 4 : kRawH;    // rows of s_ao / s_inv / s_hb
+    static_assert(kUpsTileW == 64 && TILE_H % 32 == 0, "bilateral phase: 16 x 16 lanes of 4 x 2 texels per pass");
+    static_assert(kHSegs * kHRun + 4 <= kRawPitch, "H-blur runs may read into the row padding only");
+    static_assert(kVRows * kBlurPitch <= kRawRows * kRawPitch, "s_vb aliases s_ao");
+};
+
+struct BlurConsts { float step_size, blur_tolerance; };
+
+// A run of N consecutive outputs of BlurHorizontally / BlurVertically (UPS:89-170) from N+4 AO
+// taps a[] and inverse depths z[]: output n is centred on tap n+2.  Deltas, squared lengths and
+// CompareDeltas results are shared between neighbouring outputs exactly as the reference
+// shares them between the 3 (2) outputs of one lane; every output only depends on its own
+// 5-tap window.  CompareDeltas UPS:83-87, SmartBlur UPS:74-81.
+template <int N>
+__device__ __forceinline__ void blur_run(const BlurConsts &k, const float (&a)[N + 4], const float (&z)[N + 4],
+                                         float (&out)[N])
+{
+    float dz[N + 3], ln[N + 3];
+    bool keep[N + 2];
+#pragma unroll
+    for (int i = 0; i < N + 3; ++i) {
+        dz[i] = z[i + 1] - z[i];
+        ln[i] = mad(dz[i], dz[i], k.step_size);
+    }
+#pragma unroll
+    for (int i = 0; i < N + 2; ++i) {
+        const float t = mad(dz[i], dz[i + 1], k.step_size);
+        keep[i] = t * t > (ln[i] * ln[i + 1]) * k.blur_tolerance;
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const bool left = keep[n], middle = keep[n + 1], right = keep[n + 2];
+        const float pc = a[n + 2];
+        const float pb = (left | middle) ? a[n + 1] : pc;
+        const float pa = left ? a[n] : pb;
+        const float pd = (right | middle) ? a[n + 3] : pc;
+        const float pe = right ? a[n + 4] : pd;
+        // (pa + pe) * 0.5 is exact (power of two, operands are AO values far from underflow), so
+        // fusing it into the following add rounds exactly like the reference's mul-then-add
+        out[n] = ((mad(pa + pe, 0.5f, pb) + pc) + pd) * 0.25f;
+    }
+}
+
+// BilateralUpsample (UPS:177-183); taps already in weight order 9,3,1,3.
+// The uniform operands of the bilateral phase (SGPRs / literals; pinning them in VGPRs changed nothing here:
+// this phase waits on latency, not on VALU issue, profiles/r02_ab_v14*_ups_vgpr_consts.jsonl).
+struct BilateralConsts {
+    float tolerance, noise, three, nine;
+    __device__ __forceinline__ BilateralConsts(float upsample_tolerance, float noise_filter_strength)
+        : tolerance(upsample_tolerance), noise(noise_filter_strength), three(3.0f), nine(9.0f) {}
+};
+
+template <int DIV>
+__device__ __forceinline__ float bilateral_upsample(float hi_depth, float hi_ao, float d0, float d1, float d2,
+                                                    float d3, float a0, float a1, float a2, float a3,
+                                                    const BilateralConsts &k)
+{
+    const float tolerance = k.tolerance, noise = k.noise;
+    const float w0 = div_const<DIV, 9>(__builtin_fabsf(hi_depth - d0) + tolerance, k.nine);
+    const float w1 = div_const<DIV, 3>(__builtin_fabsf(hi_depth - d1) + tolerance, k.three);
+    const float w2 = div_const<DIV, 1>(__builtin_fabsf(hi_depth - d2) + tolerance);
+    const float w3 = div_const<DIV, 3>(__builtin_fabsf(hi_depth - d3) + tolerance, k.three);
+    float total = ((w0 + w1) + w2) + w3;
+    total = total + noise;
+    float sum = a0 * w0;
+    sum = mad(a1, w1, sum);
+    sum = mad(a2, w2, sum);
+    sum = mad(a3, w3, sum);
+    sum = sum + noise;
+    return div_strict<DIV>(hi_ao * sum, total);
+}
+
+// BilateralUpsample for N texels at once with the 4N weight reciprocals issued back to back (and then the N
+// reciprocals of the final quotients): same operations per texel, in the same order, as bilateral_upsample<DIV_EXACT_RCP>.
+template <int N>
+__device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_depth)[N], const float (&hi_ao)[N], const float (&d)[N][4],
+                                                           const float (&a)[N][4], const BilateralConsts &k, float (&out)[N])
+{
+    float x[N][4], r[N][4], w[N][4];
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[t][i] = __builtin_fabsf(hi_depth[t] - d[t][i]) + k.tolerance;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_rcp_f32 %0, %1" : "=v"(r[t][i]) : "v"(x[t][i]));
+    __builtin_amdgcn_sched_barrier(0);
+    float total[N], sum[N], rr[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i == 2) {                                              // 1 / x: one Newton step (rcp_strict)
+                const float e = mad(-x[t][i], r[t][i], 1.0f);
+                w[t][i] = mad(e, r[t][i], r[t][i]);
+            } else {                                                   // {9, 3} / x (div_const)
+                const float kv = i == 0 ? k.nine : k.three;
+                const float q = kv * r[t][i];
+                const float e = mad(-x[t][i], q, kv);
+                w[t][i] = mad(e, r[t][i], q);
+            }
+        }
+        total[t] = (((w[t][0] + w[t][1]) + w[t][2]) + w[t][3]) + k.noise;
+        float sm = a[t][0] * w[t][0];
+        sm = mad(a[t][1], w[t][1], sm);
+        sm = mad(a[t][2], w[t][2], sm);
+        sm = mad(a[t][3], w[t][3], sm);
+        sum[t] = hi_ao[t] * (sm + k.noise);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < N; ++t) asm volatile("v_rcp_f32 %0, %1" : "=v"(rr[t]) : "v"(total[t]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < N; ++t) {                                      // div_strict(sum, total)
+        const float e0 = mad(-total[t], rr[t], 1.0f);
+        const float rc = mad(e0, rr[t], rr[t]);
+        const float q = sum[t] * rc;
+        const float e = mad(-total[t], q, sum[t]);
+        out[t] = mad(e, rc, q);
+    }
+}
+
+// BilateralUpsample's result as the UNORM8 code the pass stores, for DIV_EXACT_RCP operands (a frame without hostile depth:
+// every operand finite, weights and AO values >= 0, hi_ao <= 1).
+//
+// The code is floor(RN(RN(sat(q) * 255) + 0.5)) for the q of the correctly rounded chain (bilateral_upsample).  An estimate q~
+// from the same operations with every division replaced by dividend * v_rcp_f32 differs from q by at most 35 u relatively
+// (u = 2^-24):
+//   v_rcp_f32 is within one ulp of the correctly rounded reciprocal (meao_selftest(4): every binary32 in range), i.e. within
+//             1.5 ulp = 3u of the true one;
+//   weights   RN(K * rcp(x)) against RN(K / x): 3u + u (the product) + u (the quotient's rounding) = 5u;
+//   the sums  have non-negative terms only, so they inherit the largest relative error of a term plus one u per rounding in
+//             either chain: total 5u + 2 * 4u = 13u, weighted sum (times hi_ao) 5u + 2 * 6u = 17u;
+//   quotient  u (RN) + 4u (rcp + product) on top: 13u + 17u + 5u = 35u = 1.1 * 2^-19.
+// The weighted average times hi_ao is at most 1 (+ rounding), so the estimate is off by < 5.4e-4 of a code; the reference's
+// two roundings in the conversion and the fused one of the estimate add < 2.3e-5.  If v~ = fma(sat(q~), 255, 0.5) is further
+// than kR8Margin = 2^-10 (1.7 x that bound) from an integer, floor(v~) IS the reference's code.  Otherwise -- 2^-9 of the texels
+// of a noisy frame, none where the AO is flat (q~ = 1 -> v~ = 255.5) -- the lane runs the exact sequence.  The agreement of
+// estimate and exact code is also checked on the running device for 2^32 hashed operand sets (meao_selftest(7)) and, with
+// adversarial 1-ulp reciprocal errors, in numpy by tests/test_r8_estimate_bound.py.
+// GROUPED: the four weight reciprocals back to back, as in bilateral_upsample_grouped.
+// REUSE: the exact path starts from the estimate's x and 1 / x (14 instructions fewer on that path, 5 - 8 VGPRs more live across
+// the branch); without it the whole exact sequence is run again from an opaque copy of the depth, so that nothing of the estimate
+// has to stay in registers for the rare path (the nested kernels have none to spare).
+constexpr float kR8Margin = 0x1p-10f;     // (1.25 * 2^-11, still above the bound, measured the same: profiles/r04_ab_r8_margin.jsonl)
+
+// (v_cvt_pk_u8_f32, which would convert and pack in one instruction, does not truncate like v_cvt_u32_f32: tried in round 4.)
+template <bool GROUPED, bool REUSE = false>
+__device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float hi_ao, const float (&d)[4], const float (&a)[4],
+                                                          const BilateralConsts &k)
+{
+    float x[4], r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = __builtin_fabsf(hi_depth - d[i]) + k.tolerance;
+    if constexpr (GROUPED) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_rcp_f32 %0, %1" : "=v"(r[i]) : "v"(x[i]));
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(x[i]);
+    }
+    const float w0 = k.nine * r[0], w1 = k.three * r[1], w2 = r[2], w3 = k.three * r[3];
+    const float total = (((w0 + w1) + w2) + w3) + k.noise;
+    float sm = a[0] * w0;
+    sm = mad(a[1], w1, sm);
+    sm = mad(a[2], w2, sm);
+    sm = mad(a[3], w3, sm);
+    const float q = (hi_ao * (sm + k.noise)) * __builtin_amdgcn_rcpf(total);
+    const float v = mad(sat(q), 255.0f, 0.5f + kR8Margin);          // v~ + margin: its floor is the code unless its fraction is < 2 margins
+    uint32_t code = static_cast<uint32_t>(v);
+    const bool near_boundary = __builtin_amdgcn_fractf(v) < 2.0f * kR8Margin;
+    if (__builtin_expect(near_boundary, 0)) {
+        if constexpr (REUSE) {
+            float w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i == 2) {                                              // rcp_strict
+                    const float e = mad(-x[i], r[i], 1.0f);
+                    w[i] = mad(e, r[i], r[i]);
+                } else {                                                   // div_const<9 | 3>
+                    const float kv = i == 0 ? k.nine : k.three;
+                    const float qw = kv * r[i];
+                    const float e = mad(-x[i], qw, kv);
+                    w[i] = mad(e, r[i], qw);
+                }
+            }
+            const float exact_total = (((w[0] + w[1]) + w[2]) + w[3]) + k.noise;
+            float s = a[0] * w[0];
+            s = mad(a[1], w[1], s);
+            s = mad(a[2], w[2], s);
+            s = mad(a[3], w[3], s);
+            code = f32_to_unorm8(div_strict<DIV_EXACT_RCP>(hi_ao * (s + k.noise), exact_total));
+        } else {
+            float hd = hi_depth;
+            asm volatile("" : "+v"(hd));
+            code = f32_to_unorm8(bilateral_upsample<DIV_EXACT_RCP>(hd, hi_ao, d[0], d[1], d[2], d[3], a[0], a[1], a[2], a[3], k));
+        }
+    }
+    return code;
+}
+
+// One tile of Upsample.main (FINAL) / main_blendout; every thread of the workgroup must call it
+// (barriers inside; lanes outside the image leave after the last one).
+// (Eight workgroups per CU were measured in round 4: the LoResDB window kept in the registers its loads filled and written behind
+// the V-blur into the array the H-blurred values had vacated -- 17.6 KB, 57 VGPRs, one barrier more, bit-exact -- runs at 176.0 us
+// against 176.1 us: the same busy cycles, 10 % more wave-cycles, 17 % more waiting.  The pass is bound by the issue rate of its
+// instruction mix, not by the number of waves that hide latency: profiles/r04_ab_final_late_depth_8_workgroups.txt.)
+template <bool FINAL, int TILE_H = ups_tile_h(FINAL)>
+struct UpsLds {
+    typedef UpsTile<TILE_H> T;
+    static constexpr int kDep0 = FINAL ? 2 : 0;                                   // first row / column kept
+    static constexpr int kDepH = FINAL ? T::kLowH + 4 : T::kRawH, kDepW = FINAL ? T::kLowW + 4 : T::kRawW;
+    static constexpr int kDepPitch = FINAL ? 36 : T::kRawPitch;
+    static constexpr int kInvN = T::kRawH * T::kRawPitch, kHbN = T::kRawH * T::kBlurPitch, kDepN = kDepH * kDepPitch;
+    static constexpr int kAoN = T::kRawH * T::kRawPitch;
+    static constexpr int kFloats = kInvN + kHbN + kDepN + kAoN;
+};
+
+// The global loads of an interior tile (no horizontal clamping, 16-byte loads everywhere, no second AO input): its low-res
+// window as 16-byte row quads [LX0 - 4 + 4k, +4) -- depth and AO -- and the hi-res operands of the bilateral phase
+// (f16 depth in the full-resolution pass, f32 depth + AO in the blend passes).  Issued at the top of the tile.
+template <int AOFMT, bool FINAL, int TILE_H>
+struct UpsLoads {
+    typedef AoTexel<AOFMT> AO;
+    static constexpr int kItems = 10 * UpsTile<TILE_H>::kRawH, kRounds = (kItems + kThreads - 1) / kThreads, kPasses = TILE_H / 32;
+    float4v wd[kRounds];
+    typename AO::type4 wa[kRounds];
+    ushort4v hd16[kPasses][2];
+    float4v hd32[kPasses][2];
+    // four AO texels as ONE integer: a <4 x i8> value is split into bytes where it is loaded, which puts the wait for it there
+    typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type ao_bits_t;
+    ao_bits_t ha[kPasses][2];
+};
+
+template <bool FINAL, int TILE_H>
+__device__ __forceinline__ bool ups_tile_is_interior(const UpsampleArgs &a, int tile)
+{
+    const int LX0 = ((tile % a.tiles_x) * kUpsTileW) >> 1;
+    return a.vec_ok != 0 && !a.lo_ao2 && (a.lw & 3) == 0 && LX0 >= 4 && LX0 + 35 < a.lw;
+}
+
+// Hi-res operands.  CLAMPED: every lane loads (out-of-frame lanes re-read the frame's last row / quad and never use it),
+// so that the code is branch-free and the compiler's s_waitcnt counts stay exact.
+template <int AOFMT, bool FINAL, int TILE_H, bool CLAMPED>
+__device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
+{
+    const int tid = thread_index_opaque();
+    typedef AoTexel<AOFMT> AO;
+    typedef typename AO::type ao_t;
+    const int HX0 = (tile % a.tiles_x) * kUpsTileW, HY0 = (tile / a.tiles_x) * TILE_H;
+    const int hw = a.hw, hh = a.hh;
+    const int htx = tid & 15;
+    const int hhx0 = CLAMPED ? min(HX0 + 4 * htx, hw - 4) : HX0 + 4 * htx;
+#pragma unroll
+    for (int pass = 0; pass < TILE_H / 32; ++pass)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int hy_raw = HY0 + 2 * ((tid >> 4) + 16 * pass) + f;
+            const int hy = CLAMPED ? min(hy_raw, hh - 1) : hy_raw;
+            if (CLAMPED || (hhx0 < hw && hy < hh)) {
+                // texel index in the level (< 2^27): 32-bit byte offsets from the frame's uniform bases (saddr addressing)
+                const uint32_t hrow = static_cast<uint32_t>(hy * hw + hhx0);
+                if constexpr (FINAL) {
+                    L.hd16[pass][f] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(at_byte_offset(
+                        frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame), hrow * 2u)));
+                } else {
+                    L.hd32[pass][f] = *reinterpret_cast<const float4v *>(at_byte_offset(
+                        frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame), hrow * 4u));
+                    L.ha[pass][f] = *reinterpret_cast<const typename UpsLoads<AOFMT, FINAL, TILE_H>::ao_bits_t *>(at_byte_offset(
+                        frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame), hrow * static_cast<uint32_t>(sizeof(ao_t))));
+                }
+            }
+        }
+}
+
+// All loads of an interior tile: window first, hi-res operands behind them.  The window comes from L2 (written by the
+// previous pass), the hi-res operands of the final pass from HBM; vmcnt retires loads in issue order, so with the hi-res
+// loads in front the window wait would last an HBM latency.
+template <int AOFMT, bool FINAL, int TILE_H>
+__device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
+{
+    const int tid = thread_index_opaque();
+    typedef UpsLoads<AOFMT, FINAL, TILE_H> Loads;
+    typedef typename Loads::AO AO;
+    typedef typename AO::type ao_t;
+    const int LX0 = ((tile % a.tiles_x) * kUpsTileW) >> 1, LY0 = ((tile / a.tiles_x) * TILE_H) >> 1;
+    const int lw = a.lw, lh = a.lh;
+    const float *__restrict__ lo_depth = frame_ptr(a.lo_depth, a.frame_stride, frame);
+    const ao_t *__restrict__ lo_ao = frame_ptr(static_cast<const ao_t *>(a.lo_ao), a.frame_stride, frame);
+#pragma unroll
+    for (int round = 0; round < Loads::kRounds; ++round) {
+        const int i = min(tid + round * kThreads, Loads::kItems - 1);
+        const int r = i / 10, k = i % 10;
+        const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
+        const uint32_t idx = static_cast<uint32_t>(cy * lw + (LX0 - 4 + 4 * k));
+        L.wd[round] = *reinterpret_cast<const float4v *>(at_byte_offset(lo_depth, idx * 4u));
+        L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(lo_ao, idx * static_cast<uint32_t>(sizeof(ao_t))));
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
+    ups_issue_hoisted<AOFMT, FINAL, TILE_H, true>(a, tile, frame, L);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// NESTED: the LoResAO1 taps (s_ao) were already produced in LDS by blend_window_into_lds (the
+// previous pass of the chain evaluated inside this workgroup) instead of being read from global memory.
+// Places inside an upsample tile where every thread of the workgroup can put unrelated global loads in flight:
+// after_prefetch()   the tile's own low-res window is in LDS (its loads have landed); blur and bilateral follow
+// before_bilateral() the hoisted hi-res operands have landed too: nothing in the bilateral phase waits on vmcnt
+struct NoHook {
+    static constexpr bool kBeforeBilateral = false;
+    static constexpr bool kGroupReciprocals = true;      // bilateral_upsample_grouped
+    static constexpr bool kEstimateR8 = true;            // bilateral_upsample_r8
+    static constexpr bool kReuseEstimate = true;         // ... whose exact path starts from the estimate's reciprocals
+    __device__ __forceinline__ void after_prefetch() const {}
+    __device__ __forceinline__ void before_bilateral() const {}
+};
+
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
+__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
+{
+    const int tid = thread_index_opaque();
+    typedef AoTexel<AOFMT> AO;
+    typedef typename AO::type ao_t;
+    constexpr int kTileH = TILE_H;
+    typedef UpsTile<kTileH> T;
+    // One allocation, carved so that the scratch rows the last V-blur run reads past the raw window
+    // (rows kRawH .. kRawRows-1 of s_inv and s_hb; their products are never used) fall into the next
+    // array instead of being allocated.  In the full-resolution pass the LoResDB window is also cut to
+    // what the bilateral phase gathers (rows / columns 2 .. kLow+5): 22.3 KB per workgroup instead of
+    // 24.1 KB, which lets a seventh workgroup share the CU's 160 KB (with __launch_bounds__(.., 7):
+    // A/B on one box, 357 -> 343 us for the kernel that also carries the next downsample pass).
+    typedef UpsLds<FINAL, TILE_H> Lds;
+    constexpr int kDep0 = Lds::kDep0, kDepH = Lds::kDepH, kDepW = Lds::kDepW, kDepPitch = Lds::kDepPitch;
+    constexpr int kInvN = Lds::kInvN, kHbN = Lds::kHbN, kDepN = Lds::kDepN, kAoN = Lds::kAoN;
+    static_assert(kDepW <= kDepPitch && (T::kRawRows - T::kRawH) * T::kRawPitch <= kHbN &&
+                  (T::kRawRows - T::kRawH) * T::kBlurPitch <= kDepN + kAoN, "scratch rows stay inside the allocation");
+    static_assert(T::kVRows * T::kBlurPitch <= kAoN, "s_vb fits in s_ao");
+    static_assert(kInvN % 4 == 0 && kHbN % 4 == 0 && kDepN % 4 == 0, "16-byte alignment of the carved arrays");
+    float *const s_inv = smem;                       // 1 / LoResDB   (DepthCache)
+    float *const s_hb = s_inv + kInvN;               // after BlurHorizontally (AOCache2)
+    float *const s_dep = s_hb + kHbN;                // LoResDB       (LoDepths gather), window from (kDep0, kDep0)
+    float *const s_ao = s_dep + kDepN;               // LoResAO1 taps (AOCache1 before blur)
+    float *const s_vb = s_ao;                        // after BlurVertically (AOCache1): the raw taps are dead once H-blurred
+    auto dep_at = [&](int r, int c) __attribute__((always_inline)) -> float & { return s_dep[(r - kDep0) * kDepPitch + (c - kDep0)]; };
+    auto dep_kept = [&](int r, int c) __attribute__((always_inline)) { return !FINAL || (r >= kDep0 && r < kDep0 + kDepH && c >= kDep0 && c < kDep0 + kDepW); };
+
+    const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+    const int HX0 = tile_x * kUpsTileW, HY0 = tile_y * kTileH;
+    const int LX0 = HX0 >> 1, LY0 = HY0 >> 1;
+    const int lw = a.lw, lh = a.lh, hw = a.hw, hh = a.hh;
+    const float *__restrict__ lo_depth = frame_ptr(a.lo_depth, a.frame_stride, frame);
+    const ao_t *__restrict__ lo_ao = frame_ptr(static_cast<const ao_t *>(a.lo_ao), a.frame_stride, frame);
+    // main_premin*: LoResAO1 = min(LoResAO1, LoResAO2) (COMBINE_LOWER_RESOLUTIONS, UPS:58-60)
+    const ao_t *__restrict__ lo_ao2 = a.lo_ao2 ? frame_ptr(static_cast<const ao_t *>(a.lo_ao2), a.frame_stride, frame) : nullptr;
+    const BlurConsts bk = {a.step_size, a.blur_tolerance};
+    const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
+    // (fetched here, not where the bilateral phase first stores: a.dst[frame] is a scalar load whose latency would sit right
+    // behind the last barrier)
+    ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
+                                   : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
+    asm volatile("" : "+s"(dst));
+
+    PhaseClock clk(FINAL ? 0 : 8);
+    __builtin_amdgcn_s_setprio(3);
+    // The hi-res operands of the bilateral phase do not depend on anything computed here: their loads
+    // are issued first, so that their latency hides behind the prefetch and blur phases.
+    constexpr int kPasses = kTileH / 32;
+    typedef UpsLoads<AOFMT, FINAL, TILE_H> Loads;
+    Loads L;
+    auto &hoist_hd16 = L.hd16;
+    auto &hoist_hd32 = L.hd32;
+    auto &hoist_ha = L.ha;
+    const bool hoist_ok = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;
+    // interior tile, 16-byte loads everywhere, no second AO input: window loads first (ups_issue_interior_loads)
+    const bool window_first = !NESTED && (MEAO_X_HOT_PATH_ONLY || ups_tile_is_interior<FINAL, TILE_H>(a, tile));
+    if (hoist_ok && !window_first) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false>(a, tile, frame, L);
+
+    // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
+    // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
+    const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
+    if (window_first) {
+        constexpr int kItems = Loads::kItems, kRounds = Loads::kRounds;
+        if constexpr (!NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H>(a, tile, frame, L);
+        auto &wd = L.wd;
+        auto &wa = L.wa;
+#pragma unroll
+        for (int round = 0; round < kRounds; ++round) {
+            // an unconditional use: the compiler would otherwise sink the loads of the partial last round into
+            // its branch, behind the hi-res loads
+            asm volatile("" : : "v"(wd[round]));
+            if constexpr (!NESTED) {
+                typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type bits_t;
+                asm volatile("" : : "v"(__builtin_bit_cast(bits_t, wa[round])));
+            }
+            const int i = tid + round * kThreads;
+            // (storing the window as aligned 16-byte quads -- fourth column from the next lane by DPP -- removes the 4-way
+            // bank conflicts of these scalar stores and changes nothing: profiles/r02_ab_v23_aligned_fill.jsonl)
+            if (i < kItems) {
+                const int r = i / 10, k = i % 10;
+                const float dv[4] = {wd[round].x, wd[round].y, wd[round].z, wd[round].w};
+                float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (!NESTED) {
+                    av[0] = AO::decode(wa[round].x); av[1] = AO::decode(wa[round].y);
+                    av[2] = AO::decode(wa[round].z); av[3] = AO::decode(wa[round].w);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * k + e - 1;
+                    if (c >= 0 && c < T::kRawW) {
+                        if (dep_kept(r, c)) dep_at(r, c) = dv[e];
+                        s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
+                        if constexpr (!NESTED) s_ao[r * T::kRawPitch + c] = av[e];
+                    }
+                }
+            }
+        }
+    } else if (interior_x) {
+        // no horizontal clamping inside this tile: one aligned 16-byte depth load (+ 4 AO texels)
+        // per lane covers the 40-texel row segment [LX0-4, LX0+35]
+        for (int i = tid; i < 10 * T::kRawH; i += kThreads) {
+            const int r = i / 10, k = i % 10;
+            const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
+            const size_t idx = static_cast<size_t>(cy) * lw + (LX0 - 4 + 4 * k);
+            const float4v d4 = *reinterpret_cast<const float4v *>(lo_depth + idx);
+            const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+            float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (!NESTED) {
+                const typename AO::type4 a4 = *reinterpret_cast<const typename AO::type4 *>(lo_ao + idx);
+                av[0] = AO::decode(a4.x); av[1] = AO::decode(a4.y); av[2] = AO::decode(a4.z); av[3] = AO::decode(a4.w);
+            }
+            if (!NESTED && lo_ao2) {
+                const typename AO::type4 b4 = *reinterpret_cast<const typename AO::type4 *>(lo_ao2 + idx);
+                av[0] = __builtin_fminf(av[0], AO::decode(b4.x)); av[1] = __builtin_fminf(av[1], AO::decode(b4.y));
+                av[2] = __builtin_fminf(av[2], AO::decode(b4.z)); av[3] = __builtin_fminf(av[3], AO::decode(b4.w));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * k + e - 1;
+                if (c >= 0 && c < T::kRawW) {
+                    if (dep_kept(r, c)) dep_at(r, c) = dv[e];
+                    s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(dv[e]);     // UPS:67
+                    if constexpr (!NESTED) s_ao[r * T::kRawPitch + c] = av[e];
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < T::kRawW * T::kRawH; i += kThreads) {
+            const int r = i / T::kRawW, c = i % T::kRawW;
+            const int cy = clampi(LY0 - 3 + r, 0, lh - 1), cx = clampi(LX0 - 3 + c, 0, lw - 1);
+            const size_t idx = static_cast<size_t>(cy) * lw + cx;
+            const float d = lo_depth[idx];
+            if (dep_kept(r, c)) dep_at(r, c) = d;
+            s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(d);             // UPS:67
+            if constexpr (!NESTED) {
+                float av = AO::decode(lo_ao[idx]);
+                if (lo_ao2) av = __builtin_fminf(av, AO::decode(lo_ao2[idx]));
+                s_ao[r * T::kRawPitch + c] = av;
+            }
+        }
+    }
+    clk.mark(0);         // 0: window loaded, converted, stored to LDS
+    __syncthreads();
+    clk.mark(1);         // 1: barrier
+    __builtin_amdgcn_s_setprio(0);       // (3 kept through the blur phases: +10 % on the pass; rising through the phases: +2 %, r03)
+    hook.after_prefetch();
+
+    // ---- BlurHorizontally: runs of 4 outputs; output (r, c) is centred on raw column c+2.
+    // (Columns 34, 35 of the last run are scratch: they read the row padding.)
+    for (int i = tid; i < T::kHSegs * T::kRawH; i += kThreads) {
+        const int r = i / T::kHSegs, c0 = (i % T::kHSegs) * T::kHRun;
+        float av[T::kHRun + 4], zv[T::kHRun + 4], o[T::kHRun];
+        if constexpr (T::kHRun == 4) {
+            const float4v a0 = *reinterpret_cast<const float4v *>(&s_ao[r * T::kRawPitch + c0]);
+            const float4v a1 = *reinterpret_cast<const float4v *>(&s_ao[r * T::kRawPitch + c0 + 4]);
+            const float4v z0 = *reinterpret_cast<const float4v *>(&s_inv[r * T::kRawPitch + c0]);
+            const float4v z1 = *reinterpret_cast<const float4v *>(&s_inv[r * T::kRawPitch + c0 + 4]);
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            zv[0] = z0.x; zv[1] = z0.y; zv[2] = z0.z; zv[3] = z0.w; zv[4] = z1.x; zv[5] = z1.y; zv[6] = z1.z; zv[7] = z1.w;
+        } else {    // even run length: 8-byte aligned taps
+            static_assert(T::kHRun % 2 == 0, "runs start on even columns");
+#pragma unroll
+            for (int t = 0; t < T::kHRun + 4; t += 2) {
+                const float2v a2 = *reinterpret_cast<const float2v *>(&s_ao[r * T::kRawPitch + c0 + t]);
+                const float2v z2 = *reinterpret_cast<const float2v *>(&s_inv[r * T::kRawPitch + c0 + t]);
+                av[t] = a2.x; av[t + 1] = a2.y; zv[t] = z2.x; zv[t + 1] = z2.y;
+            }
+        }
+        blur_run<T::kHRun>(bk, av, zv, o);
+        if constexpr (T::kHRun == 4) {
+            *reinterpret_cast<float4v *>(&s_hb[r * T::kBlurPitch + c0]) = float4v{o[0], o[1], o[2], o[3]};
+        } else {
+#pragma unroll
+            for (int n = 0; n < T::kHRun; n += 2)
+                *reinterpret_cast<float2v *>(&s_hb[r * T::kBlurPitch + c0 + n]) = float2v{o[n], o[n + 1]};
+        }
+    }
+    clk.mark(2);         // 2: H-blur
+    __syncthreads();
+    clk.mark(3);         // 3: barrier
+
+    // ---- BlurVertically: runs of T::kVRun outputs; output (r, c) is centred on H-blurred row
+    // r+2; depths come from the same virtual column (DepthCache[... + 2], UPS:141-146).  Rows
+    // >= T::kBlurH of the last run are scratch: they read rows past the window (never used).
+    // s_vb aliases s_ao, which nothing reads after the barrier above.
+    for (int i = tid; i < T::kVSegs * T::kBlurW; i += kThreads) {
+        const int c = i % T::kBlurW, r0 = (i / T::kBlurW) * T::kVRun;
+        float av[T::kVRun + 4], zv[T::kVRun + 4], o[T::kVRun];
+#pragma unroll
+        for (int t = 0; t < T::kVRun + 4; ++t) {
+            av[t] = s_hb[(r0 + t) * T::kBlurPitch + c];
+            zv[t] = s_inv[(r0 + t) * T::kRawPitch + c + 2];
+        }
+        blur_run<T::kVRun>(bk, av, zv, o);
+#pragma unroll
+        for (int n = 0; n < T::kVRun; ++n) s_vb[(r0 + n) * T::kBlurPitch + c] = o[n];
+    }
+    clk.mark(4);         // 4: V-blur
+    __syncthreads();
+    clk.mark(5);         // 5: barrier
+    if constexpr (Hook::kBeforeBilateral) {
+        // vmcnt retires in order: a load issued here would sit behind nothing only if the hoisted operands
+        // are waited for first -- naming them in an asm makes the compiler put that wait here
+#pragma unroll
+        for (int pass = 0; pass < kPasses; ++pass) {
+            if constexpr (FINAL) {
+                asm volatile("" : : "v"(hoist_hd16[pass][0]), "v"(hoist_hd16[pass][1]));
+            } else {
+                asm volatile("" : : "v"(hoist_hd32[pass][0]), "v"(hoist_hd32[pass][1]), "v"(hoist_ha[pass][0]), "v"(hoist_ha[pass][1]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hook.before_bilateral();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- bilateral upsample: lane = 4 x 2 hi-res texels per pass of 64 x 32
+    if constexpr (!FINAL) {
+        // The hoisted AO quads (one integer each, UpsLoads) pass through an opaque statement HERE, behind the last barrier: their
+        // decoding otherwise moves up to the window phase -- `s_waitcnt vmcnt(0)` in front of the first barrier, i.e. the latency
+        // the hoisting was meant to hide (round 4: ISA of the L2->L1 kernel).
+#pragma unroll
+        for (int pass = 0; pass < kPasses; ++pass)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) asm volatile("" : "+v"(hoist_ha[pass][f]));
+    }
+    const bool vec_ok_frame = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;       // hw % 4 == 0 and (final pass) 4-texel aligned caller pointers
+    // Gather component order x=(c-1,c) y=(c,c) z=(c,c-1) w=(c-1,c-1) as (col,row) offsets
+    constexpr int gx[4] = {-1, 0, 0, -1}, gy[4] = {0, 0, -1, -1};
+    const int tx = tid & 15;
+    const int hx0 = HX0 + 4 * tx;
+    // WHOLE: the tile lies inside the frame and its rows take 4-texel loads and stores -- no lane or row of it is masked
+    // (always_inline, like every helper here: whether the compiler inlined this lambda used to depend on how many kernels of the
+    // translation unit instantiate the same upsample_tile -- the code of a kernel must not depend on its neighbours in the file)
+    auto bilateral_phase = [&](auto whole_tile) __attribute__((always_inline)) {
+        constexpr bool WHOLE = decltype(whole_tile)::value;
+        const bool vec_ok = WHOLE || vec_ok_frame;
+        if (!WHOLE && hx0 >= hw) return;
+#pragma unroll       // the hoisted operands live in registers: static indices
+        for (int pass = 0; pass < kTileH / 32; ++pass) {
+            const int ty = (tid >> 4) + 16 * pass;
+            const int hy0 = HY0 + 2 * ty;
+            if (!WHOLE && hy0 >= hh) return;
+
+            float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const float2v v0 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx]);
+                const float2v v1 = *reinterpret_cast<const float2v *>(&s_vb[(ty + rr) * T::kBlurPitch + 2 * tx + 2]);
+                const float2v d0 = *reinterpret_cast<const float2v *>(&dep_at(ty + rr + 2, 2 * tx + 2));
+                const float2v d1 = *reinterpret_cast<const float2v *>(&dep_at(ty + rr + 2, 2 * tx + 4));
+                vb[rr][0] = v0.x; vb[rr][1] = v0.y; vb[rr][2] = v1.x; vb[rr][3] = v1.y;
+                dl[rr][0] = d0.x; dl[rr][1] = d0.y; dl[rr][2] = d1.x; dl[rr][3] = d1.y;
+            }
+
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int hy = hy0 + f;
+                if (!WHOLE && hy >= hh) break;
+                const size_t hrow = static_cast<size_t>(hy) * hw + hx0;
+                float hd[4], ha[4] = {1.0f, 1.0f, 1.0f, 1.0f};                  // HiSSAOs = 1 in "main" (UPS:222)
+                if constexpr (FINAL) {
+                    const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
+                    if (vec_ok) {
+                        const ushort4v q = hoist_hd16[pass][f];
+                        hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
+                        hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hd[e] = (hx0 + e < hw) ? f16_bits_to_f32(p[e]) : 1.0f;
+                    }
+                } else {
+                    const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
+                    const ao_t *q = frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame) + hrow;
+                    if (vec_ok) {
+                        const float4v d4 = hoist_hd32[pass][f];
+                        const typename Loads::ao_bits_t a4 = hoist_ha[pass][f];
+                        hd[0] = d4.x; hd[1] = d4.y; hd[2] = d4.z; hd[3] = d4.w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ha[e] = AO::decode(static_cast<ao_t>(a4 >> (8 * sizeof(ao_t) * e)));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hd[e] = (hx0 + e < hw) ? p[e] : 1.0f;
+                            ha[e] = (hx0 + e < hw) ? AO::decode(q[e]) : 1.0f;
+                        }
+                    }
+                }
+                ao_t res[4];
+                if constexpr (!MEAO_X_UPS_EXACT_R8 && Hook::kEstimateR8 && DIV == DIV_EXACT_RCP && AOFMT == MEAO_AO_R8) {
+                    // UNORM8 storage: the code from the uncorrected reciprocals wherever that provably is the reference's code
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // as below
+                        const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+                        float gd[4], ga[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int g = (comp + i) & 3;
+                            gd[i] = dl[rr + gy[g]][cc + gx[g]];
+                            ga[i] = vb[rr + gy[g]][cc + gx[g]];
+                        }
+                        res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, !NESTED && Hook::kReuseEstimate>(hd[e], ha[e], gd, ga, bilateral_k));
+                    }
+                } else if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
+                    // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than
+                    // one that follows another (tools/ubench_issue.hip "bilateral mix": 3.81 -> 3.55 cycles per instruction).  A/B:
+                    // L2->L1 65 -> 58.5 us, L1->L0 202.5 -> 199.2 us; two texels per group: the same (profiles/r03_ab_rcp_group*.jsonl).
+                    constexpr int kGroup = 1;             // texels whose reciprocals are issued together
+#pragma unroll
+                    for (int e0 = 0; e0 < 4; e0 += kGroup) {
+                        float gd[kGroup][4], ga[kGroup][4], ghd[kGroup], gha[kGroup], gout[kGroup];
+#pragma unroll
+                        for (int t = 0; t < kGroup; ++t) {
+                            const int e = e0 + t;
+                            const int cc = ((e + 1) >> 1) + 1, rr = f + 1;
+                            const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int g = (comp + i) & 3;
+                                gd[t][i] = dl[rr + gy[g]][cc + gx[g]];
+                                ga[t][i] = vb[rr + gy[g]][cc + gx[g]];
+                            }
+                            ghd[t] = hd[e]; gha[t] = ha[e];
+                        }
+                        bilateral_upsample_grouped<kGroup>(ghd, gha, gd, ga, bilateral_k, gout);
+#pragma unroll
+                        for (int t = 0; t < kGroup; ++t) res[e0 + t] = AO::template encode<RTNE>(gout[t]);
+                    }
+                } else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // hi texel (4tx+e, 2ty+f) is written by dispatch thread D = ((hx+1)>>1, (hy+1)>>1)
+                    // through Gather component comp (UPS:229-232); its taps are rotated by comp.
+                    const int cc = ((e + 1) >> 1) + 1, rr = f + 1;            // D in vb/dl coordinates
+                    const int comp = (e & 1) ? ((f & 1) ? 3 : 0) : ((f & 1) ? 2 : 1);
+                    const int g0 = comp & 3, g1 = (comp + 1) & 3, g2 = (comp + 2) & 3, g3 = (comp + 3) & 3;
+                    const float v = bilateral_upsample<DIV>(
+                        hd[e], ha[e],
+                        dl[rr + gy[g0]][cc + gx[g0]], dl[rr + gy[g1]][cc + gx[g1]],
+                        dl[rr + gy[g2]][cc + gx[g2]], dl[rr + gy[g3]][cc + gx[g3]],
+                        vb[rr + gy[g0]][cc + gx[g0]], vb[rr + gy[g1]][cc + gx[g1]],
+                        vb[rr + gy[g2]][cc + gx[g2]], vb[rr + gy[g3]][cc + gx[g3]],
+                        bilateral_k);
+                    res[e] = AO::template encode<RTNE>(v);
+                }
+                ao_t *o = dst + hrow;
+                if (vec_ok) {
+                    typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
+                    // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
+                    if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
+                    else *reinterpret_cast<typename AO::type4 *>(o) = r4;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (hx0 + e < hw) o[e] = res[e];
+                }
+            }
+            clk.mark(6 + pass);  // 6, 7: bilateral pass 0 / 1 (64-row tiles) incl. its stores being issued
+        }
+    };
+    // (the copy exists for clean frames only -- the IEEE-division bodies of a hostile frame are four times as long -- and not in the
+    // nested launches, which have no registers for it: 3 spilled VGPRs in the two-level kernel, no gain measured there)
+    if (MEAO_X_BIL_WHOLE_TILE && !NESTED && DIV == DIV_EXACT_RCP && vec_ok_frame && HX0 + kUpsTileW <= hw && HY0 + kTileH <= hh)
+        bilateral_phase(std::true_type());
+    else
+        bilateral_phase(std::false_type());
+}
+
+// The (rare) hostile-frame variant of a tile: the same code with IEEE division.
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
+__device__ __forceinline__ void upsample_tile_checked(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
+{
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
+            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE, false, Hook, TILE_H>(a, smem, tile, frame, hook);
+            return;
+        }
+    }
+    upsample_tile<AOFMT, RTNE, FINAL, DIV, false, Hook, TILE_H>(a, smem, tile, frame, hook);
+}
+
+
+}  // namespace
+}  // namespace meao

@@ -123,6 +123,10 @@ hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s)
 hipError_t launch_downsample_side(const DownsampleArgs &a, int frames, bool pad_vgprs, hipStream_t s);
 hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
+// Render with its windows filled from the raw depth frames of `d` (f32, 36-sample set) instead of LowDepth<level>; with_downsample:
+// the same launch runs the downsample pass `d` describes as extra workgroups (meao_k_render_depth.hip).
+hipError_t launch_render_from_depth(const RenderArgs &a, const DownsampleArgs &d, bool with_downsample, int ao_format, int frames,
+                                    hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
 // Two blend passes in one launch: `inner` (e.g. L4 -> L3) is evaluated per tile of `outer` (L3 -> L2) for the

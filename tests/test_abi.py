@@ -216,12 +216,24 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_every_variant_arm_names_a_switch_of_the_kernel_source():
-    """build.VARIANTS may only carry -D flags whose macro exists in meao_kernels.hip (an arm whose switch has been removed
-    builds a copy of the product under another name: four such arms once travelled through an evidence round)."""
+    """build.VARIANTS may only carry -D flags whose macro is a switch of the native sources (an arm whose switch has been
+    removed builds a copy of the product under another name: four such arms once travelled through an evidence round)."""
     import re
     from miniengineao_amd import build
-    src = open(os.path.join(os.path.dirname(build.__file__), "csrc", "meao_kernels.hip")).read()
+    csrc = os.path.join(os.path.dirname(build.__file__), "csrc")
+    src = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)))
     for name, flags in build.VARIANTS.items():
         for flag in flags:
             macro = re.match(r"-D(\w+)", flag).group(1)
-            assert re.search(r"#\s*ifndef\s+%s\b" % macro, src), f"variant {name}: {macro} is not a switch of meao_kernels.hip"
+            assert re.search(r"#\s*ifndef\s+%s\b" % macro, src), f"variant {name}: {macro} is not a switch of miniengineao_amd/csrc"
+
+
+def test_every_kernel_unit_is_part_of_the_unity_file():
+    """csrc/meao_kernels.hip (the one-translation-unit form the `clocks` variant and the ISA tools build) includes exactly the
+    units the product compiles separately (build.KERNEL_UNITS)."""
+    import re
+    from miniengineao_amd import build
+    csrc = os.path.join(os.path.dirname(build.__file__), "csrc")
+    included = re.findall(r'#include "(meao_k_\w+\.hip)"', open(os.path.join(csrc, "meao_kernels.hip")).read())
+    assert sorted(included) == sorted(build.KERNEL_UNITS)
+    assert sorted(f for f in os.listdir(csrc) if f.startswith("meao_k_") and f.endswith(".hip")) == sorted(build.KERNEL_UNITS)

@@ -17,10 +17,10 @@ _nan_aware_equal = H.nan_aware_equal
 hostile_frame = H.hostile_frame
 
 
-def _compare(O, s, depth, ao=None, frame=0, got=None):
+def _compare(O, s, depth, ao=None, frame=0, got=None, debug=None):
     want = O.run(depth, s)
     own = ao is None
-    ao = ao or H.component(s)
+    ao = ao or H.component(s, debug=debug)
     try:
         if got is None:
             got = ao.render(depth)
@@ -60,13 +60,20 @@ def test_hostile_f32_depth_matches_oracle(oracle, w, h, seed, ao_format, f16_rou
     _compare(oracle, s, hostile_frame(w, h, seed))
 
 
+# render windows from the stored depth mips (frame-level hostile flag -> IEEE-division body) / from the raw depth frame, in one
+# launch with the downsample pass or on a second stream (per-texel IEEE division, no flag): meao_debug_set RENDER_FROM_DEPTH
+RENDER_SOURCES = {"stored_mips": 0, "raw_depth_one_launch": 1, "raw_depth_two_streams": 2}
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("source", sorted(RENDER_SOURCES))
 @pytest.mark.parametrize("kind", ["nan", "pinf", "ninf", "neg", "big", "huge", "nhuge", "denorm", "negzero",
                                   "zero_den", "tiny_den", "one", "zero"])
-def test_each_hostile_value_alone(oracle, kind):
+def test_each_hostile_value_alone(oracle, kind, source):
+    from miniengineao_amd import _lib as L
     w, h = 130, 70
     s = H.settings(oracle, w, h)
-    _compare(oracle, s, hostile_frame(w, h, 11, density=0.004, kinds=[kind]))
+    _compare(oracle, s, hostile_frame(w, h, 11, density=0.004, kinds=[kind]), debug={L.DEBUG_RENDER_FROM_DEPTH: RENDER_SOURCES[source]})
 
 
 @pytest.mark.gpu
