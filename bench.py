@@ -733,11 +733,24 @@ def main() -> int:
             return c
         lat_iters = 50
         single = {}
+        # what the validated batched run left in frame 0: every one-frame variant below must reproduce it (same depth frame)
+        frame0_validated = wl.out_dev[0][0].clone()
+        single_mismatches = {}
         # "pipelined": a stream of single frames whose next depth buffer is known one call ahead
-        # (meao_prefetch_batch with n = 1: each call's last kernel carries the next frame's downsample pass)
-        variants = (("direct", {}), ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}), ("direct_pipelined", {"pipelined": True}))
+        # (meao_prefetch_batch with n = 1: each call's last kernel carries the next frame's downsample pass).
+        # "direct" is the library's default for a call this small: render windows from the raw depth frame, the downsample
+        # pass as extra workgroups of the render launch (three dependent launches); "direct_stored_mips" = the round-4
+        # sequence (downsample | render | blends | final); "direct_two_streams" = raw-depth render next to the pass on a
+        # second stream (MEAO_DEBUG_RENDER_FROM_DEPTH 0 / 2)
+        variants = (("direct", {}), ("direct_stored_mips", {"_debug": {_lib.DEBUG_RENDER_FROM_DEPTH: 0}}),
+                    ("direct_two_streams", {"_debug": {_lib.DEBUG_RENDER_FROM_DEPTH: 2}}),
+                    ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}), ("direct_pipelined", {"pipelined": True}))
         for name, kw in variants:
+            kw = dict(kw)
+            debug = kw.pop("_debug", {})
             c = one_frame_ctx(**kw)
+            for key, value in debug.items():
+                c.debug_set(key, value)
             for sync_each in (False, True):
                 for _ in range(3):
                     if name == "direct_pipelined":
@@ -754,7 +767,11 @@ def main() -> int:
                 torch.cuda.synchronize(dev)
                 single[name + ("_call_and_wait_ms" if sync_each else "_back_to_back_ms")] = \
                     round((time.perf_counter() - t0) / lat_iters * 1e3, 4)
+            single_mismatches[name] = int((wl.out_dev[0][0] != frame0_validated).sum().item())
             c.close()
+        single["texels_differing_from_the_validated_batched_result"] = single_mismatches
+        if any(single_mismatches.values()):
+            raise SystemExit(f"one-frame-per-call results differ from the validated batched result: {single_mismatches}")
         latency_ms = single["direct_back_to_back_ms"]
 
     desc, nfl = wl.desc, wl.nfl

@@ -18,6 +18,9 @@
 #ifndef MEAO_X_BIL_WHOLE_TILE
 #define MEAO_X_BIL_WHOLE_TILE 1    // 0 = no separate copy of the bilateral phase for tiles that lie wholly inside the frame (the round-3 form):
 #endif                             // last kernel 296 -> 272 us, step 570 -> 551 us (profiles/r04_ab_bilateral_arms.jsonl)
+#ifndef MEAO_X_BIL_PAIR_RCP
+#define MEAO_X_BIL_PAIR_RCP 1      // 0 = five v_rcp_f32 per UNORM8 bilateral texel (the round-4 form) instead of three (the reciprocals of a tap
+#endif                             // pair from one reciprocal of their product, bilateral_upsample_r8<PAIRED>); variant library `nopair`
 #ifndef MEAO_X_HOT_PATH_ONLY
 #define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
 #endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the

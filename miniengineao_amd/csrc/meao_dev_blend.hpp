@@ -145,7 +145,7 @@ __device__ __forceinline__ void blend_window_into_lds(const UpsampleArgs &in, fl
         const uint32_t at = static_cast<uint32_t>(Y * hw + X) * static_cast<uint32_t>(sizeof(ao_t));      // byte offset in the level
         float v;
         if constexpr (!MEAO_X_UPS_EXACT_R8 && DIV == DIV_EXACT_RCP && AOFMT == MEAO_AO_R8) {
-            const ao_t q = static_cast<ao_t>(bilateral_upsample_r8<true>(hoist_d[j], AO::decode(hoist_a[j]), dk, ak, bilateral_k));
+            const ao_t q = static_cast<ao_t>(bilateral_upsample_r8<true, false, MEAO_X_BIL_PAIR_RCP != 0>(hoist_d[j], AO::decode(hoist_a[j]), dk, ak, bilateral_k));
             out[i] = AO::decode(q);
             if (vx0 + wc == X && vy0 + wr == Y && X >= own_x0 && X < own_x0 + own_w && Y >= own_y0 && Y < own_y0 + own_h) *at_byte_offset(dst, at) = q;
             continue;

@@ -173,17 +173,40 @@ __device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_dept
 // REUSE: the exact path starts from the estimate's x and 1 / x (14 instructions fewer on that path, 5 - 8 VGPRs more live across
 // the branch); without it the whole exact sequence is run again from an opaque copy of the depth, so that nothing of the estimate
 // has to stay in registers for the rare path (the nested kernels have none to spare).
+// PAIRED (round 5): THREE v_rcp_f32 per texel instead of five -- the reciprocals of a tap pair come from one reciprocal of their
+// product, 1/x0 = x1 * rcp(x0 * x1), 1/x1 = x0 * rcp(x0 * x1): a quarter-rate transcendental (8 - 11 issue cycles inside this
+// mix) is traded for three full-rate multiplies.  x = |dHi - dLo| + tolerance lies in [2^-44, 2^21] (exact_rcp_div_applicable +
+// nice depths), so a product of two lies in [2^-88, 2^42]: no overflow, no denormal anywhere.  Error: product u, v_rcp_f32 3u,
+// multiply u = 5u per reciprocal instead of 3u, i.e. weights 7u, total 7u + 2 * 4u = 15u, weighted sum 7u + 2 * 6u = 19u,
+// quotient + 5u: 39u = 1.22 * 2^-19 of q, < 6.0e-4 of a code (+ 2.3e-5 for the conversions) -- still inside kR8Margin = 9.8e-4.
+// The exact path cannot start from these reciprocals (the correctly-rounded guarantee of the Newton step is verified for the
+// v_rcp_f32 seed, meao_selftest(4..6), not for a 5u one): PAIRED implies !REUSE.  Checked like the five-reciprocal form:
+// tests/test_r8_estimate_bound.py (adversarial errors), meao_selftest(7) (2^32 operand sets on the device).
 constexpr float kR8Margin = 0x1p-10f;     // (1.25 * 2^-11, still above the bound, measured the same: profiles/r04_ab_r8_margin.jsonl)
 
 // (v_cvt_pk_u8_f32, which would convert and pack in one instruction, does not truncate like v_cvt_u32_f32: tried in round 4.)
-template <bool GROUPED, bool REUSE = false>
+template <bool GROUPED, bool REUSE = false, bool PAIRED = false>
 __device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float hi_ao, const float (&d)[4], const float (&a)[4],
                                                           const BilateralConsts &k)
 {
+    static_assert(!(PAIRED && REUSE), "the exact path's Newton steps are only verified for v_rcp_f32 seeds");
     float x[4], r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[i] = __builtin_fabsf(hi_depth - d[i]) + k.tolerance;
-    if constexpr (GROUPED) {
+    if constexpr (PAIRED) {
+        const float p01 = x[0] * x[1], p23 = x[2] * x[3];
+        float r01, r23;
+        if constexpr (GROUPED) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("v_rcp_f32 %0, %1" : "=v"(r01) : "v"(p01));
+            asm volatile("v_rcp_f32 %0, %1" : "=v"(r23) : "v"(p23));
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            r01 = __builtin_amdgcn_rcpf(p01);
+            r23 = __builtin_amdgcn_rcpf(p23);
+        }
+        r[0] = x[1] * r01; r[1] = x[0] * r01; r[2] = x[3] * r23; r[3] = x[2] * r23;
+    } else if constexpr (GROUPED) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("v_rcp_f32 %0, %1" : "=v"(r[i]) : "v"(x[i]));
@@ -343,7 +366,8 @@ struct NoHook {
     static constexpr bool kBeforeBilateral = false;
     static constexpr bool kGroupReciprocals = true;      // bilateral_upsample_grouped
     static constexpr bool kEstimateR8 = true;            // bilateral_upsample_r8
-    static constexpr bool kReuseEstimate = true;         // ... whose exact path starts from the estimate's reciprocals
+    static constexpr bool kReuseEstimate = true;         // ... whose exact path starts from the estimate's reciprocals (five-reciprocal form only)
+    static constexpr bool kPairReciprocals = MEAO_X_BIL_PAIR_RCP != 0;    // three reciprocals per texel (bilateral_upsample_r8<PAIRED>)
     __device__ __forceinline__ void after_prefetch() const {}
     __device__ __forceinline__ void before_bilateral() const {}
 };
@@ -652,7 +676,8 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                             gd[i] = dl[rr + gy[g]][cc + gx[g]];
                             ga[i] = vb[rr + gy[g]][cc + gx[g]];
                         }
-                        res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, !NESTED && Hook::kReuseEstimate>(hd[e], ha[e], gd, ga, bilateral_k));
+                        res[e] = static_cast<ao_t>(bilateral_upsample_r8<Hook::kGroupReciprocals, !NESTED && Hook::kReuseEstimate && !Hook::kPairReciprocals,
+                                                                          Hook::kPairReciprocals>(hd[e], ha[e], gd, ga, bilateral_k));
                     }
                 } else if constexpr (DIV == DIV_EXACT_RCP && Hook::kGroupReciprocals) {
                     // The four weight reciprocals of a texel back to back: an isolated v_rcp_f32 costs the SIMD ~3 cycles more than

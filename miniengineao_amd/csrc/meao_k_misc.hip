@@ -160,6 +160,8 @@ __global__ __launch_bounds__(kThreads) void selftest_div_kernel(unsigned long lo
             bad += bilateral_upsample_r8<true, false>(hd, hi_ao, d, a, k) != want;
             bad += bilateral_upsample_r8<false, true>(hd, hi_ao, d, a, k) != want;
             bad += bilateral_upsample_r8<true, true>(hd, hi_ao, d, a, k) != want;
+            bad += bilateral_upsample_r8<false, false, true>(hd, hi_ao, d, a, k) != want;        // three reciprocals per texel (round 5)
+            bad += bilateral_upsample_r8<true, false, true>(hd, hi_ao, d, a, k) != want;
         } else if (which == 5) {
             if (!in_exact_range(x, 0x1p-100f, 0x1p100f)) continue;
             bad += div_const<DIV_EXACT_RCP, 3>(x) != 3.0f / x;

@@ -13,6 +13,7 @@ struct IssueCarriedLoads {
     static constexpr bool kGroupReciprocals = false;     // the kernels that carry a downsample tile are short of registers: A/B +3 %
     static constexpr bool kEstimateR8 = false;           // ... and wait on memory, not on VALU issue: 10 % fewer instructions, +4 us
     static constexpr bool kReuseEstimate = false;
+    static constexpr bool kPairReciprocals = false;
     const DownsampleArgs &d;
     float (&v)[kDsTileH / kDsRowsPerPass][4];
     bool mine;
@@ -32,6 +33,7 @@ struct IssueCarriedLoadsLean {
     static constexpr bool kGroupReciprocals = true;
     static constexpr bool kEstimateR8 = true;
     static constexpr bool kReuseEstimate = false;        // (70 of the 72 VGPRs that seven workgroups per CU allow: reuse spills)
+    static constexpr bool kPairReciprocals = MEAO_X_BIL_PAIR_RCP != 0;
     const DownsampleArgs &d;
     float4v (&q)[kDsTileH / kDsRowsPerPass];
     bool mine, full;
