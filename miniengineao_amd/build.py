@@ -178,7 +178,7 @@ def build_tools(force: bool = False):
     the v_rcp_f32 division sequences).  Stand-alone HIP programs, run on the GPU box."""
     out = []
     tools = os.path.join(os.path.dirname(_PKG), "tools")
-    for name, extra in (("ubench_valu", []), ("ubench_issue", ["-Wno-unused-value"]), ("ubench_lds", []), ("ubench_launch", []),
+    for name, extra in (("ubench_valu", []), ("ubench_issue", ["-Wno-unused-value"]), ("ubench_lds", []), ("ubench_launch", []), ("ubench_fetch", []),
                         ("ubench_div", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"])):
         src, dst = os.path.join(tools, name + ".hip"), os.path.join(LIB_DIR, name)
         if not force and os.path.exists(dst) and os.path.getmtime(dst) >= os.path.getmtime(src):
