@@ -104,7 +104,7 @@ def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
 def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
     """HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes
     (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate runs by
-    tests/run_pmc.sh, corrected as MI355X_MICROARCH.md prescribes; per frame, scaled here by the
+    tools/run_pmc.sh, corrected as MI355X_MICROARCH.md prescribes; per frame, scaled here by the
     frames per launch).  Not measured in the run that prints it -- the `source` says so.
     None when no measurement exists for this workload/kernel."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -552,6 +552,10 @@ def main() -> int:
                     help="process-group backend; nccl (= RCCL) is what a multi-GPU node uses.  gloo lets the N > 1 path of this "
                          "script run on a box with fewer GPUs than ranks (ranks then share devices: rank r on device r mod visible "
                          "devices) -- a functional check of sharding / fences / gathers / validation, not a scaling number")
+    ap.add_argument("--launcher", action="store_true",
+                    help="with --gpus 1: run through the self-launcher as well (torch.distributed.run, rendezvous on 127.0.0.1, a "
+                         "one-rank process group of --dist-backend whose collectives carry fences / MAX / checksums): the driver's "
+                         "N > 1 command path rehearsed on a 1-GPU box")
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
     args = ap.parse_args()
@@ -562,7 +566,7 @@ def main() -> int:
     if args.pool > 0:
         return run_pool(args)
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.launcher) and "WORLD_SIZE" not in os.environ:
         return self_launch(args)                # plain `python bench.py --gpus N`: become the launcher of N ranks
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -738,12 +742,12 @@ def main() -> int:
         single_mismatches = {}
         # "pipelined": a stream of single frames whose next depth buffer is known one call ahead
         # (meao_prefetch_batch with n = 1: each call's last kernel carries the next frame's downsample pass).
-        # "direct" is the library's default for a call this small: render windows from the raw depth frame, the downsample
-        # pass as extra workgroups of the render launch (three dependent launches); "direct_stored_mips" = the round-4
-        # sequence (downsample | render | blends | final); "direct_two_streams" = raw-depth render next to the pass on a
-        # second stream (MEAO_DEBUG_RENDER_FROM_DEPTH 0 / 2)
-        variants = (("direct", {}), ("direct_stored_mips", {"_debug": {_lib.DEBUG_RENDER_FROM_DEPTH: 0}}),
-                    ("direct_two_streams", {"_debug": {_lib.DEBUG_RENDER_FROM_DEPTH: 2}}),
+        # "direct" = the library's default sequence (downsample | render | blends | final); "direct_raw_depth_one_launch" /
+        # "direct_raw_depth_two_streams" = MEAO_DEBUG_RENDER_FROM_DEPTH 1 / 2: render windows from the raw depth frame, the
+        # downsample pass as extra workgroups of the render launch / next to it on a second stream (round 5: built, bit-exact,
+        # not faster -- the in-line A/B stays so that every bench line shows it)
+        variants = (("direct", {}), ("direct_raw_depth_one_launch", {"_debug": {_lib.DEBUG_RENDER_FROM_DEPTH: 1}}),
+                    ("direct_raw_depth_two_streams", {"_debug": {_lib.DEBUG_RENDER_FROM_DEPTH: 2}}),
                     ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}), ("direct_pipelined", {"pipelined": True}))
         for name, kw in variants:
             kw = dict(kw)
@@ -824,7 +828,7 @@ def main() -> int:
             "config": {"workload": desc, "width": w, "height": h, "frames_per_step_per_gpu": B,
                        "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
                        "numerics": "FAST (raw rcp, not bit-exact, outside the parity bar)" if args.fast_numerics else "strict (bit-exact vs CPU oracle)",
-                       "sharding": f"frames x{world}", "batches_in_flight": nfl, "process_group": args.dist_backend if world > 1 else None,
+                       "sharding": f"frames x{world}", "batches_in_flight": nfl, "process_group": args.dist_backend if mdist.group_info()["initialized"] else None,
                        "downsample": ("own pass per step" if not pipelined else
                                       "pipelined: each step's last kernel carries the next step's downsample pass (meao_prefetch_batch)"
                                       if not args.side_stream else
@@ -835,6 +839,8 @@ def main() -> int:
             "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
             "world_seen_by_process_group": mdist.world_size(),
             "world_seen_by_rccl": mdist.world_size() if (world == 1 or args.dist_backend == "nccl") else None,
+            # what the collectives of this run actually went through (world_seen_by_rccl is 1 with no group at all, too)
+            "process_group_in_use": mdist.group_info(),
             "validation": validation,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "single_frame": single,

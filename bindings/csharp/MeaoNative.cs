@@ -137,6 +137,7 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_set_tracing(IntPtr ctx, int enable);
         [DllImport(Lib)] public static extern int meao_composite_enqueue(IntPtr ctx, int mode, int n, IntPtr[] ao, IntPtr[] color_rgba16f, IntPtr[] gbuffer0_rgba8);
         [DllImport(Lib)] public static extern int meao_composite_flush(IntPtr ctx, IntPtr stream);
+        [DllImport(Lib)] public static extern int meao_composite_pending(IntPtr ctx, out int out_frames);
 
         // multi-GPU pool: frame f of a batch runs on member f mod G (one context + stream per device)
         [DllImport(Lib)] public static extern int meao_pool_create(ref MeaoConfig cfg, int[] devices, int num_devices, out IntPtr pool);
@@ -150,6 +151,7 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_pool_prefetch_batch(IntPtr pool, int n, IntPtr[] depth);
         [DllImport(Lib)] public static extern int meao_pool_composite_enqueue(IntPtr pool, int mode, int n, IntPtr[] ao, IntPtr[] color_rgba16f, IntPtr[] gbuffer0_rgba8);
         [DllImport(Lib)] public static extern int meao_pool_composite_flush(IntPtr pool);
+        [DllImport(Lib)] public static extern int meao_pool_composite_pending(IntPtr pool, out int out_frames);
         [DllImport(Lib)] public static extern int meao_pool_gather_to_device(IntPtr pool, int n, IntPtr[] ao_src, IntPtr[] dst, int dst_device);
         [DllImport(Lib)] public static extern int meao_pool_gather_path(IntPtr pool, int member, int dst_device);   // 0 same device, 1 peer (xGMI), 2 staged
         [DllImport(Lib)] public static extern int meao_pool_synchronize(IntPtr pool);

@@ -327,6 +327,10 @@ MEAO_API int32_t meao_composite(meao_ctx *ctx, int32_t mode, const void *ao, voi
 MEAO_API int32_t meao_composite_enqueue(meao_ctx *ctx, int32_t mode, int32_t n, const void *const *ao,
                                         void *const *color_rgba16f, void *const *gbuffer0_rgba8);
 MEAO_API int32_t meao_composite_flush(meao_ctx *ctx, meao_stream stream);
+/* *out_frames = frames of an enqueued composite batch that no execute / flush / resize / second enqueue has run yet
+ * (0 = nothing waits).  Hosts ask the library instead of mirroring this state (a batch rides only in the members / calls
+ * that actually execute; an execute that fails leaves it waiting). */
+MEAO_API int32_t meao_composite_pending(const meao_ctx *ctx, int32_t *out_frames);
 
 /* Per-pass device timing: when enabled, meao_execute* brackets every pass with HIP events on
  * the launch stream; meao_get_pass_times averages each pass over the executes that ran it since
@@ -378,6 +382,7 @@ MEAO_API int32_t meao_pool_prefetch_batch(meao_pool *pool, int32_t n, const void
 MEAO_API int32_t meao_pool_composite_enqueue(meao_pool *pool, int32_t mode, int32_t n, const void *const *ao,
                                              void *const *color_rgba16f, void *const *gbuffer0_rgba8);
 MEAO_API int32_t meao_pool_composite_flush(meao_pool *pool);
+MEAO_API int32_t meao_pool_composite_pending(const meao_pool *pool, int32_t *out_frames);   /* summed over the members */
 /* Copies the n DEVICE results ao_src[f] (on their owning devices) to dst[f] on dst_device with
  * hipMemcpyPeerAsync (xGMI), each on its producer's stream, i.e. ordered behind the kernels that wrote it. */
 MEAO_API int32_t meao_pool_gather_to_device(meao_pool *pool, int32_t n, const void *const *ao_src,
@@ -415,9 +420,11 @@ typedef enum meao_debug_key {
                                         * first s tenths of the frames at `gate`, the rest at gate b (default 1).  Results identical. */
     MEAO_DEBUG_RENDER_FROM_DEPTH = 8,  /* calls that run their own downsample pass (no meao_prefetch_batch), f32 depth, 36 samples: the render
                                         * launch fills its windows from the RAW depth frame and does not wait for the downsample pass.
-                                        * 0 = never; 1 = always, both in ONE launch (the pass as extra workgroups behind the render ones);
-                                        * 2 = always, as two launches on two streams of the context joined in front of the blend launch;
-                                        * 3 (default) = form 1 for calls of at most RENDER_FROM_DEPTH_MAX_TILES render tiles */
+                                        * 0 (default) = never; 1 = always, both in ONE launch (the pass as extra workgroups behind the
+                                        * render ones); 2 = always, as two launches on two streams of the context joined in front of the
+                                        * blend launch; 3 = form 1 for calls of at most RENDER_FROM_DEPTH_MAX_TILES render tiles.
+                                        * Measured slower than the stored-mip sequence at every call size (the gathered windows touch
+                                        * 2^level times the cache lines): an option, not the default. */
     MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES = 9   /* frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190); default 1024 */
 } meao_debug_key;
 MEAO_API int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value);

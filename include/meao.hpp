@@ -129,6 +129,12 @@ public:
                                      deviceGBuffer0.empty() ? nullptr : deviceGBuffer0.data()));
     }
     void FlushComposite(meao_stream stream = nullptr) { check(meao_composite_flush(ctx_, stream)); }
+    bool CompositePending()            // a batch given to CompositeWithNextFrame that no Render* / flush / resize has run yet
+    {
+        int32_t frames = 0;
+        check(meao_composite_pending(ctx_, &frames));
+        return frames > 0;
+    }
 
     // roctx ranges per pass for rocprofv3 --marker-trace
     void SetTracing(bool enable) { check(meao_set_tracing(ctx_, enable ? 1 : 0)); }

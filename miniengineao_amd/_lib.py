@@ -19,7 +19,7 @@ import os
 import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# MEAO_LIB_PATH: an alternative build of the same library (A/B of kernel variants, tests/run_gpu_variants_ab.sh)
+# MEAO_LIB_PATH: an alternative build of the same library (A/B of kernel variants, tools/run_gpu_variants_ab.sh)
 LIB_PATH = os.environ.get("MEAO_LIB_PATH") or os.path.join(_PKG, "lib", "libmeao_hip.so")
 
 ABI_VERSION = 5
@@ -120,6 +120,7 @@ SIGNATURES = {
     "meao_composite_enqueue": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p)]),
     "meao_composite_flush": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "meao_composite_pending": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "meao_pool_create": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
     "meao_pool_destroy": (C.c_int32, [C.c_void_p]),
     "meao_pool_size": (C.c_int32, [C.c_void_p]),
@@ -135,6 +136,7 @@ SIGNATURES = {
     "meao_pool_composite_enqueue": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                 C.POINTER(C.c_void_p)]),
     "meao_pool_composite_flush": (C.c_int32, [C.c_void_p]),
+    "meao_pool_composite_pending": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "meao_pool_gather_path": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     "meao_hostile_frames": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "meao_debug_set": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),

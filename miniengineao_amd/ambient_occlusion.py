@@ -115,7 +115,6 @@ class AmbientOcclusion:
         """Screen-size change (AO.cs:338-341)."""
         L.check(self._lib.meao_resize(self._ctx, width, height), self._ctx)
         self._cfg.width, self._cfg.height = width, height
-        self._composite_waiting = False        # meao_resize runs a waiting composite as plain launches
 
     def _sync_params(self) -> None:
         if self._dirty:
@@ -141,7 +140,6 @@ class AmbientOcclusion:
         pin = (C.c_void_p * n)(*[d.ctypes.data for d in ins])
         pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         L.check(self._lib.meao_execute_batch(self._ctx, n, pin, L.MEM_HOST, pout, L.MEM_HOST, None), self._ctx)
-        self._composite_waiting = False
         return outs
 
     def execute_device(self, depth_ptrs: Sequence[int], out_ptrs: Sequence[int], stream: int = 0) -> None:
@@ -152,7 +150,6 @@ class AmbientOcclusion:
         pout = (C.c_void_p * n)(*out_ptrs)
         L.check(self._lib.meao_execute_batch(self._ctx, n, pin, L.MEM_DEVICE, pout, L.MEM_DEVICE,
                                              C.c_void_p(stream) if stream else None), self._ctx)
-        self._composite_waiting = False        # a waiting composite rode in (or was run before) this call's render kernel
 
     def prefetch_device(self, depth_ptrs: Sequence[int]) -> None:
         """Announce the device depth frames of the call after next (meao_prefetch_batch): the next
@@ -195,16 +192,19 @@ class AmbientOcclusion:
         g = (C.c_void_p * n)(*gbuffer0_ptrs) if gbuffer0_ptrs else None
         L.check(self._lib.meao_composite_enqueue(self._ctx, mode, n, (C.c_void_p * n)(*ao_ptrs),
                                                  (C.c_void_p * n)(*color_ptrs), g), self._ctx)
-        self._composite_waiting = True
 
     def composite_flush(self, stream: int = 0) -> None:
         L.check(self._lib.meao_composite_flush(self._ctx, C.c_void_p(stream) if stream else None), self._ctx)
-        self._composite_waiting = False
 
     @property
     def composite_pending(self) -> bool:
-        """A batch enqueued with composite_enqueue_device() that no execute / flush / resize has run yet."""
-        return bool(getattr(self, "_composite_waiting", False))
+        """A batch enqueued with composite_enqueue_device() that no execute / flush / resize has run yet
+        (meao_composite_pending: the library's own state, not a mirror of it)."""
+        if not self._ctx:
+            return False
+        n = C.c_int32()
+        L.check(self._lib.meao_composite_pending(self._ctx, C.byref(n)), self._ctx)
+        return n.value > 0
 
     # ---- observability (the _debug views, AO.cs:787-820) -------------------------------
     def debug_buffer(self, debug_id: int, frame: int = 0) -> np.ndarray:
@@ -334,7 +334,6 @@ class AmbientOcclusionPool:
         pin = (C.c_void_p * n)(*[d.ctypes.data for d in ins])
         pout = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         self._check(self._lib.meao_pool_execute_batch(self._pool, n, pin, L.MEM_HOST, pout, L.MEM_HOST))
-        self._composite_waiting = False
         return outs
 
     def execute_device(self, depth_ptrs: Sequence[int], out_ptrs: Sequence[int]) -> None:
@@ -342,7 +341,6 @@ class AmbientOcclusionPool:
         n = len(depth_ptrs)
         pin, pout = (C.c_void_p * n)(*depth_ptrs), (C.c_void_p * n)(*out_ptrs)
         self._check(self._lib.meao_pool_execute_batch(self._pool, n, pin, L.MEM_DEVICE, pout, L.MEM_DEVICE))
-        self._composite_waiting = False
 
     def prefetch_device(self, depth_ptrs: Sequence[int]) -> None:
         """meao_pool_prefetch_batch: the frames of the call after next, dealt like execute_device deals them."""
@@ -355,13 +353,18 @@ class AmbientOcclusionPool:
         g = (C.c_void_p * n)(*gbuffer0_ptrs) if gbuffer0_ptrs else None
         self._check(self._lib.meao_pool_composite_enqueue(self._pool, mode, n, (C.c_void_p * n)(*ao_ptrs),
                                                           (C.c_void_p * n)(*color_ptrs), g))
-        self._composite_waiting = True
 
     def composite_flush(self) -> None:
         self._check(self._lib.meao_pool_composite_flush(self._pool))
-        self._composite_waiting = False
 
-    composite_pending = property(lambda s: bool(getattr(s, "_composite_waiting", False)))
+    @property
+    def composite_pending(self) -> bool:
+        """Frames of an enqueued composite batch still waiting in any member (meao_pool_composite_pending)."""
+        if not self._pool:
+            return False
+        n = C.c_int32()
+        self._check(self._lib.meao_pool_composite_pending(self._pool, C.byref(n)))
+        return n.value > 0
 
     def gather_path(self, member: int, dst_device: int) -> int:
         """L.POOL_PATH_*: how gather_to_device copies from `member`'s device to dst_device."""

@@ -119,7 +119,7 @@ VARIANTS = {
     "clocks": ["-DMEAO_X_PHASE_CLOCKS=1"],          # diagnostic: phase stamps, render residency log
     "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],         # every UNORM8 bilateral result through the exact-division sequences (cross-check of the estimate)
     "testhooks": ["-DMEAO_TESTING=1"],              # the product + meao_test_fail_next_allocs (fault injection for the resize tests; not in the product ABI)
-    "nopair": ["-DMEAO_X_BIL_PAIR_RCP=0"],          # five reciprocals per UNORM8 bilateral texel (the round-4 form) instead of three
+    "pair": ["-DMEAO_X_BIL_PAIR_RCP=1"],            # three reciprocals per UNORM8 bilateral texel instead of five (round-5 A/B: no gain in the kernels)
     "nowt": ["-DMEAO_X_BIL_WHOLE_TILE=0"],          # without the unmasked copy of the bilateral phase (the round-3 form of the upsample tile)
 }
 

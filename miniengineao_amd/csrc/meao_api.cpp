@@ -80,11 +80,14 @@ struct meao_ctx {
     int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
     int nested_max_tiles = 1024;       // calls with at most this many L2->L1 tiles (frames x tiles; one 4K frame: 1020) run the three blend passes as one launch
                                        // (with the round-4 blend_window_into_lds: 55.9 vs 56.6 us per pipelined 4K frame, a tie unpipelined; 512 before)
-    // Calls with few tiles (one frame per call, AmbientOcclusion.cs:329-347): render fills its windows from the RAW depth frame
-    // (meao_k_render_depth.hip) and no longer depends on the downsample pass.  0 = never; 1 = one launch for both (the pass as
-    // extra workgroups of the render launch); 2 = two launches on two streams, joined in front of the first blend launch (A/B arm);
-    // 3 = form 1 for calls of at most render_from_depth_max_tiles render tiles (default).  f32 depth, 36-sample set.
-    int render_from_depth = 3;
+    // Render with its windows filled from the RAW depth frame (meao_k_render_depth.hip): render no longer depends on the
+    // downsample pass.  0 = never (default); 1 = one launch for both (the pass as extra workgroups of the render launch);
+    // 2 = two launches on two streams, joined in front of the first blend launch; 3 = form 1 for calls of at most
+    // render_from_depth_max_tiles render tiles.  f32 depth, 36-sample set.  Built for one frame per call
+    // (AmbientOcclusion.cs:329-347) and measured there: NOT faster -- a window of LowDepth<k> gathered from the raw frame touches
+    // 2^k times the cache lines (4K frame: 61.0 us against 60.4; render + pass in one launch 33.0 us against 15.4 + 18.6;
+    // two streams 86 us: two event hand-overs) -- profiles/r05_from_depth_sweep.jsonl, LABNOTES round 5.  Bit-exact and tested.
+    int render_from_depth = 0;
     int render_from_depth_max_tiles = 1024;      // frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190)
     hipStream_t rfd_stream = nullptr;            // form 2
     hipEvent_t rfd_fork = nullptr, rfd_join = nullptr;
@@ -603,13 +606,16 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         TraceRange tr(ctx, "meao:downsample_next(side stream)");
         MEAO_HIP(ctx, hipEventRecord(ctx->side_gate, stream));
         MEAO_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_gate, 0));
-        if (first == 0) MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
+        // (the side kernel is timed in the DOWNSAMPLE slot only in calls that did not run a pass of their own there)
+        if (first == 0 && prefetched) MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
         MEAO_HIP(ctx, launch_downsample_side(ds, count, side.shape == 0 || side.shape == 4, ctx->side_stream));
         side.issued = first + count;
+        // recorded behind EVERY part: whenever side_pending is set, side_done orders a later call (or meao_synchronize) behind
+        // everything that was launched on the side stream so far -- also when a later part fails to launch
+        MEAO_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
         ctx->side_pending = true;
         if (side.issued == side.total) {
-            MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));      // the slot spans all parts (and the wait between them)
-            MEAO_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
+            if (prefetched) MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));      // the slot spans all parts (and the wait between them)
             ctx->ready_n = ctx->next_n;
             ctx->ready_set = side.other;
             ctx->ready_stream = stream;
@@ -1124,6 +1130,9 @@ int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream)
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     MEAO_HIP(ctx, hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : ctx->last_stream));
+    // a downsample pass of the next batch that the last call put on the side stream (MEAO_DEBUG_DS_SIDE_STREAM) reads the
+    // caller's announced depth frames and holds profiling events: "synchronized" includes it
+    if (ctx->side_pending && ctx->side_done) MEAO_HIP(ctx, hipEventSynchronize(ctx->side_done));
     return MEAO_OK;
 }
 
@@ -1359,6 +1368,13 @@ int32_t meao_composite_enqueue(meao_ctx *ctx, int32_t mode, int32_t n, const voi
     pc.pixels = static_cast<int64_t>(ctx->cfg.width) * ctx->cfg.height;
     pc.mode = mode;
     pc.frames = n;
+    return MEAO_OK;
+}
+
+int32_t meao_composite_pending(const meao_ctx *ctx, int32_t *out_frames)
+{
+    if (!ctx || !out_frames) return MEAO_ERR_INVALID_ARGUMENT;
+    *out_frames = ctx->pending_comp.frames;
     return MEAO_OK;
 }
 

@@ -10,7 +10,7 @@
 // Every design decision below that replaced an alternative was A/B-measured on one box; the arms that
 // lost (or changed nothing) were removed in round 3 -- their logs stay in profiles/ (r02_ab_*.jsonl) and
 // profiles/README.md lists them.  Experimental arms of the current round live behind the MEAO_X_* switches
-// of this block only (tests/build_variants.py builds variants next to the product library;
+// of this block only (tools/build_variants.py builds variants next to the product library;
 // tests/test_variants_gpu.py runs a parity smoke through every variant library it finds).
 #ifndef MEAO_X_UPS_EXACT_R8
 #define MEAO_X_UPS_EXACT_R8 0      // 1 = every UNORM8 bilateral result through the full exact-division sequence (the round-2 form) instead of
@@ -19,8 +19,11 @@
 #define MEAO_X_BIL_WHOLE_TILE 1    // 0 = no separate copy of the bilateral phase for tiles that lie wholly inside the frame (the round-3 form):
 #endif                             // last kernel 296 -> 272 us, step 570 -> 551 us (profiles/r04_ab_bilateral_arms.jsonl)
 #ifndef MEAO_X_BIL_PAIR_RCP
-#define MEAO_X_BIL_PAIR_RCP 1      // 0 = five v_rcp_f32 per UNORM8 bilateral texel (the round-4 form) instead of three (the reciprocals of a tap
-#endif                             // pair from one reciprocal of their product, bilateral_upsample_r8<PAIRED>); variant library `nopair`
+#define MEAO_X_BIL_PAIR_RCP 0      // 1 = three v_rcp_f32 per UNORM8 bilateral texel instead of five (the reciprocals of a tap pair from one reciprocal
+#endif                             // of their product, bilateral_upsample_r8<PAIRED>; variant library `pair`).  Proven and device-checked like the
+                                   // five-reciprocal form, -5.5 % on the instruction mix in isolation -- and nothing in the kernels: last kernel
+                                   // 269.6 vs 269.4 us, full-resolution pass 170.7 vs 170.3 us, L2->L1 54.9 vs 53.5 us per 16 frames (the exact
+                                   // path can no longer start from the estimate's reciprocals): profiles/r05_ab_pair_rcp.jsonl
 #ifndef MEAO_X_HOT_PATH_ONLY
 #define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
 #endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the

@@ -1,9 +1,13 @@
-// meao_k_render_depth.hip -- one frame per call (AmbientOcclusion.cs:329-347, the reference's own calling pattern): the render
-// pass fills its windows from the caller's RAW depth buffer (render_tile<FROM_DEPTH>), so it does not wait for the downsample
-// pass -- and the downsample pass rides in the SAME launch as extra workgroups behind the render ones.  A call is then
-// render + downsample | blend passes | full-resolution pass: three dependent launches instead of four, and the streaming pass
-// overlaps the VALU-bound one.  For batched throughput the stored-mip form stays (the window fill costs ~8 VALU instructions per
-// window texel more here, and a batch carries its downsample pass inside the previous call's last kernel anyway).
+// meao_k_render_depth.hip -- an OPTION (meao_debug_set MEAO_DEBUG_RENDER_FROM_DEPTH, off by default), built for the reference's
+// own calling pattern, one frame per call (AmbientOcclusion.cs:329-347): the render pass fills its windows from the caller's RAW
+// depth buffer (render_tile<FROM_DEPTH>), so it does not wait for the downsample pass, and the downsample pass can ride in the
+// SAME launch as extra workgroups behind the render ones -- render + downsample | blend passes | full-resolution pass: three
+// dependent launches instead of four.  Bit-exact (every launch-structure test runs it), and measured NOT faster: a window of
+// LowDepth<k> gathered from the raw frame touches 2^k times the cache lines of the stored mip (L1: every other texel of every other
+// row), so the merged launch takes 33.0 us for a 4K frame where the two separate launches take 15.4 + 18.6 us, the call 61.0 us
+// against 60.4 (1080p: 33.4 against 30.9); as two launches on two streams the event hand-overs cost more than the overlap gains
+// (86 us).  profiles/r05_from_depth_sweep.jsonl, LABNOTES.md round 5.  Kept as a tested launch structure; the default stays the
+// stored-mip sequence.
 #include "meao_dev_render.hpp"
 #include "meao_dev_downsample.hpp"
 

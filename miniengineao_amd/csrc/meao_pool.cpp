@@ -19,6 +19,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -45,7 +46,9 @@ struct PoolWorker {
     {
         (void)hipSetDevice(device);
         for (;;) {
-            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+            // (a stream of 4K steps posts a job every ~60 us per member; 100 us of spinning covers that and gives the core
+            // back soon after the stream ends -- the host may be running CPU work next to the pool)
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
             int st;
             while ((st = state.load(std::memory_order_acquire)) != 1 && st != 3) {
                 if (std::chrono::steady_clock::now() > spin_until) {
@@ -86,6 +89,7 @@ struct PoolWorker {
 
 struct meao_pool {
     std::vector<std::unique_ptr<PoolWorker>> worker;      // started by the first DEVICE batch of a pool with several members
+    bool workers_unavailable = false;                     // thread creation failed once: this pool enqueues serially
     std::vector<meao_ctx *> ctx;
     std::vector<int32_t> device;
     std::vector<hipStream_t> stream;
@@ -138,13 +142,26 @@ int32_t for_each_member(meao_pool *p, const std::function<int32_t(int32_t)> &fn,
         }
         return status;
     }
+    if (p->worker.empty() && !p->workers_unavailable) {
+        try {
+            for (int32_t m = 0; m < G; ++m) {
+                p->worker.emplace_back(new PoolWorker());
+                p->worker.back()->device = p->device[m];
+                PoolWorker *w = p->worker.back().get();
+                w->thread = std::thread([w] { w->loop(); });
+            }
+        } catch (const std::exception &) {     // std::system_error (no thread to be had) / bad_alloc: keep working, serially
+            for (auto &w : p->worker) w->quit();
+            p->worker.clear();
+            p->workers_unavailable = true;
+        }
+    }
     if (p->worker.empty()) {
         for (int32_t m = 0; m < G; ++m) {
-            p->worker.emplace_back(new PoolWorker());
-            p->worker.back()->device = p->device[m];
-            PoolWorker *w = p->worker.back().get();
-            w->thread = std::thread([w] { w->loop(); });
+            const int32_t rc = fn(m);
+            if (rc != MEAO_OK && status == MEAO_OK) { status = rc; *failed_member = m; }
         }
+        return status;
     }
     for (int32_t m = 0; m < G; ++m) p->worker[m]->post([&fn, m] { return fn(m); });
     for (int32_t m = 0; m < G; ++m) {
@@ -315,18 +332,20 @@ int32_t meao_pool_prefetch_batch(meao_pool *p, int32_t n, const void *const *dep
         return pool_fail(p, MEAO_ERR_INVALID_ARGUMENT, "meao_pool_prefetch_batch: n must be 1..max_batch * members");
     DeviceGuard guard;
     int32_t failed = -1;
+    bool set_device_failed = false;
     // (a context with cfg.pipelined = 1 never allocates or synchronises here: this is bookkeeping, cheaper than a hand-over
     // to the workers -- and the first call of a context created without it re-allocates, which must not race anything)
     const int32_t status = for_each_member(p, [&](int32_t m) -> int32_t {
         const void *d[MEAO_MAX_BATCH];
         const int32_t k = share_of(m, G, n, depth, d);
         if (k == 0) return MEAO_OK;
-        if (hipSetDevice(p->device[m]) != hipSuccess) { (void)hipGetLastError(); return MEAO_ERR_HIP; }
+        if (hipSetDevice(p->device[m]) != hipSuccess) { (void)hipGetLastError(); set_device_failed = true; return MEAO_ERR_HIP; }
         return meao_prefetch_batch(p->ctx[m], k, d);
     }, false, &failed);
-    if (status != MEAO_OK)
+    if (status != MEAO_OK)       // (a failed hipSetDevice never reached the context: its last error would name an older failure)
         return pool_fail(p, status, std::string("meao_pool_prefetch_batch: member ") + std::to_string(failed) + ": " +
-                                        meao_last_error(p->ctx[failed]));
+                                        (set_device_failed ? "hipSetDevice(" + std::to_string(p->device[failed]) + ") failed"
+                                                           : std::string(meao_last_error(p->ctx[failed]))));
     return MEAO_OK;
 }
 
@@ -350,6 +369,20 @@ int32_t meao_pool_composite_enqueue(meao_pool *p, int32_t mode, int32_t n, const
             return pool_fail(p, rc, std::string("meao_pool_composite_enqueue: member ") + std::to_string(m) + ": " +
                                         meao_last_error(p->ctx[m]));
     }
+    return MEAO_OK;
+}
+
+int32_t meao_pool_composite_pending(const meao_pool *p, int32_t *out_frames)
+{
+    if (!p || !out_frames) return MEAO_ERR_INVALID_ARGUMENT;
+    int32_t total = 0;
+    for (size_t m = 0; m < p->ctx.size(); ++m) {
+        int32_t k = 0;
+        const int32_t rc = meao_composite_pending(p->ctx[m], &k);
+        if (rc != MEAO_OK) return rc;
+        total += k;
+    }
+    *out_frames = total;
     return MEAO_OK;
 }
 
@@ -401,7 +434,8 @@ int32_t meao_pool_synchronize(meao_pool *p)
     if (!p) return MEAO_ERR_INVALID_ARGUMENT;
     DeviceGuard guard;
     for (size_t i = 0; i < p->ctx.size(); ++i) {
-        if (hipSetDevice(p->device[i]) != hipSuccess || hipStreamSynchronize(p->stream[i]) != hipSuccess) {
+        // meao_synchronize also waits for a downsample pass the member put on its side stream (MEAO_DEBUG_DS_SIDE_STREAM)
+        if (hipSetDevice(p->device[i]) != hipSuccess || meao_synchronize(p->ctx[i], p->stream[i]) != MEAO_OK) {
             (void)hipGetLastError();
             return pool_fail(p, MEAO_ERR_HIP, "meao_pool_synchronize: stream synchronisation failed");
         }

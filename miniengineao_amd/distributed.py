@@ -29,7 +29,9 @@ _free_port = free_port
 def init(backend: str = "nccl", device: "torch.device | None" = None) -> Tuple[int, int, int]:
     """Initialise the default process group when WORLD_SIZE > 1.  Returns (rank, world, local_rank)."""
     rank, world, local_rank = env_world()
-    force = os.environ.get("MEAO_FORCE_DIST") == "1"     # exercise the collective path with one rank
+    # one rank still gets a group when a launcher started it (torch.distributed.run exports WORLD_SIZE; `bench.py --gpus 1
+    # --launcher`) or on request: the collective path -- RCCL communicator, barrier, all_reduce, all_gather -- with a single rank
+    force = os.environ.get("MEAO_FORCE_DIST") == "1" or "TORCHELASTIC_RUN_ID" in os.environ
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
@@ -67,6 +69,13 @@ def max_over_ranks(value: float, device: "torch.device | None" = None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=_tensor_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def group_info() -> dict:
+    """What the collectives of this process go through: nothing (single process, no group), or a group of `backend`."""
+    if not dist.is_initialized():
+        return {"initialized": False, "backend": None, "world": 1}
+    return {"initialized": True, "backend": str(dist.get_backend()), "world": dist.get_world_size()}
 
 
 def world_size() -> int:

@@ -66,7 +66,7 @@ def checksum(arr: np.ndarray) -> int:
         return int(np.bitwise_xor.reduce(mixed) ^ np.uint64(len(b)))
 
 
-# ---- hostile depth inputs (tests/test_hostile_depth.py, tests/fuzz_gpu.py)
+# ---- hostile depth inputs (tests/test_hostile_depth.py, tools/fuzz_gpu.py)
 
 def nan_aware_equal(got, want):
     if got.dtype == np.float32:

@@ -95,3 +95,43 @@ def test_rccl_two_ranks_when_two_gpus_are_visible():
     line = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "1"] + flags)
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["devices_shared"] is False and line["world_seen_by_rccl"] == 2
     assert line["validation"]["mismatching_frames"] == 0 and line["validation"]["distinct_checksums"] == 2
+
+
+# ---- round 5: the 8-GPU command path rehearsed on one GPU (readiness, not a curve: VERDICT r4 next #7) ----------------
+
+@pytest.mark.gpu
+def test_one_rank_through_the_launcher_with_a_real_rccl_group():
+    """`bench.py --gpus 1 --launcher`: the script re-launches itself under torch.distributed.run exactly as for N > 1, the
+    rank creates an RCCL communicator on its device (backend "nccl"), and the fences, the MAX over ranks, the per-rank
+    times and the checksum gather of the run go through it.  world_seen_by_rccl == 1 alone would also be true with no
+    group at all -- process_group_in_use says which it was."""
+    flags = [f for f in BENCH_FLAGS if f not in ("--dist-backend", "gloo")]
+    line = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launcher", "--batch", "2",
+                      "--no-other-workloads", "--no-best-host-config"] + flags)
+    assert line["process_group_in_use"] == {"initialized": True, "backend": "nccl", "world": 1}
+    assert line["world_seen_by_rccl"] == 1 and line["n_gpus"] == 1 and line["ranks"] == 1
+    assert line["config"]["process_group"] == "nccl"
+    assert line["validation"]["mismatching_frames"] == 0 and line["validation"]["frames_checksummed"] == 2
+
+
+@pytest.mark.gpu
+def test_without_a_launcher_there_is_no_group():
+    line = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "1", "--no-other-workloads",
+                      "--no-best-host-config"] + [f for f in BENCH_FLAGS if f not in ("--dist-backend", "gloo")])
+    assert line["process_group_in_use"] == {"initialized": False, "backend": None, "world": 1}
+    assert line["config"]["process_group"] is None
+
+
+@pytest.mark.gpu
+def test_eight_pool_members_one_frame_each_is_baseline_config_4_in_process():
+    """BASELINE config 4 through the in-process host (meao_pool_*): eight members, one 4K frame per member per step, every
+    member's frame validated against the oracle.  All members sit on device 0 here (their kernels time-share: the value
+    is not a scaling number); on an 8-GPU node the same command puts member m on device m."""
+    line = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--pool", "8", "--batch", "1", "--workload", "4k",
+                      "--steps", "3", "--warmup", "1", "--min-time-ms", "0"])
+    assert line["pool_members"] == 8 and line["config"]["frames_per_step_per_member"] == 1
+    assert len(line["per_member_ms"]) == 8 and all(ms > 0 for ms in line["per_member_ms"])
+    v = line["validation"]
+    assert v["frames_checksummed"] == 8 and v["distinct_checksums"] == 8
+    assert v["frames_vs_oracle"] == 8 and v["mismatching_frames"] == 0          # first and last frame of every member = its one frame
+    assert len(line["gather_paths"]) == 8

@@ -417,24 +417,24 @@ def test_render_from_the_raw_depth_frame_is_bit_exact(oracle, form, small_tiles,
         ao.close()
 
 
-def test_render_from_depth_is_chosen_by_call_size_and_falls_back(oracle):
-    """The default (RENDER_FROM_DEPTH 3): small calls take the one-launch form -- no separate downsample launch is timed --
-    large ones, pipelined ones and non-f32 depth keep the stored-mip form; results identical either way."""
+def test_render_from_depth_is_an_option_and_falls_back(oracle):
+    """The default is the stored-mip sequence (a separate downsample launch is timed); RENDER_FROM_DEPTH 3 lets small calls take the
+    one-launch form -- no separate downsample time -- while larger ones and non-f32 depth keep the stored-mip form; results
+    identical either way."""
     w, h = 640, 360
     s = H.settings(oracle, w, h)
     depth = synth.make("S2", w, h, seed=3)
     want = oracle.run(depth, s, result_only=True)["result"]
     ao = H.component(s)
     try:
-        ao.set_profiling(True)
-        assert np.array_equal(ao.render(depth), want)
-        ms = dict(zip(L.PASS_NAMES, ao.pass_times_ms()[0]))
-        assert ms["downsample"] == 0 and ms["render"] > 0, ms          # the pass rode in the render launch
-        ao.debug_set(L.DEBUG_RENDER_FROM_DEPTH_MAX_TILES, 1)           # "too large": stored mips
-        ao.set_profiling(True)
-        assert np.array_equal(ao.render(depth), want)
-        ms = dict(zip(L.PASS_NAMES, ao.pass_times_ms()[0]))
-        assert ms["downsample"] > 0 and ms["render"] > 0, ms
+        for mode, max_tiles, rides_in_render in ((None, None, False), (3, 1024, True), (3, 1, False), (1, 1, True), (0, 1024, False)):
+            if mode is not None:
+                ao.debug_set(L.DEBUG_RENDER_FROM_DEPTH, mode)
+                ao.debug_set(L.DEBUG_RENDER_FROM_DEPTH_MAX_TILES, max_tiles)
+            ao.set_profiling(True)
+            assert np.array_equal(ao.render(depth), want)
+            ms = dict(zip(L.PASS_NAMES, ao.pass_times_ms()[0]))
+            assert (ms["downsample"] == 0) == rides_in_render and ms["render"] > 0, (mode, max_tiles, ms)
     finally:
         ao.close()
     s16 = H.settings(oracle, w, h, depth_format=oracle.DEPTH_UNORM16)
@@ -462,7 +462,9 @@ def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
     db = [torch.from_numpy(f).to(dev) for f in b_frames]
     out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
     s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    ao = H.component(s, max_batch=2, pipelined=True)
+    # (RENDER_FROM_DEPTH 0: a call this small would otherwise run its own pass inside the render launch, where no separate
+    # downsample time exists to observe)
+    ao = H.component(s, max_batch=2, pipelined=True, debug={L.DEBUG_RENDER_FROM_DEPTH: 0})
     try:
         ao.set_profiling(True)
         for consumer in (s2, s1):                      # other stream first, then the carrying stream
@@ -641,7 +643,7 @@ def test_carried_downsample_split_between_blend_and_last_kernel(oracle, share, w
     dd = [[torch.from_numpy(f).to(dev) for f in b] for b in seqs]
     out = [[torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in b] for b in seqs]
     st = torch.cuda.current_stream(dev).cuda_stream
-    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_SHARE_IN_BLEND: share})
+    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_SHARE_IN_BLEND: share, L.DEBUG_RENDER_FROM_DEPTH: 0})
     try:
         ao.set_profiling(True)
         for k in range(3):

@@ -1,4 +1,4 @@
-"""Every variant library that tests/build_variants.py left under miniengineao_amd/lib/variants/ (experimental -D arms
+"""Every variant library that tools/build_variants.py left under miniengineao_amd/lib/variants/ (experimental -D arms
 of meao_kernels.hip, A/B candidates) must pass the same parity smoke as the product: an arm that stays in the
 source cannot rot unseen.  No variants built -> nothing to check."""
 import glob

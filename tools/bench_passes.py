@@ -1,5 +1,5 @@
 """Per-pass kernel times of the plain launch sequence (HIP events inside the library), for A/B runs of
-kernel variants:   MEAO_LIB_PATH=<variant .so> python tests/bench_passes.py [--workload 4k] [--steps 20]
+kernel variants:   MEAO_LIB_PATH=<variant .so> python tools/bench_passes.py [--workload 4k] [--steps 20]
 Prints one JSON line {pass: us per launch, ..., "step_us": wall per step, "ok": results match the oracle}."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """Builds kernel variants of libmeao_hip.so next to the product library for A/B runs on one GPU box:
-    python tests/build_variants.py name=-DFLAG[,-DFLAG2] ...      ->  miniengineao_amd/lib/variants/libmeao_<name>.so"""
+    python tools/build_variants.py name=-DFLAG[,-DFLAG2] ...      ->  miniengineao_amd/lib/variants/libmeao_<name>.so"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concurrent.futures import ThreadPoolExecutor

@@ -1,8 +1,8 @@
-# usage: bash tests/collect_round.sh <tag> [frames-per-launch=16]   (here, after `gpurun ... tests/run_gpu_round.sh <tag>`)
+# usage: bash tools/collect_round.sh <tag> [frames-per-launch=16]   (here, after `gpurun ... tools/run_gpu_round.sh <tag>`)
 # copies the judged evidence of a round from gpurun_out/ (scratch) into profiles/ (tracked)
 set -e
 T=$1; N=${2:-16}
-python tests/rocprof_timed_region.py gpurun_out/prof_$T/trace_kernel_trace.csv 30 > profiles/${T}_kernel_trace_timed_region.txt
+python tools/rocprof_timed_region.py gpurun_out/prof_$T/trace_kernel_trace.csv 30 > profiles/${T}_kernel_trace_timed_region.txt
 cp gpurun_out/prof_$T/trace_kernel_stats.csv profiles/${T}_kernel_stats.csv
 cp gpurun_out/bench_$T.json profiles/${T}_bench_4k_batch16.json
 cp gpurun_out/bench_${T}_1080p.json profiles/${T}_bench_1080p_batch64.json
@@ -19,6 +19,6 @@ cp gpurun_out/ubench_lds_$T.txt profiles/${T}_ubench_lds.txt
 for f in pool2 pool3; do [ -f gpurun_out/bench_${T}_$f.log ] && grep '^{' gpurun_out/bench_${T}_$f.log > profiles/${T}_bench_4k_$f.json; done
 for f in plain pipelined; do [ -f gpurun_out/phase_clocks_${f}_$T.json ] && cp gpurun_out/phase_clocks_${f}_$T.json profiles/${T}_phase_clocks_$f.json; done
 [ -f gpurun_out/ubench_launch_$T.txt ] && cp gpurun_out/ubench_launch_$T.txt profiles/${T}_ubench_launch.txt
-python tests/pmc_summary.py gpurun_out/pmc_$T > profiles/${T}_pmc_summary.txt
-python tests/make_pmc_traffic.py gpurun_out/pmc_$T 4k $N > /dev/null
+python tools/pmc_summary.py gpurun_out/pmc_$T > profiles/${T}_pmc_summary.txt
+python tools/make_pmc_traffic.py gpurun_out/pmc_$T 4k $N > /dev/null
 ls -la profiles/${T}_*

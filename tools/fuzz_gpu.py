@@ -1,5 +1,5 @@
 """Long randomized GPU-vs-oracle sweep (not part of the default suite; run on demand):
-    python tests/fuzz_gpu.py [count] [seed0]
+    python tools/fuzz_gpu.py [count] [seed0]
 Emphasises the vector fast paths (widths that are multiples of 4 / 8 / 64) and tile-edge cases."""
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where an upsample workgroup's time goes (diagnostic build -DMEAO_X_PHASE_CLOCKS=1):
-    python tests/build_variants.py clocks=-DMEAO_X_PHASE_CLOCKS=1
+    python tools/build_variants.py clocks=-DMEAO_X_PHASE_CLOCKS=1
     MEAO_LIB_PATH=$PWD/miniengineao_amd/lib/variants/libmeao_clocks.so python tools/phase_clocks.py [--workload 4k] [--pipeline]
 Every wave of every upsample tile stamps s_memrealtime (100 MHz) at its phase boundaries; the table is the mean
 time per wave and phase over all upsample launches of the timed steps (all four passes pooled: run with

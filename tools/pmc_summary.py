@@ -1,6 +1,6 @@
-"""Per-kernel means of every counter in a tests/run_pmc.sh output directory.
+"""Per-kernel means of every counter in a tools/run_pmc.sh output directory.
 
-    python tests/pmc_summary.py gpurun_out/pmc_<tag>
+    python tools/pmc_summary.py gpurun_out/pmc_<tag>
 """
 import collections
 import csv

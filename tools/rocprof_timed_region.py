@@ -2,7 +2,7 @@
 "the last N launches" (= bench.py's timed region: the process also runs an untimed clock-ramp phase
 and the warm-up steps first, which the --stats average includes).
 
-    python tests/rocprof_timed_region.py gpurun_out/prof_<tag>/trace_kernel_trace.csv [N=30]
+    python tools/rocprof_timed_region.py gpurun_out/prof_<tag>/trace_kernel_trace.csv [N=30]
 """
 import collections
 import csv

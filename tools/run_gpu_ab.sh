@@ -1,4 +1,4 @@
-# A/B on one box: bench.py with two flag sets, alternating, 3 runs each.   bash tests/run_gpu_ab.sh TAG "flagsA" "flagsB"
+# A/B on one box: bench.py with two flag sets, alternating, 3 runs each.   bash tools/run_gpu_ab.sh TAG "flagsA" "flagsB"
 TAG=$1; A=$2; B=$3
 mkdir -p gpurun_out
 for i in 1 2 3; do

@@ -14,9 +14,9 @@ timeout 600 python bench.py --pool 2 > gpurun_out/bench_${TAG}_pool2.log 2>&1
 timeout 600 python bench.py --pool 3 --batch 8 > gpurun_out/bench_${TAG}_pool3.log 2>&1
 MEAO_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --skip-latency --no-other-workloads --min-time-ms 100 > gpurun_out/bench_force_dist_$TAG.log 2>&1
 timeout 600 python bench.py --shaded --no-cpu-baseline --skip-latency --no-other-workloads 2>/dev/null | grep '^{' > gpurun_out/bench_${TAG}_shaded.json
-timeout 600 python tests/fuzz_gpu.py 200 12000 > gpurun_out/fuzz_$TAG.log 2>&1
-bash tests/run_rocprof.sh $TAG > gpurun_out/rocprof_$TAG.log 2>&1
-bash tests/run_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
+timeout 600 python tools/fuzz_gpu.py 200 12000 > gpurun_out/fuzz_$TAG.log 2>&1
+bash tools/run_rocprof.sh $TAG > gpurun_out/rocprof_$TAG.log 2>&1
+bash tools/run_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
 MEAO_LIB_PATH=$PWD/miniengineao_amd/lib/variants/libmeao_clocks.so timeout 300 python tools/phase_clocks.py 2>/dev/null > gpurun_out/phase_clocks_plain_$TAG.json
 MEAO_LIB_PATH=$PWD/miniengineao_amd/lib/variants/libmeao_clocks.so timeout 300 python tools/phase_clocks.py --pipeline 2>/dev/null > gpurun_out/phase_clocks_pipelined_$TAG.json
 timeout 300 miniengineao_amd/lib/ubench_issue 5.0 > gpurun_out/ubench_issue_$TAG.txt 2>&1

@@ -1,4 +1,4 @@
-# usage: [PMC_GROUPS="sq1 sq5"] bash tests/run_pmc.sh <tag> [bench args...]   -- PMC passes, one counter group per run
+# usage: [PMC_GROUPS="sq1 sq5"] bash tools/run_pmc.sh <tag> [bench args...]   -- PMC passes, one counter group per run
 set -x
 TAG=${1:-r01}; shift
 REPO=$(pwd)
@@ -16,5 +16,5 @@ run sq5 SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 cd $REPO
-python tests/pmc_summary.py $OUT
+python tools/pmc_summary.py $OUT
 find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete

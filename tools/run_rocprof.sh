@@ -1,4 +1,4 @@
-# usage: bash tests/run_rocprof.sh <tag> [bench args...]   (on the GPU box, via gpurun)
+# usage: bash tools/run_rocprof.sh <tag> [bench args...]   (on the GPU box, via gpurun)
 set -x
 TAG=${1:-r01}; shift
 REPO=$(pwd)
