@@ -753,8 +753,8 @@ def main() -> int:
             kw = dict(kw)
             debug = kw.pop("_debug", {})
             c = one_frame_ctx(**kw)
-            for key, value in debug.items():
-                c.debug_set(key, value)
+            for debug_key, debug_value in debug.items():
+                c.debug_set(debug_key, debug_value)
             for sync_each in (False, True):
                 for _ in range(3):
                     if name == "direct_pipelined":
@@ -849,6 +849,11 @@ def main() -> int:
             "other_workloads": others,
             "best_host_config": best_host,
         }
+        # the headline must be what the clock says: pixels of the timed region / its duration (round 5: a loop variable named
+        # `value` once overwrote it between here and its computation -- caught by reading the line, now caught by the script)
+        implied = float(w) * h * B * world / (line["ms_per_step"] * 1e-3) / 1e6
+        if abs(line["value"] - implied) > 0.002 * implied:
+            raise SystemExit(f"bench.py: value {line['value']} disagrees with pixels / ms_per_step = {implied:.1f}")
         print(json.dumps(line), flush=True)
     mdist.shutdown()
     return 0

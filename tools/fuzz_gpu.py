@@ -57,6 +57,9 @@ for k in range(count):
                           pipelined=bool(k % 2))
     ao.noiseFilterTolerance, ao.blurTolerance, ao.upsampleTolerance = s.noise_filter_tolerance, s.blur_tolerance, s.upsample_tolerance
     ao.thicknessModifier, ao.intensity = s.thickness_modifier, s.intensity
+    if k % 3 == 2:          # a third of the cases: render windows from the RAW depth frame (one launch with the pass / two streams)
+        from miniengineao_amd import _lib
+        ao.debug_set(_lib.DEBUG_RENDER_FROM_DEPTH, 1 + (k // 3) % 2)
     outs = ao.render_batch([depth, depth])
     ok = same(outs[0], want["result"]) and same(outs[1], want["result"])
     for i in H.valid_debug_ids(s.num_levels, s.hq_levels):

@@ -16,7 +16,8 @@ _CACHE = os.path.join(tempfile.gettempdir(), "meao_kernel_isa")
 
 def asm_text(flags):
     src = os.path.join(ROOT, "miniengineao_amd", "csrc", "meao_kernels.hip")
-    key = str(abs(hash((os.path.getmtime(src), os.path.getmtime(src.replace(".hip", ".hpp")), tuple(flags)))))
+    csrc = os.path.dirname(src)       # the unity file includes every kernel unit and device header: any of them invalidates the cache
+    key = str(abs(hash((max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)), tuple(flags)))))
     out = os.path.join(_CACHE, key + ".s")
     if not os.path.exists(out):
         os.makedirs(_CACHE, exist_ok=True)

@@ -22,7 +22,11 @@ def counters(group, counter):
 
 
 def known_bytes(kernel):
-    return BYTES // 256 * 160 if "read_window_kernel" in kernel else BYTES
+    if "read_window_kernel" in kernel:
+        return BYTES // 256 * 160
+    if "tile_rows_kernel" in kernel:        # image-shaped streams: 3840 x 262144 bytes (write), 7680 x 131072 (read)
+        return 3840 * 262144
+    return BYTES
 
 
 rows = []

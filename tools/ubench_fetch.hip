@@ -68,6 +68,31 @@ __global__ __launch_bounds__(256) void read_window_kernel(const float4v *__restr
     if (acc == 1234.5678f) *sink = acc;
 }
 
+// The full-resolution pass's output pattern: a lane stores 4 bytes, 16 lanes make one 64-byte row segment, consecutive groups of 16
+// lanes go to the NEXT ROW of a W-byte-pitch image (a 64 x 4 texel block per wave); every byte of the image is written once.
+__global__ __launch_bounds__(256) void write_tile_rows_kernel(uchar4v *__restrict__ dst, int w_bytes, int h, uchar4v value, bool nt)
+{
+    // workgroup = a 64-byte x 16-row block; blocks tile the image
+    const int blocks_x = w_bytes / 64;
+    for (int b = blockIdx.x; b < blocks_x * (h / 16); b += gridDim.x) {
+        const int x = (b % blocks_x) * 64 + (threadIdx.x & 15) * 4, y = (b / blocks_x) * 16 + (threadIdx.x >> 4);
+        uchar4v *p = dst + (static_cast<size_t>(y) * w_bytes + x) / 4;
+        if (nt) __builtin_nontemporal_store(value, p);
+        else *p = value;
+    }
+}
+// and its f16 depth input: 8 bytes per lane, 16 lanes = one 128-byte row segment, next group of lanes = next row
+__global__ __launch_bounds__(256) void read_tile_rows_kernel(const ushort4v *__restrict__ src, int w_bytes, int h, float *sink)
+{
+    const int blocks_x = w_bytes / 128;
+    float acc = 0.0f;
+    for (int b = blockIdx.x; b < blocks_x * (h / 16); b += gridDim.x) {
+        const int x = (b % blocks_x) * 128 + (threadIdx.x & 15) * 8, y = (b / blocks_x) * 16 + (threadIdx.x >> 4);
+        acc += fold<ushort4v>(__builtin_nontemporal_load(src + (static_cast<size_t>(y) * w_bytes + x) / 8));
+    }
+    if (acc == 1234.5678f) *sink = acc;
+}
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <typename K>
@@ -116,6 +141,14 @@ int main(int argc, char **argv)
     WRITE(float2v, true, (float2v{0, 0}), "write_8B_per_lane_nt");
     WRITE(float4v, false, (float4v{0, 0, 0, 0}), "write_16B_per_lane");
     WRITE(float4v, true, (float4v{0, 0, 0, 0}), "write_16B_per_lane_nt");
+    // image-shaped streams (pitch 3840 / 7680 bytes, rows as the upsample tiles touch them); 1 GiB = 3840 x 279620 rows -> use 3840 x 262144
+    const int img_h = 262144;
+    rc |= timed("write_64B_row_segments_4B_per_lane", static_cast<size_t>(3840) * img_h,
+                [&] { write_tile_rows_kernel<<<grid, block>>>(static_cast<uchar4v *>(buf), 3840, img_h, uchar4v{0, 0, 0, 0}, false); });
+    rc |= timed("write_64B_row_segments_4B_per_lane_nt", static_cast<size_t>(3840) * img_h,
+                [&] { write_tile_rows_kernel<<<grid, block>>>(static_cast<uchar4v *>(buf), 3840, img_h, uchar4v{0, 0, 0, 0}, true); });
+    rc |= timed("read_128B_row_segments_8B_per_lane_nt", static_cast<size_t>(7680) * (img_h / 2),
+                [&] { read_tile_rows_kernel<<<grid, block>>>(static_cast<const ushort4v *>(buf), 7680, img_h / 2, sink); });
     CHECK(hipDeviceSynchronize());
     return rc;
 }
