@@ -417,6 +417,32 @@ def test_render_from_the_raw_depth_frame_is_bit_exact(oracle, form, small_tiles,
         ao.close()
 
 
+@pytest.mark.parametrize("form", [1, 2])
+def test_render_from_depth_inside_a_captured_launch_sequence(oracle, form):
+    """MEAO_LAUNCH_GRAPH with the raw-depth render: the captured sequence is the one-launch form (form 2 would fork to a second
+    stream; a captured sequence stays on one) and replays bit-exactly, hostile frame included."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h = 644, 364
+    s = H.settings(oracle, w, h)
+    frames = [synth.make("S2", w, h, seed=11), H.hostile_frame(w, h, 12, density=0.004)]
+    want = [oracle.run(f, s, result_only=True)["result"] for f in frames]
+    dd = [torch.from_numpy(f).to(dev) for f in frames]
+    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in frames]
+    st = torch.cuda.Stream(dev)
+    ao = H.component(s, max_batch=2, launch_mode=L.LAUNCH_GRAPH, debug={L.DEBUG_RENDER_FROM_DEPTH: form})
+    try:
+        for _ in range(3):                      # capture, replay, replay
+            ao.execute_device([t.data_ptr() for t in dd], [t.data_ptr() for t in out], st.cuda_stream)
+            st.synchronize()
+            for f in range(2):
+                ok, bad = H.nan_aware_equal(out[f].cpu().numpy(), want[f])
+                assert ok, (f, int(bad.sum()))
+            assert ao.hostile_frames() == 2
+    finally:
+        ao.close()
+
+
 def test_render_from_depth_is_an_option_and_falls_back(oracle):
     """The default is the stored-mip sequence (a separate downsample launch is timed); RENDER_FROM_DEPTH 3 lets small calls take the
     one-launch form -- no separate downsample time -- while larger ones and non-f32 depth keep the stored-mip form; results
