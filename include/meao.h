@@ -417,7 +417,8 @@ typedef enum meao_debug_key {
                                         * (1 = the full-resolution upsample launch, 2 = L2 -> L1, 3 = the coarse blend launch, 4 = render);
                                         * shape 0..4 = loads in flight per lane {16 + 120 VGPRs declared, 16, 8, 4, 8 + 120 VGPRs declared};
                                         * + 100 * p: stream priority p = 0 lowest, 1 default, 2 highest; + 1000 * s + 10000 * b: only the
-                                        * first s tenths of the frames at `gate`, the rest at gate b (default 1).  Results identical. */
+                                        * first s tenths of the frames at `gate`, the rest at gate b (default 1; b = 5: the rest rides in the last kernel, the
+                                        * default fused form).  Results identical. */
     MEAO_DEBUG_RENDER_FROM_DEPTH = 8,  /* calls that run their own downsample pass (no meao_prefetch_batch), f32 depth, 36 samples: the render
                                         * launch fills its windows from the RAW depth frame and does not wait for the downsample pass.
                                         * 0 (default) = never; 1 = always, both in ONE launch (the pass as extra workgroups behind the

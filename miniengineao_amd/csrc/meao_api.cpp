@@ -577,7 +577,9 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         side.total = ctx->next_n;
         side.gate_a = v % 10; side.shape = v / 10 % 10; side.prio = v / 100 % 10;
         side.gate_b = v / 10000 % 10 ? v / 10000 % 10 : 1;
-        side.first_part = (split == 0 || side.gate_b >= side.gate_a) ? side.total
+        // gate_b 5: the frames the side kernel does not take ride in the last kernel (the fused form) -- the HBM-bound last kernel
+        // sheds part of its carried bytes to a co-runner of the VALU-bound render launch
+        side.first_part = (split == 0 || (side.gate_b >= side.gate_a && side.gate_b != 5)) ? side.total
                                                                      : std::min(side.total, std::max(1, (side.total * split + 9) / 10));
         side.other = 1 - ctx->ds_cur;
     }
@@ -717,10 +719,15 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         const UpsampleArgs up = upsample_args(0);
         MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_0, stream));
         if (ctx->next_n > 0) {
-            // carry the downsample of the announced next batch in this (VALU-bound) kernel
+            // carry the downsample of the announced next batch in this kernel; frames [0, first) of it may already be with the
+            // side-stream kernel (MEAO_DEBUG_DS_SIDE_STREAM ... gate_b 5), then this launch carries frames [first, next_n)
             const int other = 1 - ctx->ds_cur;
-            ctx->set_gen[other] = carried_in_blend > 0 ? next_gen : next_generation();     // one generation for both carrying launches
-            DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other]);
+            const int first = side.active ? side.issued : 0;
+            if (first == 0) ctx->set_gen[other] = carried_in_blend > 0 ? next_gen : next_generation();     // one generation for all carrying launches
+            DownsampleArgs ds = downsample_args(ctx->next_n - first, ctx->next_depth + first, other, ctx->set_gen[other]);
+            ds.linear = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(ds.linear) + ctx->slot_bytes * first);
+            for (int k = 0; k < 4; ++k) ds.low[k] = reinterpret_cast<float *>(reinterpret_cast<char *>(ds.low[k]) + ctx->slot_bytes * first);
+            ds.hostile += first;
             ds.tile_begin = carried_in_blend;
             MEAO_HIP(ctx, launch_upsample_final_with_downsample(up, ds, c.ao_format, n, stream));
             ctx->ready_n = ctx->next_n;
@@ -1419,7 +1426,7 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES: ctx->render_from_depth_max_tiles = value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
-        if (value < 0 || value % 10 > 4 || (value > 0 && value % 10 == 0) || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
+        if (value < 0 || value % 10 > 4 || (value > 0 && value % 10 == 0) || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 5 || value >= 100000)
             return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");
         if (ctx->side_stream && value / 100 % 10 != ctx->ds_side_stream / 100 % 10) {       // the stream's priority is fixed at creation
             const int rc = use_device(ctx);
