@@ -42,6 +42,47 @@ __global__ __launch_bounds__(ren_tile_w(false) * 4, 6) void render_from_depth_ke
         a, tile, frame, xcd_contiguous(blockIdx.x, a.blocks_per_frame), NoRenderHook(), &d);
 }
 
+// The batched counterpart (MEAO_DEBUG_DS_SHARE_IN_RENDER): the stored-mip render of THIS batch with the first d.tile_end downsample
+// tiles of every frame of the NEXT batch (meao_prefetch_batch) as extra workgroups of the same launch, the rest of that pass
+// staying with the last upsample kernel (d.tile_begin there).  The last kernel of a pipelined step is HBM-bound (0.94 - 0.97 of the
+// copy rate), render is VALU-bound with HBM idle: bytes moved from the former to the latter cost less there than they save here --
+// and a co-runner in the SAME launch needs no second stream (the side-stream form pays 16 - 18 us per step for its two event
+// hand-overs, profiles/r05_ab_side_stream_split.jsonl).  Downsample workgroups are dealt evenly among the render ones (the
+// hardware dispatches in index order: bunched at the end they would run alone).
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_carrying_downsample_kernel(const RenderArgs a, const DownsampleArgs d)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(false) + 2 * kRenApron)];
+    const int frame = blockIdx.y;
+    const int R = a.blocks_per_frame, D = (d.tile_end + 1) / 2, total = R + D;
+    // block i is a downsample block iff floor((i + 1) D / total) > floor(i D / total); it is then downsample block floor(i D / total),
+    // otherwise render block i - floor((i + 1) D / total)
+    const int i = blockIdx.x;
+    const int q0 = static_cast<int>(static_cast<int64_t>(i) * D / total), q1 = static_cast<int>(static_cast<int64_t>(i + 1) * D / total);
+    if (q1 > q0) {
+        const int t = 2 * q0 + static_cast<int>(threadIdx.x >> 8);
+        if (t >= d.tile_end || frame >= d.frames) return;
+        const unsigned tid = threadIdx.x & 255u;
+        if (d.vec_ok) downsample_tile<RTNE, true, DIV>(d, t, frame, tid);
+        else downsample_tile<RTNE, false, DIV>(d, t, frame, tid);
+        return;
+    }
+    const int block = xcd_contiguous(i - q1, R);
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
+            render_tile<AOFMT, RTNE, DIV_IEEE, false>(a, tile, frame, block);
+            return;
+        }
+    }
+    render_tile<AOFMT, RTNE, DIV, false>(a, tile, frame, block);
+}
+
+template <int AOFMT, bool RTNE, int DIV>
+void launch_render_carrying_downsample_t(const RenderArgs &a, const DownsampleArgs &d, dim3 grid, hipStream_t s)
+{
+    render_carrying_downsample_kernel<AOFMT, RTNE, DIV><<<grid, dim3(ren_tile_w(false) * 4), 0, s>>>(a, d);
+}
+
 template <int AOFMT, bool RTNE, int DIV>
 void launch_render_from_depth_t(const RenderArgs &a, const DownsampleArgs &d, dim3 grid, hipStream_t s)
 {
@@ -74,6 +115,25 @@ hipError_t launch_render_from_depth(const RenderArgs &a, const DownsampleArgs &d
         else if (a.exact_rcp_div == 2) launch_render_from_depth_t<MEAO_AO_F16, false, DIV_FAST>(a, d, grid, s);
         else if (a.exact_rcp_div) launch_render_from_depth_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, d, grid, s);
         else launch_render_from_depth_t<MEAO_AO_F16, false, DIV_IEEE>(a, d, grid, s);
+    }
+    return hipGetLastError();
+}
+
+// Stored-mip render of this batch + downsample tiles [0, d.tile_end) of every frame of the next one (32-row tiles, 36 samples).
+hipError_t launch_render_carrying_downsample(const RenderArgs &a, const DownsampleArgs &d, int ao_format, int frames, hipStream_t s)
+{
+    if (a.exhaustive || a.tile_h != kRenTileH || d.row_passes != kDsTileH / kDsRowsPerPass || d.frames > frames) return hipErrorInvalidValue;
+    const dim3 grid(a.blocks_per_frame + (d.tile_end + 1) / 2, frames, 1);
+    if (ao_format == MEAO_AO_R8) {
+        if (a.f16_rtne) launch_render_carrying_downsample_t<MEAO_AO_R8, true, DIV_IEEE>(a, d, grid, s);
+        else if (a.exact_rcp_div == 2) launch_render_carrying_downsample_t<MEAO_AO_R8, false, DIV_FAST>(a, d, grid, s);
+        else if (a.exact_rcp_div) launch_render_carrying_downsample_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(a, d, grid, s);
+        else launch_render_carrying_downsample_t<MEAO_AO_R8, false, DIV_IEEE>(a, d, grid, s);
+    } else {
+        if (a.f16_rtne) launch_render_carrying_downsample_t<MEAO_AO_F16, true, DIV_IEEE>(a, d, grid, s);
+        else if (a.exact_rcp_div == 2) launch_render_carrying_downsample_t<MEAO_AO_F16, false, DIV_FAST>(a, d, grid, s);
+        else if (a.exact_rcp_div) launch_render_carrying_downsample_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, d, grid, s);
+        else launch_render_carrying_downsample_t<MEAO_AO_F16, false, DIV_IEEE>(a, d, grid, s);
     }
     return hipGetLastError();
 }
