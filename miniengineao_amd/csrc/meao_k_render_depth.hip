@@ -54,20 +54,26 @@ __global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_carrying_down
 {
     __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(false) + 2 * kRenApron)];
     const int frame = blockIdx.y;
-    const int R = a.blocks_per_frame, D = (d.tile_end + 1) / 2, total = R + D;
-    // block i is a downsample block iff floor((i + 1) D / total) > floor(i D / total); it is then downsample block floor(i D / total),
-    // otherwise render block i - floor((i + 1) D / total)
-    const int i = blockIdx.x;
-    const int q0 = static_cast<int>(static_cast<int64_t>(i) * D / total), q1 = static_cast<int>(static_cast<int64_t>(i + 1) * D / total);
+    // Workgroups are dealt in OCTETS (ids 8g .. 8g + 7 land on the 8 XCDs): an octet is all render or all downsample, so that render
+    // workgroup number r keeps r = id (mod 8) -- what xcd_contiguous needs to put neighbouring tiles, which share their aprons, on
+    // one XCD's L2.  (Dealt one by one the render tiles lost that: +36 us on the launch for a 20 % share.)
+    const int R = a.blocks_per_frame, D = (d.tile_end + 1) / 2;
+    const int Rg = (R + 7) >> 3, Dg = (D + 7) >> 3, groups = Rg + Dg;
+    const int i = blockIdx.x, g = i >> 3, lane8 = i & 7;
+    // octet g is a downsample octet iff floor((g + 1) Dg / groups) > floor(g Dg / groups); it is then downsample octet floor(g Dg / groups),
+    // otherwise render octet g - floor((g + 1) Dg / groups)
+    const int q0 = static_cast<int>(static_cast<int64_t>(g) * Dg / groups), q1 = static_cast<int>(static_cast<int64_t>(g + 1) * Dg / groups);
     if (q1 > q0) {
-        const int t = 2 * q0 + static_cast<int>(threadIdx.x >> 8);
+        const int t = 2 * (8 * q0 + lane8) + static_cast<int>(threadIdx.x >> 8);
         if (t >= d.tile_end || frame >= d.frames) return;
         const unsigned tid = threadIdx.x & 255u;
         if (d.vec_ok) downsample_tile<RTNE, true, DIV>(d, t, frame, tid);
         else downsample_tile<RTNE, false, DIV>(d, t, frame, tid);
         return;
     }
-    const int block = xcd_contiguous(i - q1, R);
+    const int r = 8 * (g - q1) + lane8;
+    if (r >= R) return;
+    const int block = xcd_contiguous(r, R);
     if constexpr (DIV == DIV_EXACT_RCP) {
         if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
             render_tile<AOFMT, RTNE, DIV_IEEE, false>(a, tile, frame, block);
@@ -123,7 +129,7 @@ hipError_t launch_render_from_depth(const RenderArgs &a, const DownsampleArgs &d
 hipError_t launch_render_carrying_downsample(const RenderArgs &a, const DownsampleArgs &d, int ao_format, int frames, hipStream_t s)
 {
     if (a.exhaustive || a.tile_h != kRenTileH || d.row_passes != kDsTileH / kDsRowsPerPass || d.frames > frames) return hipErrorInvalidValue;
-    const dim3 grid(a.blocks_per_frame + (d.tile_end + 1) / 2, frames, 1);
+    const dim3 grid(8 * (((a.blocks_per_frame + 7) >> 3) + ((((d.tile_end + 1) / 2) + 7) >> 3)), frames, 1);      // whole octets
     if (ao_format == MEAO_AO_R8) {
         if (a.f16_rtne) launch_render_carrying_downsample_t<MEAO_AO_R8, true, DIV_IEEE>(a, d, grid, s);
         else if (a.exact_rcp_div == 2) launch_render_carrying_downsample_t<MEAO_AO_R8, false, DIV_FAST>(a, d, grid, s);
