@@ -122,22 +122,17 @@ def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
         return None
 
 
-def pass_table(ao, pass_ms, B, pipelined, ds_share_in_render=0.0):
-    """Per-launch roofline rows: algorithmic bytes of what each launch carries / its HIP-event duration.
-    ds_share_in_render: fraction of the next step's downsample tiles that rides in the render launch (--ds-share-in-render)."""
+def pass_table(ao, pass_ms, B, pipelined):
+    """Per-launch roofline rows: algorithmic bytes of what each launch carries / its HIP-event duration."""
     alg = ao.algorithmic_bytes()                 # per frame, reference storage formats
     names = list(_lib.PASS_NAMES)
     if pipelined:
-        # the downsample pass of the next step runs inside the last upsample kernel (and, with a share, the render launch):
-        # its bytes move there
-        u0, d0, r0 = names.index("upsample_L1_to_L0"), names.index("downsample"), names.index("render")
+        # the downsample pass of the next step runs inside the last upsample kernel: its bytes move there
+        u0, d0 = names.index("upsample_L1_to_L0"), names.index("downsample")
         if pass_ms[d0] <= 0:
-            alg[r0] += int(alg[d0] * ds_share_in_render)
-            alg[u0] += alg[d0] - int(alg[d0] * ds_share_in_render)
+            alg[u0] += alg[d0]
             alg[d0] = 0
-            names[u0] = "upsample_L1_to_L0+downsample_next" if ds_share_in_render < 1.0 else "upsample_L1_to_L0"
-            if ds_share_in_render > 0:
-                names[r0] = "render+%d%%_of_downsample_next" % round(100 * ds_share_in_render)
+            names[u0] = "upsample_L1_to_L0+downsample_next"
     u3, u2 = names.index("upsample_L4_to_L3"), names.index("upsample_L3_to_L2")
     if pass_ms[u3] <= 0 < pass_ms[u2]:
         # the library evaluates L4 -> L3 inside the L3 -> L2 launch (upsample_two_level_kernel): its bytes move there
@@ -202,8 +197,6 @@ class Workload:
                 c.set_tracing(True)
             if args.side_stream and self.pipelined:
                 c.debug_set(_lib.DEBUG_DS_SIDE_STREAM, args.side_stream)
-            if args.ds_share_in_render and self.pipelined:
-                c.debug_set(_lib.DEBUG_DS_SHARE_IN_RENDER, args.ds_share_in_render)
             self.ctxs.append(c)
         self.ao = self.ctxs[0]
         tstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(self.nfl - 1)]
@@ -536,9 +529,6 @@ def main() -> int:
                     help="meao_debug_set(MEAO_DEBUG_DS_SIDE_STREAM, MODE): the next step's downsample pass as its own kernel on the "
                          "context's low-priority side stream instead of inside the last upsample kernel (4 = released at the start "
                          "of the call).  Kernels then overlap: per-kernel durations are no longer attributable, the line says so")
-    ap.add_argument("--ds-share-in-render", type=int, default=0, metavar="PERCENT",
-                    help="meao_debug_set(MEAO_DEBUG_DS_SHARE_IN_RENDER, PERCENT): that share of the next step's downsample tiles rides in the "
-                         "render launch as extra workgroups, the rest in the last upsample kernel")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not use meao_prefetch_batch: every step launches its own downsample pass instead of "
                          "carrying the next step's inside its last upsample kernel")
@@ -645,7 +635,7 @@ def main() -> int:
     step_ms = elapsed / args.steps * 1e3
 
     # roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration
-    passes, alg, names = pass_table(ao, pass_ms, B, pipelined, args.ds_share_in_render / 100.0 if pipelined else 0.0)
+    passes, alg, names = pass_table(ao, pass_ms, B, pipelined)
     ren_ups_bytes = sum(ao.algorithmic_bytes()[1:])    # render + upsample passes only (north_star's sub-path)
     dominant = int(np.argmax(pass_ms))
     dom_gbps = alg[dominant] * B / (pass_ms[dominant] * 1e-3) / 1e9

@@ -417,8 +417,7 @@ typedef enum meao_debug_key {
                                         * (1 = the full-resolution upsample launch, 2 = L2 -> L1, 3 = the coarse blend launch, 4 = render);
                                         * shape 0..4 = loads in flight per lane {16 + 120 VGPRs declared, 16, 8, 4, 8 + 120 VGPRs declared};
                                         * + 100 * p: stream priority p = 0 lowest, 1 default, 2 highest; + 1000 * s + 10000 * b: only the
-                                        * first s tenths of the frames at `gate`, the rest at gate b (default 1; b = 5: the rest rides in the last kernel, the
-                                        * default fused form).  Results identical. */
+                                        * first s tenths of the frames at `gate`, the rest at gate b (default 1).  Results identical. */
     MEAO_DEBUG_RENDER_FROM_DEPTH = 8,  /* calls that run their own downsample pass (no meao_prefetch_batch), f32 depth, 36 samples: the render
                                         * launch fills its windows from the RAW depth frame and does not wait for the downsample pass.
                                         * 0 (default) = never; 1 = always, both in ONE launch (the pass as extra workgroups behind the
@@ -426,9 +425,7 @@ typedef enum meao_debug_key {
                                         * blend launch; 3 = form 1 for calls of at most RENDER_FROM_DEPTH_MAX_TILES render tiles.
                                         * Measured slower than the stored-mip sequence at every call size (the gathered windows touch
                                         * 2^level times the cache lines): an option, not the default. */
-    MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES = 9,  /* frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190); default 1024 */
-    MEAO_DEBUG_DS_SHARE_IN_RENDER = 10 /* percent (0..100) of the next batch's downsample tiles (meao_prefetch_batch) that ride in the render
-                                        * launch as extra workgroups dealt among the render ones, instead of in the last kernel */
+    MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES = 9   /* frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190); default 1024 */
 } meao_debug_key;
 MEAO_API int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value);
 

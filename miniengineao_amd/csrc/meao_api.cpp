@@ -91,8 +91,6 @@ struct meao_ctx {
     int render_from_depth_max_tiles = 1024;      // frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190)
     hipStream_t rfd_stream = nullptr;            // form 2
     hipEvent_t rfd_fork = nullptr, rfd_join = nullptr;
-    int ds_share_in_render = 0;        // percent of the carried (next batch's) downsample tiles that ride in the render launch as extra workgroups
-                                       // (render_carrying_downsample_kernel) instead of the last kernel
     int ds_share_in_blend = 0;         // percent of the carried (next batch's) downsample tiles that ride in the L2->L1 blend launch instead of the last kernel
     // MEAO_DEBUG_DS_SIDE_STREAM (0 = off): the announced next batch's downsample pass as its OWN kernel on a second,
     // low-priority stream of the context, gated behind a point of this call's launch sequence, instead of riding inside
@@ -579,9 +577,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         side.total = ctx->next_n;
         side.gate_a = v % 10; side.shape = v / 10 % 10; side.prio = v / 100 % 10;
         side.gate_b = v / 10000 % 10 ? v / 10000 % 10 : 1;
-        // gate_b 5: the frames the side kernel does not take ride in the last kernel (the fused form) -- the HBM-bound last kernel
-        // sheds part of its carried bytes to a co-runner of the VALU-bound render launch
-        side.first_part = (split == 0 || (side.gate_b >= side.gate_a && side.gate_b != 5)) ? side.total
+        side.first_part = (split == 0 || side.gate_b >= side.gate_a) ? side.total
                                                                      : std::min(side.total, std::max(1, (side.total * split + 9) / 10));
         side.other = 1 - ctx->ds_cur;
     }
@@ -634,10 +630,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         if (rc != MEAO_OK) return rc;
     }
     { const int rc = side_downsample_at(4); if (rc != MEAO_OK) return rc; }
-    // tiles [0, carried_earlier) of every frame of the announced batch's downsample pass ride in a launch in front of the last
-    // kernel (render: DS_SHARE_IN_RENDER, or the L2 -> L1 blend: DS_SHARE_IN_BLEND), all under one generation
-    int carried_earlier = 0;
-    uint32_t next_gen = 0;
     if (from_depth != 0) {
         // one frame per call: windows from the raw depth; form 1 carries the downsample pass as extra workgroups, form 2 runs on
         // the second stream next to the pass and is joined here, in front of the first reader of both
@@ -650,28 +642,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             MEAO_HIP(ctx, hipEventRecord(ctx->rfd_join, rs));
             MEAO_HIP(ctx, hipStreamWaitEvent(stream, ctx->rfd_join, 0));
         }
-    } else if (ctx->next_n > 0 && ctx->ds_share_in_render > 0 && ctx->next_n <= n && !side.active && ctx->pending_comp.frames == 0 &&
-               c.sample_set == MEAO_SAMPLES_CHECKER && c.depth_format == MEAO_DEPTH_F32 &&
-               downsample_args(ctx->next_n, ctx->next_depth, 1 - ctx->ds_cur, 0).vec_ok &&
-               p.mip[0].w * 1ll * p.mip[0].h >= 128 * 64) {
-        // MEAO_DEBUG_DS_SHARE_IN_RENDER: the first tiles of every frame of the announced batch's downsample pass as extra
-        // workgroups of this (VALU-bound, HBM idle) launch; the last kernel (HBM-bound) carries the rest from tile_begin on
-        next_gen = next_generation();
-        DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, 1 - ctx->ds_cur, next_gen);
-        const int ds_tiles = ds.tiles_x * ds.tiles_y;
-        const int final_tiles = ((p.mip[0].w + kUpsTileW - 1) / kUpsTileW) * ((p.mip[0].h + ups_tile_h(true) - 1) / ups_tile_h(true));
-        int share = static_cast<int>(static_cast<int64_t>(ds_tiles) * ctx->ds_share_in_render / 100);
-        if (ds_tiles > final_tiles) share = 0;          // the last kernel takes the rest in its split form only
-        TraceRange tr(ctx, share > 0 ? "meao:render+part_of_downsample_next" : "meao:render");
-        MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
-        if (share > 0) {
-            ds.tile_end = share;
-            MEAO_HIP(ctx, launch_render_carrying_downsample(render_args(1, c.num_levels, false), ds, c.ao_format, n, stream));
-            carried_earlier = share;
-        } else {
-            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false, true), c.ao_format, n, stream));
-        }
-        MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
     } else {
         TraceRange tr(ctx, ctx->pending_comp.frames > 0 ? "meao:render+composite_of_previous_call" : "meao:render");
         MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
@@ -718,9 +688,10 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     // issue slots idle) instead of the last kernel: tiles [0, carried_in_blend) of every frame
     { const int rc = side_downsample_at(2); if (rc != MEAO_OK) return rc; }
     int carried_in_blend = 0;
+    uint32_t next_gen = 0;
     if (c.num_levels >= 2 && !blend_done) {
         const UpsampleArgs up1 = upsample_args(1);
-        if (ctx->next_n > 0 && ctx->ds_share_in_blend > 0 && ctx->next_n <= n && !side.active && carried_earlier == 0) {
+        if (ctx->next_n > 0 && ctx->ds_share_in_blend > 0 && ctx->next_n <= n && !side.active) {
             next_gen = next_generation();
             DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, 1 - ctx->ds_cur, next_gen);
             const int blend_tiles = up1.tiles_x * up1.tiles_y, ds_tiles = ds.tiles_x * ds.tiles_y;
@@ -733,7 +704,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
                 MEAO_HIP(ctx, launch_upsample_blend_with_downsample(up1, ds, c.ao_format, n, stream));
                 MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_1, stream));
                 carried_in_blend = share;
-                carried_earlier = share;
             }
         }
         if (carried_in_blend == 0) {
@@ -747,16 +717,11 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         const UpsampleArgs up = upsample_args(0);
         MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_0, stream));
         if (ctx->next_n > 0) {
-            // carry the downsample of the announced next batch in this kernel; frames [0, first) of it may already be with the
-            // side-stream kernel (MEAO_DEBUG_DS_SIDE_STREAM ... gate_b 5), then this launch carries frames [first, next_n)
+            // carry the downsample of the announced next batch in this (VALU-bound) kernel
             const int other = 1 - ctx->ds_cur;
-            const int first = side.active ? side.issued : 0;
-            if (first == 0) ctx->set_gen[other] = carried_earlier > 0 ? next_gen : next_generation();     // one generation for all carrying launches
-            DownsampleArgs ds = downsample_args(ctx->next_n - first, ctx->next_depth + first, other, ctx->set_gen[other]);
-            ds.linear = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(ds.linear) + ctx->slot_bytes * first);
-            for (int k = 0; k < 4; ++k) ds.low[k] = reinterpret_cast<float *>(reinterpret_cast<char *>(ds.low[k]) + ctx->slot_bytes * first);
-            ds.hostile += first;
-            ds.tile_begin = carried_earlier;
+            ctx->set_gen[other] = carried_in_blend > 0 ? next_gen : next_generation();     // one generation for both carrying launches
+            DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other]);
+            ds.tile_begin = carried_in_blend;
             MEAO_HIP(ctx, launch_upsample_final_with_downsample(up, ds, c.ao_format, n, stream));
             ctx->ready_n = ctx->next_n;
             ctx->ready_set = other;
@@ -1453,9 +1418,8 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
         break;
     case MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES: ctx->render_from_depth_max_tiles = value; break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
-    case MEAO_DEBUG_DS_SHARE_IN_RENDER: ctx->ds_share_in_render = value < 0 ? 0 : (value > 100 ? 100 : value); break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
-        if (value < 0 || value % 10 > 4 || (value > 0 && value % 10 == 0) || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 5 || value >= 100000)
+        if (value < 0 || value % 10 > 4 || (value > 0 && value % 10 == 0) || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
             return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");
         if (ctx->side_stream && value / 100 % 10 != ctx->ds_side_stream / 100 % 10) {       // the stream's priority is fixed at creation
             const int rc = use_device(ctx);

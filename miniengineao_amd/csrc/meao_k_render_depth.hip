@@ -42,53 +42,6 @@ __global__ __launch_bounds__(ren_tile_w(false) * 4, 6) void render_from_depth_ke
         a, tile, frame, xcd_contiguous(blockIdx.x, a.blocks_per_frame), NoRenderHook(), &d);
 }
 
-// The batched counterpart (MEAO_DEBUG_DS_SHARE_IN_RENDER): the stored-mip render of THIS batch with the first d.tile_end downsample
-// tiles of every frame of the NEXT batch (meao_prefetch_batch) as extra workgroups of the same launch, the rest of that pass
-// staying with the last upsample kernel (d.tile_begin there).  The last kernel of a pipelined step is HBM-bound (0.94 - 0.97 of the
-// copy rate), render is VALU-bound with HBM idle: bytes moved from the former to the latter cost less there than they save here --
-// and a co-runner in the SAME launch needs no second stream (the side-stream form pays 16 - 18 us per step for its two event
-// hand-overs, profiles/r05_ab_side_stream_split.jsonl).  Downsample workgroups are dealt evenly among the render ones (the
-// hardware dispatches in index order: bunched at the end they would run alone).
-template <int AOFMT, bool RTNE, int DIV>
-__global__ __launch_bounds__(ren_tile_w(false) * 4, 8) void render_carrying_downsample_kernel(const RenderArgs a, const DownsampleArgs d)
-{
-    __shared__ __attribute__((aligned(16))) float tile[kRenLdsH * (ren_tile_w(false) + 2 * kRenApron)];
-    const int frame = blockIdx.y;
-    // Workgroups are dealt in OCTETS (ids 8g .. 8g + 7 land on the 8 XCDs): an octet is all render or all downsample, so that render
-    // workgroup number r keeps r = id (mod 8) -- what xcd_contiguous needs to put neighbouring tiles, which share their aprons, on
-    // one XCD's L2.  (Dealt one by one the render tiles lost that: +36 us on the launch for a 20 % share.)
-    const int R = a.blocks_per_frame, D = (d.tile_end + 1) / 2;
-    const int Rg = (R + 7) >> 3, Dg = (D + 7) >> 3, groups = Rg + Dg;
-    const int i = blockIdx.x, g = i >> 3, lane8 = i & 7;
-    // octet g is a downsample octet iff floor((g + 1) Dg / groups) > floor(g Dg / groups); it is then downsample octet floor(g Dg / groups),
-    // otherwise render octet g - floor((g + 1) Dg / groups)
-    const int q0 = static_cast<int>(static_cast<int64_t>(g) * Dg / groups), q1 = static_cast<int>(static_cast<int64_t>(g + 1) * Dg / groups);
-    if (q1 > q0) {
-        const int t = 2 * (8 * q0 + lane8) + static_cast<int>(threadIdx.x >> 8);
-        if (t >= d.tile_end || frame >= d.frames) return;
-        const unsigned tid = threadIdx.x & 255u;
-        if (d.vec_ok) downsample_tile<RTNE, true, DIV>(d, t, frame, tid);
-        else downsample_tile<RTNE, false, DIV>(d, t, frame, tid);
-        return;
-    }
-    const int r = 8 * (g - q1) + lane8;
-    if (r >= R) return;
-    const int block = xcd_contiguous(r, R);
-    if constexpr (DIV == DIV_EXACT_RCP) {
-        if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
-            render_tile<AOFMT, RTNE, DIV_IEEE, false>(a, tile, frame, block);
-            return;
-        }
-    }
-    render_tile<AOFMT, RTNE, DIV, false>(a, tile, frame, block);
-}
-
-template <int AOFMT, bool RTNE, int DIV>
-void launch_render_carrying_downsample_t(const RenderArgs &a, const DownsampleArgs &d, dim3 grid, hipStream_t s)
-{
-    render_carrying_downsample_kernel<AOFMT, RTNE, DIV><<<grid, dim3(ren_tile_w(false) * 4), 0, s>>>(a, d);
-}
-
 template <int AOFMT, bool RTNE, int DIV>
 void launch_render_from_depth_t(const RenderArgs &a, const DownsampleArgs &d, dim3 grid, hipStream_t s)
 {
@@ -121,25 +74,6 @@ hipError_t launch_render_from_depth(const RenderArgs &a, const DownsampleArgs &d
         else if (a.exact_rcp_div == 2) launch_render_from_depth_t<MEAO_AO_F16, false, DIV_FAST>(a, d, grid, s);
         else if (a.exact_rcp_div) launch_render_from_depth_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, d, grid, s);
         else launch_render_from_depth_t<MEAO_AO_F16, false, DIV_IEEE>(a, d, grid, s);
-    }
-    return hipGetLastError();
-}
-
-// Stored-mip render of this batch + downsample tiles [0, d.tile_end) of every frame of the next one (32-row tiles, 36 samples).
-hipError_t launch_render_carrying_downsample(const RenderArgs &a, const DownsampleArgs &d, int ao_format, int frames, hipStream_t s)
-{
-    if (a.exhaustive || a.tile_h != kRenTileH || d.row_passes != kDsTileH / kDsRowsPerPass || d.frames > frames) return hipErrorInvalidValue;
-    const dim3 grid(8 * (((a.blocks_per_frame + 7) >> 3) + ((((d.tile_end + 1) / 2) + 7) >> 3)), frames, 1);      // whole octets
-    if (ao_format == MEAO_AO_R8) {
-        if (a.f16_rtne) launch_render_carrying_downsample_t<MEAO_AO_R8, true, DIV_IEEE>(a, d, grid, s);
-        else if (a.exact_rcp_div == 2) launch_render_carrying_downsample_t<MEAO_AO_R8, false, DIV_FAST>(a, d, grid, s);
-        else if (a.exact_rcp_div) launch_render_carrying_downsample_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(a, d, grid, s);
-        else launch_render_carrying_downsample_t<MEAO_AO_R8, false, DIV_IEEE>(a, d, grid, s);
-    } else {
-        if (a.f16_rtne) launch_render_carrying_downsample_t<MEAO_AO_F16, true, DIV_IEEE>(a, d, grid, s);
-        else if (a.exact_rcp_div == 2) launch_render_carrying_downsample_t<MEAO_AO_F16, false, DIV_FAST>(a, d, grid, s);
-        else if (a.exact_rcp_div) launch_render_carrying_downsample_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, d, grid, s);
-        else launch_render_carrying_downsample_t<MEAO_AO_F16, false, DIV_IEEE>(a, d, grid, s);
     }
     return hipGetLastError();
 }

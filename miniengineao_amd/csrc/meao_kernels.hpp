@@ -127,9 +127,6 @@ hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hi
 // the same launch runs the downsample pass `d` describes as extra workgroups (meao_k_render_depth.hip).
 hipError_t launch_render_from_depth(const RenderArgs &a, const DownsampleArgs &d, bool with_downsample, int ao_format, int frames,
                                     hipStream_t s);
-// Stored-mip render of this batch carrying downsample tiles [0, d.tile_end) of every frame of the NEXT batch as extra workgroups
-// dealt among the render ones (meao_k_render_depth.hip).
-hipError_t launch_render_carrying_downsample(const RenderArgs &a, const DownsampleArgs &d, int ao_format, int frames, hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
                            hipStream_t s);
 // Two blend passes in one launch: `inner` (e.g. L4 -> L3) is evaluated per tile of `outer` (L3 -> L2) for the
