@@ -232,13 +232,14 @@ class Workload:
                 self.step()
             torch.cuda.synchronize(self.dev)
 
-    def timed(self, steps, warmup):
-        """W warm-up steps, then exactly `steps` steps between two fences, per-pass HIP events on.
-        Returns (elapsed max over ranks, own elapsed, pass_ms, event samples)."""
+    def timed(self, steps, warmup, pass_events=True):
+        """W warm-up steps, then exactly `steps` steps between two fences, per-pass HIP events on (pass_events=False: off --
+        the library then puts nothing but its kernels on the stream).  Returns (elapsed max over ranks, own elapsed, pass_ms,
+        event samples)."""
         for _ in range(warmup):
             self.step()
         for c in self.ctxs:
-            c.set_profiling(True)       # HIP events around every pass, on the launch stream
+            c.set_profiling(pass_events)       # HIP events around every pass, on the launch stream
         self.fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -600,6 +601,14 @@ def main() -> int:
     # last step of that region (prefetched downsample consumed, final pass = the fused kernel)
     check_timed, sums_timed = wl.validate(n_validate)
 
+    # The same K steps once more WITHOUT the per-pass HIP events (two event records per launch = eight marker packets per step
+    # on the stream): what the library does for a host that does not profile it.  `value` stays on the timed region above, whose
+    # events the roofline rows come from; this leg says what those events cost.
+    ne_elapsed, _, _, _ = wl.timed(args.steps, 3, pass_events=False)
+    without_events = {"value": round(float(w) * h * B * args.steps * world / ne_elapsed / 1e6, 1),
+                      "ms_per_step": round(ne_elapsed / args.steps * 1e3, 4),
+                      "note": "the timed path with meao_set_profiling off: no event records between the launches"}
+
     # for reference, the same K steps as the plain launch sequence (every step runs its own downsample
     # pass), with per-pass events: this is where the north-star sub-path (render + upsample passes,
     # nothing else inside those kernels) is timed
@@ -845,6 +854,7 @@ def main() -> int:
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "single_frame": single,
             "plain_launch_sequence": plain,
+            "without_pass_events": without_events,
             "sum_kernel_ms_per_step": round(kernel_ms, 4),
             "other_workloads": others,
             "best_host_config": best_host,
