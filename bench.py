@@ -122,6 +122,9 @@ def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
         return None
 
 
+PASS_EVENT_PERIOD = 4        # per-pass HIP events in one step of four of a timed region (meao_set_profiling(4))
+
+
 def pass_table(ao, pass_ms, B, pipelined):
     """Per-launch roofline rows: algorithmic bytes of what each launch carries / its HIP-event duration."""
     alg = ao.algorithmic_bytes()                 # per frame, reference storage formats
@@ -238,8 +241,10 @@ class Workload:
         event samples)."""
         for _ in range(warmup):
             self.step()
+        # HIP events around every pass of every PASS_EVENT_PERIOD-th step, on the launch stream (an event record is a marker
+        # packet between two launches; on every step they cost 1 - 4 % of it, `without_pass_events`)
         for c in self.ctxs:
-            c.set_profiling(pass_events)       # HIP events around every pass, on the launch stream
+            c.set_profiling(PASS_EVENT_PERIOD if pass_events else 0)
         self.fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -316,6 +321,7 @@ def measure_other_workload(name, args, dev, local_rank):
                "passes": rows, "validation_pipelined": check}
         if wl.pipelined:
             wl.use_prefetch = False
+            wl.ramp(0.020)
             pel, _, plain_ms, _ = wl.timed(steps, 3)
             ren_ups_bytes = sum(wl.ao.algorithmic_bytes()[1:])
             ren_ups_ms = sum(plain_ms[1:])
@@ -383,7 +389,7 @@ def measure_pool(args, G, B=None, ramp_s=0.080, side_stream=None) -> dict:
         sync_all()
         steps = max(steps, int(np.ceil(args.min_time_ms * 1e-3 / max((time.perf_counter() - t_est) / 3.0, 1e-6))))
     for m in range(G):
-        _lib.check(lib.meao_set_profiling(pool.member_context(m), 1))
+        _lib.check(lib.meao_set_profiling(pool.member_context(m), PASS_EVENT_PERIOD))
     sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -590,7 +596,7 @@ def main() -> int:
     n_validate = args.validate_frames if args.validate_frames >= 0 else (B if world == 1 else 2)
 
     steps_requested = args.steps
-    wl.ramp(0.080)
+    wl.ramp(0.250)          # (80 ms until round 5: with the driver's 20 timed steps = 11 ms the region still sat on the slope, render 178 vs 169 us)
     args.steps = wl.steps_for(args.min_time_ms, args.steps)
     elapsed, my_elapsed, pass_ms, samples = wl.timed(args.steps, args.warmup)
     per_rank_ms = mdist.gather_floats(my_elapsed / args.steps * 1e3, dev)
@@ -604,6 +610,7 @@ def main() -> int:
     # The same K steps once more WITHOUT the per-pass HIP events (two event records per launch = eight marker packets per step
     # on the stream): what the library does for a host that does not profile it.  `value` stays on the timed region above, whose
     # events the roofline rows come from; this leg says what those events cost.
+    wl.ramp(0.100)          # (the validation above left the device idle: back to steady clocks first, as before the main region)
     ne_elapsed, _, _, _ = wl.timed(args.steps, 3, pass_events=False)
     without_events = {"value": round(float(w) * h * B * args.steps * world / ne_elapsed / 1e6, 1),
                       "ms_per_step": round(ne_elapsed / args.steps * 1e3, 4),
@@ -615,6 +622,7 @@ def main() -> int:
     plain, plain_pass_ms, check_plain, sums_plain = None, None, None, None
     if pipelined:
         wl.use_prefetch = False
+        wl.ramp(0.100)      # steady clocks for this leg too: with an explicit small --steps it would otherwise be timed on the ramp
         plain_elapsed, _, plain_pass_ms, _ = wl.timed(args.steps, 3)
         plain = {"value": round(float(w) * h * B * args.steps * world / plain_elapsed / 1e6, 1),
                  "ms_per_step": round(plain_elapsed / args.steps * 1e3, 4),
@@ -658,6 +666,7 @@ def main() -> int:
                 "kernel": names[dominant], "achieved": round(dom_gbps, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "launch_ms": round(pass_ms[dominant], 5), "event_samples": samples,
+                "event_period": PASS_EVENT_PERIOD,      # HIP events around the launches of every 4th step of the timed region
                 "whole_frame": {"GBps": round(whole_gbps, 1), "frac": round(whole_gbps / HBM_PEAK_GBPS, 4),
                                 "over": "ms_per_step (launch gaps included)"},
                 # north_star's sub-path (target: frac >= 0.60), timed per pass in the plain launch sequence

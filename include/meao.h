@@ -335,7 +335,11 @@ MEAO_API int32_t meao_composite_pending(const meao_ctx *ctx, int32_t *out_frames
 /* Per-pass device timing: when enabled, meao_execute* brackets every pass with HIP events on
  * the launch stream; meao_get_pass_times averages each pass over the executes that ran it since
  * the last reset (synchronises the stream); *out_samples = executes measured.
- * ms[MEAO_NUM_PASSES]; passes not run report 0. */
+ * ms[MEAO_NUM_PASSES]; passes not run report 0.
+ * enable: 0 = off; 1 = every execute; N > 1 = every Nth execute (the first one after the call included), the others run
+ * without event records.  An event record is a marker packet between two launches: eight of them per 4K x 16 step cost
+ * 1 - 4 % of the step depending on the box (bench.py `without_pass_events`), so a throughput measurement that also wants
+ * kernel durations samples them. */
 MEAO_API int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable);
 MEAO_API int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *out_samples);
 

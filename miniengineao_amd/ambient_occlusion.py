@@ -222,8 +222,9 @@ class AmbientOcclusion:
         L.check(self._lib.meao_debug_view(self._ctx, frame, debug_id, out.ctypes.data, L.MEM_HOST, None), self._ctx)
         return out
 
-    def set_profiling(self, enable: bool) -> None:
-        L.check(self._lib.meao_set_profiling(self._ctx, 1 if enable else 0), self._ctx)
+    def set_profiling(self, enable) -> None:
+        """False / True, or an int N > 1: HIP events around the passes of every Nth execute only (meao_set_profiling)."""
+        L.check(self._lib.meao_set_profiling(self._ctx, int(enable)), self._ctx)
 
     def hostile_frames(self) -> int:
         """Bit mask of the frames of the last execute that ran the IEEE-division bodies (meao_hostile_frames)."""

@@ -127,6 +127,7 @@ struct meao_ctx {
     // profiling: a ring of per-execute event sets (one start/end pair per launch slot); each entry
     // remembers which slots it used
     bool profiling = false;
+    int profile_period = 1, profile_phase = 0;   // meao_set_profiling(N > 1): every Nth execute is bracketed with events, the others run bare
     std::vector<hipEvent_t> events;              // kProfileRing * kProfSlots * 2
     int ring_fill = 0;
     uint32_t ran_mask[kProfileRing] = {};        // bit k: launch slot k ran in that execute
@@ -360,7 +361,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     const int rtne = c.f16_rounding == MEAO_F16_RTNE;
     hipEvent_t *ev = nullptr;
     uint32_t ran = 0;
-    if (ctx->profiling) {
+    if (ctx->profiling && ctx->profile_phase++ % ctx->profile_period == 0) {
         if (ctx->ring_fill == kProfileRing) fold_profile(ctx);
         ev = &ctx->events[ctx->ring_fill * kProfSlots * 2];
     }
@@ -1263,6 +1264,8 @@ int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable)
         ctx->executes_profiled = 0;
     }
     ctx->profiling = enable != 0;
+    ctx->profile_period = enable > 1 ? enable : 1;
+    ctx->profile_phase = 0;
     return MEAO_OK;
 }
 

@@ -443,6 +443,25 @@ def test_render_from_depth_inside_a_captured_launch_sequence(oracle, form):
         ao.close()
 
 
+def test_sampled_profiling_brackets_every_nth_execute(oracle):
+    """meao_set_profiling(N > 1): events around the passes of executes 0, N, 2N, ... only; the others run bare."""
+    w, h = 322, 182
+    s = H.settings(oracle, w, h)
+    depth = synth.make("S2", w, h, seed=4)
+    want = oracle.run(depth, s, result_only=True)["result"]
+    ao = H.component(s)
+    try:
+        for period, calls, sampled in ((3, 7, 3), (1, 4, 4), (4, 4, 1), (0, 5, 0)):
+            ao.set_profiling(period)
+            for _ in range(calls):
+                assert np.array_equal(ao.render(depth), want)
+            ms, n = ao.pass_times_ms()
+            assert n == sampled, (period, n)
+            assert (sum(ms) > 0) == (sampled > 0)
+    finally:
+        ao.close()
+
+
 def test_render_from_depth_is_an_option_and_falls_back(oracle):
     """The default is the stored-mip sequence (a separate downsample launch is timed); RENDER_FROM_DEPTH 3 lets small calls take the
     one-launch form -- no separate downsample time -- while larger ones and non-f32 depth keep the stored-mip form; results
