@@ -122,7 +122,11 @@ def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
         return None
 
 
-PASS_EVENT_PERIOD = 4        # per-pass HIP events in one step of four of a timed region (meao_set_profiling(4))
+# Per-pass HIP events in EVERY step of a timed region.  (meao_set_profiling(N) can sample every Nth step, and the event records cost
+# 1 - 4 % of a step -- `without_pass_events` -- but a sampled step is not a typical one: the markers of the one evented step in four
+# stall a front end that otherwise runs ahead, render reads 183 us instead of 169 and the kernels' sum exceeds the step.  Every
+# step evented is self-consistent: sum of kernels <= step.)
+PASS_EVENT_PERIOD = 1
 
 
 def pass_table(ao, pass_ms, B, pipelined):
@@ -241,8 +245,7 @@ class Workload:
         event samples)."""
         for _ in range(warmup):
             self.step()
-        # HIP events around every pass of every PASS_EVENT_PERIOD-th step, on the launch stream (an event record is a marker
-        # packet between two launches; on every step they cost 1 - 4 % of it, `without_pass_events`)
+        # HIP events around every pass of every step (PASS_EVENT_PERIOD = 1), on the launch stream
         for c in self.ctxs:
             c.set_profiling(PASS_EVENT_PERIOD if pass_events else 0)
         self.fence()
@@ -666,7 +669,7 @@ def main() -> int:
                 "kernel": names[dominant], "achieved": round(dom_gbps, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "launch_ms": round(pass_ms[dominant], 5), "event_samples": samples,
-                "event_period": PASS_EVENT_PERIOD,      # HIP events around the launches of every 4th step of the timed region
+                "event_period": PASS_EVENT_PERIOD,      # HIP events around the launches of every step of the timed region
                 "whole_frame": {"GBps": round(whole_gbps, 1), "frac": round(whole_gbps / HBM_PEAK_GBPS, 4),
                                 "over": "ms_per_step (launch gaps included)"},
                 # north_star's sub-path (target: frac >= 0.60), timed per pass in the plain launch sequence

@@ -451,13 +451,16 @@ def test_sampled_profiling_brackets_every_nth_execute(oracle):
     want = oracle.run(depth, s, result_only=True)["result"]
     ao = H.component(s)
     try:
-        for period, calls, sampled in ((3, 7, 3), (1, 4, 4), (4, 4, 1), (0, 5, 0)):
+        for period, calls, sampled in ((3, 7, 3), (1, 4, 4), (4, 4, 1), (2, 5, 3)):
             ao.set_profiling(period)
             for _ in range(calls):
                 assert np.array_equal(ao.render(depth), want)
             ms, n = ao.pass_times_ms()
-            assert n == sampled, (period, n)
-            assert (sum(ms) > 0) == (sampled > 0)
+            assert n == sampled and sum(ms) > 0, (period, n)
+        ao.set_profiling(0)                 # off: the window of the last measurement stays as it was
+        for _ in range(3):
+            assert np.array_equal(ao.render(depth), want)
+        assert ao.pass_times_ms()[1] == 3
     finally:
         ao.close()
 
