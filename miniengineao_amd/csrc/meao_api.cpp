@@ -131,7 +131,6 @@ struct meao_ctx {
     std::vector<hipEvent_t> events;              // kProfileRing * kProfSlots * 2
     int ring_fill = 0;
     uint32_t ran_mask[kProfileRing] = {};        // bit k: launch slot k ran in that execute
-    uint8_t begin_of[kProfileRing][kProfSlots] = {};   // which event of the entry opens slot k: its own, or the closing event of the launch in front of it
     double pass_ms_sum[MEAO_NUM_PASSES] = {};
     int pass_samples[MEAO_NUM_PASSES] = {};      // executes that ran pass k
     int executes_profiled = 0;
@@ -319,7 +318,7 @@ void fold_profile(meao_ctx *ctx)
     for (int r = 0; r < ctx->ring_fill; ++r) {
         for (int k = 0; k < kProfSlots; ++k) {
             if (!(ctx->ran_mask[r] >> k & 1u)) continue;
-            hipEvent_t a = ctx->events[r * kProfSlots * 2 + ctx->begin_of[r][k]], b = ctx->events[(r * kProfSlots + k) * 2 + 1];
+            hipEvent_t a = ctx->events[(r * kProfSlots + k) * 2], b = ctx->events[(r * kProfSlots + k) * 2 + 1];
             (void)hipEventSynchronize(b);
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, a, b) != hipSuccess) continue;
@@ -366,30 +365,11 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         if (ctx->ring_fill == kProfileRing) fold_profile(ctx);
         ev = &ctx->events[ctx->ring_fill * kProfSlots * 2];
     }
-    // One launch = one profiling slot: events right before and after it on ITS stream.  Back-to-back launches on one stream share the
-    // event between them -- the closing event of launch i opens launch i + 1 (it cannot start earlier) -- so a step of four launches
-    // puts five marker packets on the stream instead of eight: each one stalls the front end for a couple of microseconds (round 5:
-    // the eight of a 4K x 16 step cost 1 - 4 % of it).  Anything else enqueued in between (composite flush, fork / gate events)
-    // breaks the sharing: the next slot records its own opening event.
-    uint8_t begin_idx[kProfSlots] = {};
-    int last_marker = -1;
-    hipStream_t last_marker_stream = nullptr;
-    auto other_work_enqueued = [&]() { last_marker = -1; };
-    auto begin = [&](int slot, hipStream_t s) -> hipError_t {
-        if (!ev) return hipSuccess;
-        if (last_marker >= 0 && last_marker_stream == s) {
-            begin_idx[slot] = static_cast<uint8_t>(last_marker);
-            return hipSuccess;
-        }
-        begin_idx[slot] = static_cast<uint8_t>(slot * 2);
-        return hipEventRecord(ev[slot * 2], s);
-    };
+    // one launch = one profiling slot: events right before and after it on ITS stream
+    auto begin = [&](int slot, hipStream_t s) -> hipError_t { return ev ? hipEventRecord(ev[slot * 2], s) : hipSuccess; };
     auto end = [&](int slot, hipStream_t s) -> hipError_t {
         ran |= 1u << slot;
-        if (!ev) return hipSuccess;
-        last_marker = slot * 2 + 1;
-        last_marker_stream = s;
-        return hipEventRecord(ev[slot * 2 + 1], s);
+        return ev ? hipEventRecord(ev[slot * 2 + 1], s) : hipSuccess;
     };
 
     // 4-texel vector loads / stores need 16-byte (f32, UNORM24), 8-byte (16-bit) aligned depth rows and
@@ -474,7 +454,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
                 MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->rfd_fork, hipEventDisableTiming));
                 MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->rfd_join, hipEventDisableTiming));
             }
-            other_work_enqueued();
             MEAO_HIP(ctx, hipEventRecord(ctx->rfd_fork, stream));      // behind the previous call's readers of the Occlusion buffers
             MEAO_HIP(ctx, hipStreamWaitEvent(ctx->rfd_stream, ctx->rfd_fork, 0));
         }
@@ -626,7 +605,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         ds.tiles_y = (p.mip[0].h + ds.row_passes * kDsRowsPerPass - 1) / (ds.row_passes * kDsRowsPerPass);
         ds.tile_end = ds.tiles_x * ds.tiles_y;
         TraceRange tr(ctx, "meao:downsample_next(side stream)");
-        other_work_enqueued();
         MEAO_HIP(ctx, hipEventRecord(ctx->side_gate, stream));
         MEAO_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_gate, 0));
         // (the side kernel is timed in the DOWNSAMPLE slot only in calls that did not run a pass of their own there)
@@ -649,7 +627,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     };
 
     if (ctx->pending_comp.frames > 0 && c.sample_set == MEAO_SAMPLES_EXHAUSTIVE) {
-        other_work_enqueued();
         const int rc = flush_pending_composite(ctx, stream);     // the 68-sample render kernel carries nothing
         if (rc != MEAO_OK) return rc;
     }
@@ -665,7 +642,6 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         if (from_depth == 2) {
             MEAO_HIP(ctx, hipEventRecord(ctx->rfd_join, rs));
             MEAO_HIP(ctx, hipStreamWaitEvent(stream, ctx->rfd_join, 0));
-            other_work_enqueued();
         }
     } else {
         TraceRange tr(ctx, ctx->pending_comp.frames > 0 ? "meao:render+composite_of_previous_call" : "meao:render");
@@ -758,10 +734,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         }
         MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_0, stream));
     }
-    if (ev) {
-        std::memcpy(ctx->begin_of[ctx->ring_fill], begin_idx, sizeof begin_idx);
-        ctx->ran_mask[ctx->ring_fill++] = ran;
-    }
+    if (ev) ctx->ran_mask[ctx->ring_fill++] = ran;
     for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
     ctx->last_frames = n;
     ctx->last_stream = stream;
