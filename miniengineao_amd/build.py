@@ -120,6 +120,7 @@ VARIANTS = {
     "exactr8": ["-DMEAO_X_UPS_EXACT_R8=1"],         # every UNORM8 bilateral result through the exact-division sequences (cross-check of the estimate)
     "testhooks": ["-DMEAO_TESTING=1"],              # the product + meao_test_fail_next_allocs (fault injection for the resize tests; not in the product ABI)
     "pair": ["-DMEAO_X_BIL_PAIR_RCP=1"],            # three reciprocals per UNORM8 bilateral texel instead of five (round-5 A/B: no gain in the kernels)
+    "ntstore": ["-DMEAO_X_FINAL_NT_STORE=1"],       # non-temporal stores for the result texels of the full-resolution pass (the form of rounds 2-4)
     "nowt": ["-DMEAO_X_BIL_WHOLE_TILE=0"],          # without the unmasked copy of the bilateral phase (the round-3 form of the upsample tile)
 }
 

@@ -24,6 +24,12 @@
                                    // five-reciprocal form, -5.5 % on the instruction mix in isolation -- and nothing in the kernels: last kernel
                                    // 269.6 vs 269.4 us, full-resolution pass 170.7 vs 170.3 us, L2->L1 54.9 vs 53.5 us per 16 frames (the exact
                                    // path can no longer start from the estimate's reciprocals): profiles/r05_ab_pair_rcp.jsonl
+#ifndef MEAO_X_FINAL_NT_STORE
+#define MEAO_X_FINAL_NT_STORE 0    // 1 = the result texels of the full-resolution pass with non-temporal stores (rounds 2-4; variant `ntstore`).  A 64-texel
+#endif                             // tile row of R8 results is HALF a 128-byte line, the other half belongs to the next tile: streamed out at once the
+                                   // halves cost 1.31x their bytes in HBM writes (WRITE_SIZE 10.82 MB per 4K frame for 8.29 MB of results; temporal:
+                                   // 8.30 MB -- L2 merges the halves), last kernel 268.7 -> 267.1 us: profiles/r05_result_store_write_size.txt,
+                                   // r05_ab_result_stores.jsonl.  (fp16 results are whole lines per tile row: 1.00x either way.)
 #ifndef MEAO_X_HOT_PATH_ONLY
 #define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
 #endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the

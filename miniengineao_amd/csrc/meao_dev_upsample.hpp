@@ -724,8 +724,9 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 ao_t *o = dst + hrow;
                 if (vec_ok) {
                     typename AO::type4 r4; r4.x = res[0]; r4.y = res[1]; r4.z = res[2]; r4.w = res[3];
-                    // the result leaves the path; the blend passes' outputs are re-read by the next pass from L2
-                    if constexpr (FINAL) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
+                    // the blend passes' outputs are re-read by the next pass from L2; the result leaves the path, but a tile row of it is half a
+                    // cache line (R8): temporal stores let L2 merge it with the neighbouring tile's half (MEAO_X_FINAL_NT_STORE)
+                    if constexpr (FINAL && MEAO_X_FINAL_NT_STORE) __builtin_nontemporal_store(r4, reinterpret_cast<typename AO::type4 *>(o));
                     else *reinterpret_cast<typename AO::type4 *>(o) = r4;
                 } else {
 #pragma unroll

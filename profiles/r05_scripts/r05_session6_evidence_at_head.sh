@@ -27,5 +27,7 @@ PY
 bash tools/run_rocprof.sh $TAG > gpurun_out/rocprof_$TAG.log 2>&1
 python tools/rocprof_timed_region.py gpurun_out/prof_$TAG/trace_kernel_trace.csv 30
 PMC_GROUPS="sq1 sq2 sq5 fetch write" bash tools/run_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
+PMC_GROUPS="sq1 fetch write" bash tools/run_pmc.sh ${TAG}_1080p --workload 1080p > gpurun_out/pmc_${TAG}_1080p.log 2>&1
+PMC_GROUPS="sq1 fetch write" bash tools/run_pmc.sh ${TAG}_8k --workload 8k > gpurun_out/pmc_${TAG}_8k.log 2>&1
 timeout 600 python tools/fuzz_gpu.py 200 12000 > gpurun_out/${TAG}_fuzz_gpu.log 2>&1; tail -1 gpurun_out/${TAG}_fuzz_gpu.log
 # (the 6000-case fuzz and the variant fuzz runs were made by the previous run of this script, same kernels: profiles/r05_fuzz_gpu_long.log, r05_fuzz_gpu_variant_*.log)
