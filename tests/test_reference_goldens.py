@@ -19,13 +19,16 @@ def _case(oracle, name):
     return fx, H.settings(oracle, w, h, cam=cam, **over)
 
 
+FULL_CASES = sorted(n for n in R.CASES if n not in R.CHECKSUM_CASES)      # fixtures that hold all 17 buffers
+
+
 def _same(name):
     """Bit equality; frames with NaN texels compare any-NaN == any-NaN (the payload of a NaN that went through
     arithmetic is not part of the contract, tests/helpers.py)."""
     return (lambda a, b: H.nan_aware_equal(a, b)[0]) if name in R.HOSTILE_CASES else np.array_equal
 
 
-@pytest.mark.parametrize("name", sorted(R.CASES))
+@pytest.mark.parametrize("name", FULL_CASES)
 def test_oracle_matches_reference_shader_outputs(oracle, name):
     fx, s = _case(oracle, name)
     w, h, kind, seed, cam, over, sky = R.CASES[name]
@@ -221,7 +224,7 @@ def test_interpreter_semantics():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(R.CASES))
+@pytest.mark.parametrize("name", FULL_CASES)
 def test_gpu_matches_reference_shader_outputs(name):
     from oracle import oracle as O      # Settings container only
     fx, s = _case(O, name)
@@ -232,6 +235,60 @@ def test_gpu_matches_reference_shader_outputs(name):
         assert same(got, fx["result"]), H.diff_report("result", got, fx["result"])
         for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
             assert same(ao.debug_buffer(i), fx[H.NAMES[i]]), H.NAMES[i]
+    finally:
+        ao.close()
+
+
+# ---- BASELINE config 2's size, from the reference's text: the result texture + a checksum of every buffer ------------------------
+
+def _checksum_case(oracle, name):
+    w, h, kind, seed, cam, over, sky = R.CASES[name]
+    path = os.path.join(HERE, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.npz not generated yet (an hour of interpreter time: tests/golden/make_reference_goldens.py {name})")
+    fx = np.load(path)
+    depth = R.make_depth(kind, w, h, seed, cam, sky)
+    assert np.uint64(H.checksum(depth)) == fx["depth_checksum"], "the synthetic frame is not the one the fixture was made from"
+    return fx, depth, H.settings(oracle, w, h, cam=cam, **over)
+
+
+@pytest.mark.parametrize("name", R.CHECKSUM_CASES)
+def test_oracle_matches_the_reference_text_at_1080p(oracle, name):
+    fx, depth, s = _checksum_case(oracle, name)
+    out = oracle.run(depth, s)
+    assert np.array_equal(out["result"], fx["result"]), H.diff_report("result", out["result"], fx["result"])
+    for key, arr in out.items():
+        assert np.uint64(H.checksum(arr)) == fx["checksum_" + key], key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipelined", [False, True])
+@pytest.mark.parametrize("name", R.CHECKSUM_CASES)
+def test_gpu_matches_the_reference_text_at_1080p(name, pipelined):
+    """The default launch structures at BASELINE config 2's size (one call; and the pipelined path: the frame's downsample pass
+    carried by the previous call's last kernel) against what the reference's text produced -- no oracle in the loop."""
+    import torch
+    from oracle import oracle as O
+    fx, depth, s = _checksum_case(O, name)
+    ao = H.component(s, max_batch=2, pipelined=pipelined)
+    try:
+        if not pipelined:
+            got = ao.render(depth)
+            frame = 0
+        else:
+            dev = torch.device("cuda", 0)
+            other = R.make_depth("S2", s.width, s.height, 99, R.CASES[name][4], False)
+            d = [torch.from_numpy(other).to(dev), torch.from_numpy(depth).to(dev)]
+            out = [torch.zeros((s.height, s.width), dtype=torch.uint8, device=dev) for _ in range(2)]
+            st = torch.cuda.Stream(dev)
+            for k in range(2):          # the second call consumes the downsample pass the first one carried
+                ao.prefetch_device([t.data_ptr() for t in d])
+                ao.execute_device([t.data_ptr() for t in d], [t.data_ptr() for t in out], st.cuda_stream)
+            st.synchronize()
+            got, frame = out[1].cpu().numpy(), 1
+        assert np.array_equal(got, fx["result"]), H.diff_report("result", got, fx["result"])
+        for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+            assert np.uint64(H.checksum(ao.debug_buffer(i, frame=frame))) == fx["checksum_" + H.NAMES[i]], H.NAMES[i]
     finally:
         ao.close()
 
