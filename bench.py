@@ -204,6 +204,8 @@ class Workload:
                 c.set_tracing(True)
             if args.side_stream and self.pipelined:
                 c.debug_set(_lib.DEBUG_DS_SIDE_STREAM, args.side_stream)
+            if args.blend_tall_min_tiles is not None:
+                c.debug_set(_lib.DEBUG_BLEND_TALL_MIN_TILES, args.blend_tall_min_tiles)
             self.ctxs.append(c)
         self.ao = self.ctxs[0]
         tstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(self.nfl - 1)]
@@ -539,6 +541,8 @@ def main() -> int:
                     help="meao_debug_set(MEAO_DEBUG_DS_SIDE_STREAM, MODE): the next step's downsample pass as its own kernel on the "
                          "context's low-priority side stream instead of inside the last upsample kernel (4 = released at the start "
                          "of the call).  Kernels then overlap: per-kernel durations are no longer attributable, the line says so")
+    ap.add_argument("--blend-tall-min-tiles", type=int, default=None, metavar="TILES",
+                    help="meao_debug_set(MEAO_DEBUG_BLEND_TALL_MIN_TILES, TILES): L2 -> L1 blend launches of at least TILES 64x32 tiles use 64x64 tiles")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not use meao_prefetch_batch: every step launches its own downsample pass instead of "
                          "carrying the next step's inside its last upsample kernel")

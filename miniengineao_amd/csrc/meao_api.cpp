@@ -91,6 +91,11 @@ struct meao_ctx {
     int render_from_depth_max_tiles = 1024;      // frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190)
     hipStream_t rfd_stream = nullptr;            // form 2
     hipEvent_t rfd_fork = nullptr, rfd_join = nullptr;
+    // L2 -> L1 launches of at least this many 64x32 tiles (frames x tiles; 4K: 1020 per frame) use 64x64 tiles with R8 AO storage
+    // (upsample_blend_tall_kernel): 53.9 -> 52.5 us per 16 frames at 4K, 57.7 -> 56.3 at 1080p x 64, fp16 storage +-0
+    // (profiles/r05_ab_blend_tall.jsonl).  MEAO_DEBUG_BLEND_TALL_MIN_TILES overrides it for both storage formats.
+    int blend_tall_min_tiles = 4096;
+    bool blend_tall_forced = false;
     int ds_share_in_blend = 0;         // percent of the carried (next batch's) downsample tiles that ride in the L2->L1 blend launch instead of the last kernel
     // MEAO_DEBUG_DS_SIDE_STREAM (0 = off): the announced next batch's downsample pass as its OWN kernel on a second,
     // low-priority stream of the context, gated behind a point of this call's launch sequence, instead of riding inside
@@ -560,8 +565,15 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     auto launch_blend = [&](int hi, hipStream_t s) -> int {   // hi = 3, 2, 1
         const int pass = MEAO_PASS_UPSAMPLE_0 - hi;
         TraceRange tr(ctx, kUpsRange[hi]);
+        UpsampleArgs up = upsample_args(hi);
+        // L2 -> L1 of a large batch: 64 x 64 tiles like the full-resolution pass (upsample_blend_tall_kernel)
+        if (hi == 1 && (c.ao_format == MEAO_AO_R8 || ctx->blend_tall_forced) &&
+            static_cast<int64_t>(n) * up.tiles_x * up.tiles_y >= ctx->blend_tall_min_tiles) {
+            up.tile_h = kUpsTileHTall;
+            up.tiles_y = (up.hh + up.tile_h - 1) / up.tile_h;
+        }
         MEAO_HIP(ctx, begin(pass, s));
-        MEAO_HIP(ctx, launch_upsample(upsample_args(hi), c.ao_format, false, n, s));
+        MEAO_HIP(ctx, launch_upsample(up, c.ao_format, false, n, s));
         MEAO_HIP(ctx, end(pass, s));
         return MEAO_OK;
     };
@@ -1420,6 +1432,10 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
         ctx->render_from_depth = value;
         break;
     case MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES: ctx->render_from_depth_max_tiles = value; break;
+    case MEAO_DEBUG_BLEND_TALL_MIN_TILES:
+        ctx->blend_tall_min_tiles = value <= 0 ? 0x7fffffff : value;
+        ctx->blend_tall_forced = true;
+        break;
     case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
     case MEAO_DEBUG_DS_SIDE_STREAM:
         if (value < 0 || value % 10 > 4 || (value > 0 && value % 10 == 0) || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)

@@ -20,6 +20,15 @@ __global__ __launch_bounds__(kThreads) void upsample_final_small_kernel(const Up
     upsample_tile_checked<AOFMT, RTNE, true, DIV, NoHook, kUpsTileHSmall>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
 }
 
+// Upsample.main_blendout with the full-resolution pass's 64 x 64 tiles, for launches of many tiles (L2 -> L1 of a batch: 16 320 tiles
+// of 64 x 32 at 4K x 16): half the barriers and window fills per texel, apron share 1.4x instead of 1.6x; six workgroups per CU
+// (23.7 KB windows, <= 80 VGPRs).  MEAO_DEBUG_BLEND_TALL_MIN_TILES.
+template <int AOFMT, bool RTNE, int DIV>
+__global__ __launch_bounds__(kThreads, 6) void upsample_blend_tall_kernel(const UpsampleArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[UpsLds<false, kUpsTileHTall>::kFloats];
+    upsample_tile_checked<AOFMT, RTNE, false, DIV, NoHook, kUpsTileHTall>(a, smem, xcd_contiguous(blockIdx.x, gridDim.x), blockIdx.z);
+}
 
 }  // namespace
 
@@ -31,6 +40,7 @@ static void launch_upsample_t(const UpsampleArgs &a, bool final_pass, dim3 grid,
 {
     if (final_pass && a.tile_h == kUpsTileHSmall) upsample_final_small_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else if (final_pass) upsample_kernel<AOFMT, RTNE, true, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
+    else if (a.tile_h == kUpsTileHTall) upsample_blend_tall_kernel<AOFMT, RTNE, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
     else upsample_kernel<AOFMT, RTNE, false, DIV><<<grid, dim3(kThreads), 0, s>>>(a);
 }
 

@@ -86,6 +86,7 @@ constexpr int kWideLdsW = kWideTileW + 2 * kWideApron, kWideLdsH = kRenTileH + 2
 // frame and run faster with 64 x 32 (measured on one MI355X, see profiles/README.md).
 constexpr int kUpsTileW = 64;
 constexpr int ups_tile_h(bool final_pass) { return final_pass ? 64 : 32; }
+constexpr int kUpsTileHTall = 64;               // a blend pass with many tiles (UpsampleArgs::tile_h; upsample_blend_tall_kernel)
 constexpr int kUpsTileHSmall = 32;              // the final pass of calls with few 64 x 64 tiles (UpsampleArgs::tile_h)
 
 struct UpsampleArgs {

@@ -443,6 +443,39 @@ def test_render_from_depth_inside_a_captured_launch_sequence(oracle, form):
         ao.close()
 
 
+@pytest.mark.parametrize("variant", [dict(), dict(ao_format=1, f16_rounding=1), dict(num_levels=2), dict(hq_levels=2)])
+@pytest.mark.parametrize("w,h,batch", [(644, 364, 3), (1280, 720, 2), (203, 117, 2), (2048, 1152, 1)])
+def test_l2_to_l1_blend_with_64x64_tiles_is_bit_exact(oracle, variant, w, h, batch):
+    """MEAO_DEBUG_BLEND_TALL_MIN_TILES: the L2 -> L1 pass with the full-resolution pass's 64 x 64 tiles (upsample_blend_tall_kernel),
+    plain and pipelined, a hostile frame, every buffer of every frame against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = H.settings(oracle, w, h, **variant)
+    frames = [synth.make("S2", w, h, seed=40 + f) for f in range(batch)]
+    frames[-1] = H.hostile_frame(w, h, 43, density=0.004)
+    elem = torch.uint8 if s.ao_format == oracle.AO_R8 else torch.int16
+    for pipelined in (False, True):
+        ao = H.component(s, max_batch=batch, pipelined=pipelined, debug={L.DEBUG_BLEND_TALL_MIN_TILES: 1, L.DEBUG_NESTED_MAX_TILES: 0})
+        try:
+            dd = [torch.from_numpy(f).to(dev) for f in frames]
+            out = [torch.zeros((h, w), dtype=elem, device=dev) for _ in frames]
+            st = torch.cuda.Stream(dev)
+            for k in range(2):
+                if pipelined:
+                    ao.prefetch_device([t.data_ptr() for t in dd])
+                ao.execute_device([t.data_ptr() for t in dd], [t.data_ptr() for t in out], st.cuda_stream)
+            st.synchronize()
+            for f in range(batch):
+                want = oracle.run(frames[f], s)
+                ok, bad = H.nan_aware_equal(out[f].cpu().numpy().view(want["result"].dtype), want["result"])
+                assert ok, (pipelined, f, int(bad.sum()))
+                for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
+                    ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
+                    assert ok, (H.NAMES[i], pipelined, f, int(bad.sum()))
+        finally:
+            ao.close()
+
+
 def test_sampled_profiling_brackets_every_nth_execute(oracle):
     """meao_set_profiling(N > 1): events around the passes of executes 0, N, 2N, ... only; the others run bare."""
     w, h = 322, 182
