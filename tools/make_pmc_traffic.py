@@ -26,6 +26,7 @@ KERNELS = {
     "render_kernel": ("render", FETCH_FACTOR, "FETCH_SIZE x2 (calibrated)"),
     "upsample_kernel<A, false, true": ("upsample_L1_to_L0", FETCH_FACTOR, "FETCH_SIZE x2 (calibrated; rounds 2-4 left this row raw = half)"),
     "upsample_kernel<A, false, false": ("upsample_blend_passes", FETCH_FACTOR, "mean of the stand-alone main_blendout launches (L2->L1 only when L4->L3 rides inside L3->L2); FETCH_SIZE x2 (calibrated)"),
+    "upsample_blend_tall_kernel<A, false": ("upsample_blend_passes", FETCH_FACTOR, "the L2->L1 launch with 64 x 64 tiles (large R8 batches); FETCH_SIZE x2 (calibrated)"),
     "upsample_two_level_kernel<A, false": ("upsample_L4_to_L3+L3_to_L2", FETCH_FACTOR, "the fused two-level launch; FETCH_SIZE x2 (calibrated)"),
     "upsample_final_with_next_downsample_kernel<A, false": ("upsample_L1_to_L0+downsample_next", FETCH_FACTOR,
                                                            "FETCH_SIZE x2 (calibrated; rounds 2-4 doubled only the carried depth stream)"),
