@@ -60,6 +60,10 @@ for k in range(count):
     if k % 3 == 2:          # a third of the cases: render windows from the RAW depth frame (one launch with the pass / two streams)
         from miniengineao_amd import _lib
         ao.debug_set(_lib.DEBUG_RENDER_FROM_DEPTH, 1 + (k // 3) % 2)
+    if k % 7 == 3:          # a seventh of the cases: the L2 -> L1 pass on 64 x 64 tiles whatever the size (large R8 batches take them by default)
+        from miniengineao_amd import _lib
+        ao.debug_set(_lib.DEBUG_BLEND_TALL_MIN_TILES, 1)
+        ao.debug_set(_lib.DEBUG_NESTED_MAX_TILES, 0)
     outs = ao.render_batch([depth, depth])
     ok = same(outs[0], want["result"]) and same(outs[1], want["result"])
     for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
