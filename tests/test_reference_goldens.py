@@ -281,7 +281,7 @@ def _checksum_case(oracle, name):
 
 
 @pytest.mark.parametrize("name", R.CHECKSUM_CASES)
-def test_oracle_matches_the_reference_text_at_1080p(oracle, name):
+def test_oracle_matches_the_reference_text_at_baseline_sizes(oracle, name):
     fx, depth, s = _checksum_case(oracle, name)
     out = oracle.run(depth, s)
     assert np.array_equal(out["result"], fx["result"]), H.diff_report("result", out["result"], fx["result"])
@@ -292,8 +292,8 @@ def test_oracle_matches_the_reference_text_at_1080p(oracle, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("name", R.CHECKSUM_CASES)
-def test_gpu_matches_the_reference_text_at_1080p(name, pipelined):
-    """The default launch structures at BASELINE config 2's size (one call; and the pipelined path: the frame's downsample pass
+def test_gpu_matches_the_reference_text_at_baseline_sizes(name, pipelined):
+    """The default launch structures at BASELINE's sizes (config 2's 1080p atrium frame, the metric's 4K frame; one call; and the pipelined path: the frame's downsample pass
     carried by the previous call's last kernel) against what the reference's text produced -- no oracle in the loop."""
     import torch
     from oracle import oracle as O
