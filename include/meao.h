@@ -430,8 +430,11 @@ typedef enum meao_debug_key {
                                         * Measured slower than the stored-mip sequence at every call size (the gathered windows touch
                                         * 2^level times the cache lines): an option, not the default. */
     MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES = 9,  /* frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190); default 1024 */
-    MEAO_DEBUG_BLEND_TALL_MIN_TILES = 10 /* L2 -> L1 blend launches of at least this many 64x32 tiles (frames x tiles) use 64x64 tiles, either AO
+    MEAO_DEBUG_BLEND_TALL_MIN_TILES = 10, /* L2 -> L1 blend launches of at least this many 64x32 tiles (frames x tiles) use 64x64 tiles, either AO
                                           * storage format; 0 = never.  Default: 4096, R8 storage only */
+    MEAO_DEBUG_PROFILE_PASS_MASK = 11    /* meao_set_profiling: bit k set = launch slot k (meao_pass) is bracketed with events; 0 = all (default).
+                                          * Each event record is a marker packet between two launches (1 - 4 % of a batched step for all
+                                          * eight): a host that wants one kernel's duration in a throughput run asks for that slot only */
 } meao_debug_key;
 MEAO_API int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value);
 

@@ -47,7 +47,7 @@ DEBUG_OCCLUSION_HQ1 = 18
 # exists only in the `testhooks` variant library, built with -DMEAO_TESTING=1)
 (DEBUG_FUSE_COARSE_BLEND, DEBUG_NESTED_MAX_TILES, DEBUG_RENDER_SMALL_MAX_TILES, DEBUG_FINAL_SMALL_MAX_TILES,
  DEBUG_DS_SMALL_MAX_TILES, _DEBUG_RESERVED_5, DEBUG_DS_SHARE_IN_BLEND, DEBUG_DS_SIDE_STREAM, DEBUG_RENDER_FROM_DEPTH,
- DEBUG_RENDER_FROM_DEPTH_MAX_TILES, DEBUG_BLEND_TALL_MIN_TILES) = range(11)
+ DEBUG_RENDER_FROM_DEPTH_MAX_TILES, DEBUG_BLEND_TALL_MIN_TILES, DEBUG_PROFILE_PASS_MASK) = range(12)
 POOL_PATH_SAME_DEVICE, POOL_PATH_PEER_DIRECT, POOL_PATH_STAGED = 0, 1, 2
 NUM_BUFFERS = 21
 

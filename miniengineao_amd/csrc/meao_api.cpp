@@ -132,6 +132,7 @@ struct meao_ctx {
     // profiling: a ring of per-execute event sets (one start/end pair per launch slot); each entry
     // remembers which slots it used
     bool profiling = false;
+    uint32_t profile_mask = ~0u;                 // MEAO_DEBUG_PROFILE_PASS_MASK: bit k = launch slot k is bracketed with events
     int profile_period = 1, profile_phase = 0;   // meao_set_profiling(N > 1): every Nth execute is bracketed with events, the others run bare
     std::vector<hipEvent_t> events;              // kProfileRing * kProfSlots * 2
     int ring_fill = 0;
@@ -371,8 +372,12 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         ev = &ctx->events[ctx->ring_fill * kProfSlots * 2];
     }
     // one launch = one profiling slot: events right before and after it on ITS stream
-    auto begin = [&](int slot, hipStream_t s) -> hipError_t { return ev ? hipEventRecord(ev[slot * 2], s) : hipSuccess; };
+    const uint32_t profile_mask = ctx->profile_mask;
+    auto begin = [&](int slot, hipStream_t s) -> hipError_t {
+        return ev && (profile_mask >> slot & 1u) ? hipEventRecord(ev[slot * 2], s) : hipSuccess;
+    };
     auto end = [&](int slot, hipStream_t s) -> hipError_t {
+        if (!(profile_mask >> slot & 1u)) return hipSuccess;
         ran |= 1u << slot;
         return ev ? hipEventRecord(ev[slot * 2 + 1], s) : hipSuccess;
     };
@@ -1432,6 +1437,7 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
         ctx->render_from_depth = value;
         break;
     case MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES: ctx->render_from_depth_max_tiles = value; break;
+    case MEAO_DEBUG_PROFILE_PASS_MASK: ctx->profile_mask = value == 0 ? ~0u : static_cast<uint32_t>(value); break;
     case MEAO_DEBUG_BLEND_TALL_MIN_TILES:
         ctx->blend_tall_min_tiles = value <= 0 ? 0x7fffffff : value;
         ctx->blend_tall_forced = true;

@@ -498,6 +498,29 @@ def test_sampled_profiling_brackets_every_nth_execute(oracle):
         ao.close()
 
 
+def test_profiling_of_selected_passes_only(oracle):
+    """MEAO_DEBUG_PROFILE_PASS_MASK: only the launch slots named by the mask are bracketed with events (a host that wants one
+    kernel's duration in a throughput run pays for one pair of marker packets, not eight); 0 = all again.  Results unchanged."""
+    w, h = 644, 364
+    s = H.settings(oracle, w, h)
+    depth = synth.make("S2", w, h, seed=5)
+    want = oracle.run(depth, s, result_only=True)["result"]
+    ao = H.component(s)
+    try:
+        names = list(L.PASS_NAMES)
+        final, render = names.index("upsample_L1_to_L0"), names.index("render")
+        for mask, expect in ((1 << final, {final}), ((1 << final) | (1 << render), {final, render}), (0, None)):
+            ao.debug_set(L.DEBUG_PROFILE_PASS_MASK, mask)
+            ao.set_profiling(True)
+            for _ in range(3):
+                assert np.array_equal(ao.render(depth), want)
+            ms, n = ao.pass_times_ms()
+            timed = {k for k in range(len(names)) if ms[k] > 0}
+            assert n == 3 and (timed == expect if expect is not None else {final, render, names.index("downsample")} <= timed), (mask, ms)
+    finally:
+        ao.close()
+
+
 def test_render_from_depth_is_an_option_and_falls_back(oracle):
     """The default is the stored-mip sequence (a separate downsample launch is timed); RENDER_FROM_DEPTH 3 lets small calls take the
     one-launch form -- no separate downsample time -- while larger ones and non-f32 depth keep the stored-mip form; results
