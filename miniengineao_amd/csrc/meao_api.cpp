@@ -1270,7 +1270,9 @@ int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable)
         ctx->events.reserve(count);
         for (int i = 0; i < count; ++i) {
             hipEvent_t ev;
-            MEAO_HIP(ctx, hipEventCreate(&ev));
+            // timing only: no system-scope fence (cache write-back + invalidate) when a record completes -- nothing synchronizes
+            // with these events but hipEventElapsedTime
+            MEAO_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
             ctx->events.push_back(ev);
         }
     }
