@@ -337,9 +337,11 @@ MEAO_API int32_t meao_composite_pending(const meao_ctx *ctx, int32_t *out_frames
  * the last reset (synchronises the stream); *out_samples = executes measured.
  * ms[MEAO_NUM_PASSES]; passes not run report 0.
  * enable: 0 = off; 1 = every execute; N > 1 = every Nth execute (the first one after the call included), the others run
- * without event records.  An event record is a marker packet between two launches: eight of them per 4K x 16 step cost
- * 1 - 4 % of the step depending on the box (bench.py `without_pass_events`), so a throughput measurement that also wants
- * kernel durations samples them. */
+ * without event records.  An event record is a marker packet between two launches; the events are created with
+ * hipEventDisableSystemFence (nothing synchronizes with them but hipEventElapsedTime), so a record does not write back and
+ * invalidate the caches: eight of them per 4K x 16 step cost 1 - 3 % of the step depending on the box (bench.py
+ * `without_pass_events`; with fenced events it was up to 4 %, and the short launches read 2 us longer).  meao_debug_set
+ * MEAO_DEBUG_PROFILE_PASS_MASK restricts the records to chosen passes. */
 MEAO_API int32_t meao_set_profiling(meao_ctx *ctx, int32_t enable);
 MEAO_API int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *out_samples);
 
