@@ -190,20 +190,16 @@ class Workload:
         self.nfl = max(1, in_flight)
         self.out_dev = [[torch.empty((h, w), dtype=ao_dtype, device=dev) for _ in range(self.B)] for _ in range(self.nfl)]
         self.pipelined = not args.no_pipeline
-        self.fast = args.fast_numerics
         self.ctxs = []
         for _ in range(self.nfl):
             c = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=self.ao_format, max_batch=self.B,
                                  near_clip=self.cam.near, far_clip=self.cam.far, projection00=self.cam.proj00(w, h),
                                  reversed_z=self.cam.reversed_z, hq_levels=self.hq_levels,
                                  sample_set=_lib.SAMPLES_EXHAUSTIVE if self.exhaustive else _lib.SAMPLES_CHECKER,
-                                 numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT,
                                  pipelined=self.pipelined)
             c.intensity = self.intensity
             if args.roctx:
                 c.set_tracing(True)
-            if args.side_stream and self.pipelined:
-                c.debug_set(_lib.DEBUG_DS_SIDE_STREAM, args.side_stream)
             if args.blend_tall_min_tiles is not None:
                 c.debug_set(_lib.DEBUG_BLEND_TALL_MIN_TILES, args.blend_tall_min_tiles)
             self.ctxs.append(c)
@@ -285,7 +281,7 @@ class Workload:
         sums = [frame_checksum(a) for a in host]
         all_sums = mdist.gather_checksums(sums, self.dev)
         validated = mismatched = 0
-        if frames_vs_oracle > 0 and not self.fast:
+        if frames_vs_oracle > 0:
             O, s = oracle_settings(self.w, self.h, self.cam, self.intensity, self.ao_format, self.hq_levels, self.exhaustive)
             order = list(dict.fromkeys([0, self.B - 1] + list(range(self.B))))      # first, last, then the rest
             threads = max(1, O.host_cores() // max(self.world, 1))
@@ -340,7 +336,7 @@ def measure_other_workload(name, args, dev, local_rank):
         wl.close()
 
 
-def measure_pool(args, G, B=None, ramp_s=0.080, side_stream=None) -> dict:
+def measure_pool(args, G, B=None, ramp_s=0.080) -> dict:
     """The in-process host of DESIGN.md section 7: ONE process drives G pool members through the C ABI
     (meao_pool_prefetch_batch + meao_pool_execute_batch), member m on device m mod (visible devices) --
     all on device 0 on a 1-GPU box, devices 0..G-1 on a real node.  Same step, same JSON as the
@@ -362,10 +358,6 @@ def measure_pool(args, G, B=None, ramp_s=0.080, side_stream=None) -> dict:
                                 projection00=cam.proj00(w, h), reversed_z=cam.reversed_z, intensity=intensity,
                                 pipelined=pipelined)
     lib = _lib.load()
-    side_stream = args.side_stream if side_stream is None else side_stream
-    if side_stream and pipelined:
-        for m in range(G):
-            _lib.check(lib.meao_debug_set(pool.member_context(m), _lib.DEBUG_DS_SIDE_STREAM, side_stream))
     dptr, optr = [t.data_ptr() for t in depth_dev], [t.data_ptr() for t in out_dev]
 
     def sync_all():
@@ -412,7 +404,7 @@ def measure_pool(args, G, B=None, ramp_s=0.080, side_stream=None) -> dict:
     host = [t.cpu().numpy() for t in out_dev]
     sums = [frame_checksum(a) for a in host]
     validated = mismatched = 0
-    if args.validate_frames != 0 and not args.fast_numerics:
+    if args.validate_frames != 0:
         O, s = oracle_settings(w, h, cam, intensity, ao_format)
         for g in sorted({m for m in range(G)} | {n - 1 - m for m in range(G)}):
             want = O.run(frames[g], s, nthreads=O.host_cores(), result_only=True)["result"]
@@ -430,7 +422,6 @@ def measure_pool(args, G, B=None, ramp_s=0.080, side_stream=None) -> dict:
                    "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
                    "host": "ONE process, meao_pool_* (C ABI): frame g -> member g mod G, one calling thread "
                            "(the pool enqueues each member's launches from its own worker thread)",
-                   "downsample_side_stream_mode": side_stream if pipelined else 0,
                    "member_devices": devices,
                    "downsample": "pipelined (meao_pool_prefetch_batch)" if pipelined else "own pass per step"},
         "per_member_ms": per_member, "gather_paths": paths,
@@ -531,17 +522,11 @@ def main() -> int:
                          "same work as separate composite launches")
     ap.add_argument("--ao-format", choices=["r8", "f16"], default=None,
                     help="override the AO storage of the workload (R8 = reference, F16 = fp16 AO)")
-    ap.add_argument("--fast-numerics", action="store_true",
-                    help="MEAO_NUMERICS_FAST (raw v_rcp_f32 divides; NOT bit-exact, outside the parity bar, reported as such)")
     ap.add_argument("--hq-levels", type=int, default=0,
                     help="variant (not the reference's wiring): the coarsest N levels also run Render.main "
                          "(wide) and the upsamples become main_premin*; changes config.workload")
     ap.add_argument("--exhaustive", action="store_true",
                     help="variant: SAMPLE_EXHAUSTIVELY (68 samples instead of 36); changes config.workload")
-    ap.add_argument("--side-stream", type=int, default=0, metavar="MODE",
-                    help="meao_debug_set(MEAO_DEBUG_DS_SIDE_STREAM, MODE): the next step's downsample pass as its own kernel on the "
-                         "context's low-priority side stream instead of inside the last upsample kernel (4 = released at the start "
-                         "of the call).  Kernels then overlap: per-kernel durations are no longer attributable, the line says so")
     ap.add_argument("--blend-tall-min-tiles", type=int, default=None, metavar="TILES",
                     help="meao_debug_set(MEAO_DEBUG_BLEND_TALL_MIN_TILES, TILES): L2 -> L1 blend launches of at least TILES 64x32 tiles use 64x64 tiles")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -756,19 +741,15 @@ def main() -> int:
                             "ms_per_step": round(dt / args.steps * 1e3, 4)}
         shaded["note"] = "next tier, not part of `value`: AO + Blit.shader pass 2 on an RGBA16F frame per step"
 
-    # single-frame use (one frame per call, the real-time case): one launch per pass (DIRECT) vs one
-    # hipGraphLaunch per call (MEAO_LAUNCH_GRAPH); back-to-back calls, and call + wait per frame
+    # single-frame use (one frame per call, the real-time case): back-to-back calls, and call + wait per frame
     latency_ms, single = None, None
     if not args.skip_latency:
         def one_frame_ctx(**kw):
             c = AmbientOcclusion(w, h, device=local_rank, num_levels=4, ao_format=ao_format, max_batch=1,
                                  near_clip=cam.near, far_clip=cam.far, projection00=cam.proj00(w, h),
                                  reversed_z=cam.reversed_z, hq_levels=args.hq_levels,
-                                 sample_set=_lib.SAMPLES_EXHAUSTIVE if args.exhaustive else _lib.SAMPLES_CHECKER,
-                                 numerics=_lib.NUMERICS_FAST if args.fast_numerics else _lib.NUMERICS_STRICT, **kw)
+                                 sample_set=_lib.SAMPLES_EXHAUSTIVE if args.exhaustive else _lib.SAMPLES_CHECKER, **kw)
             c.intensity = intensity
-            if args.side_stream and kw.get("pipelined"):
-                c.debug_set(_lib.DEBUG_DS_SIDE_STREAM, args.side_stream)
             return c
         lat_iters = 50
         single = {}
@@ -777,13 +758,8 @@ def main() -> int:
         single_mismatches = {}
         # "pipelined": a stream of single frames whose next depth buffer is known one call ahead
         # (meao_prefetch_batch with n = 1: each call's last kernel carries the next frame's downsample pass).
-        # "direct" = the library's default sequence (downsample | render | blends | final); "direct_raw_depth_one_launch" /
-        # "direct_raw_depth_two_streams" = MEAO_DEBUG_RENDER_FROM_DEPTH 1 / 2: render windows from the raw depth frame, the
-        # downsample pass as extra workgroups of the render launch / next to it on a second stream (round 5: built, bit-exact,
-        # not faster -- the in-line A/B stays so that every bench line shows it)
-        variants = (("direct", {}), ("direct_raw_depth_one_launch", {"_debug": {_lib.DEBUG_RENDER_FROM_DEPTH: 1}}),
-                    ("direct_raw_depth_two_streams", {"_debug": {_lib.DEBUG_RENDER_FROM_DEPTH: 2}}),
-                    ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}), ("direct_pipelined", {"pipelined": True}))
+        # "direct" = the library's default sequence (downsample | render | blends | final)
+        variants = (("direct", {}), ("direct_pipelined", {"pipelined": True}))
         for name, kw in variants:
             kw = dict(kw)
             debug = kw.pop("_debug", {})
@@ -819,7 +795,7 @@ def main() -> int:
 
     # BASELINE configs 2 and 5 on the same clock: short sub-measurements (N = 1, default line only)
     others = None
-    if rank == 0 and world == 1 and not args.no_other_workloads and not (args.hq_levels or args.exhaustive or args.fast_numerics):
+    if rank == 0 and world == 1 and not args.no_other_workloads and not (args.hq_levels or args.exhaustive):
         others = {}
         for name in ("1080p", "8k"):
             if name != args.workload:
@@ -831,14 +807,14 @@ def main() -> int:
     # context above, where per-kernel durations are attributable.
     best_host = None
     if (rank == 0 and world == 1 and not args.no_best_host_config and B >= 2 and nfl == 1 and pipelined
-            and not (args.hq_levels or args.exhaustive or args.fast_numerics or args.ao_format or args.side_stream)):
+            and not (args.hq_levels or args.exhaustive or args.ao_format)):
         torch.cuda.empty_cache()
-        # candidates: (pool members on device 0, MEAO_DEBUG_DS_SIDE_STREAM mode of every member); all run the same step on the
-        # same frames and are validated like the headline (every output checksummed, first / last frame of every member vs the oracle)
+        # the step dealt to two pool members on device 0, validated like the headline (every output checksummed, first / last
+        # frame of every member vs the oracle)
         tried = []
-        for members, side in ((1, 4), (2, 0), (2, 4)):
-            pl = measure_pool(args, members, B // members, ramp_s=0.050, side_stream=side)
-            tried.append({"pool_members": members, "frames_per_member": B // members, "downsample_side_stream_mode": side,
+        for members in (2,):
+            pl = measure_pool(args, members, B // members, ramp_s=0.050)
+            tried.append({"pool_members": members, "frames_per_member": B // members,
                           "value": pl["value"], "ms_per_step": pl["ms_per_step"], "steps": pl["steps"],
                           "per_member_ms": pl["per_member_ms"], "validation": pl["validation"]})
         ok = [t for t in tried if t["validation"]["mismatching_frames"] == 0 and t["validation"]["frames_vs_oracle"] > 0]
@@ -846,8 +822,8 @@ def main() -> int:
             best = max(ok, key=lambda t: t["value"])
             best_host = dict(best, unit="Mpixels/s", vs_single_context=round(best["value"] / value, 4),
                              host="ONE process, meao_pool_* members on device 0 (frame g -> member g mod members), pipelined step",
-                             candidates=[{k: t[k] for k in ("pool_members", "downsample_side_stream_mode", "value", "ms_per_step")} for t in tried],
-                             note="kernels of co-running members / of the side stream overlap: per-kernel durations are not "
+                             candidates=[{k: t[k] for k in ("pool_members", "value", "ms_per_step")} for t in tried],
+                             note="kernels of co-running members overlap: per-kernel durations are not "
                                   "attributable there, so `value` and the roofline rows stay on the single-context leg")
 
     if rank == 0:
@@ -862,13 +838,10 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": desc, "width": w, "height": h, "frames_per_step_per_gpu": B,
                        "num_levels": 4, "ao_storage": "R8" if ao_format == _lib.AO_R8 else "F16",
-                       "numerics": "FAST (raw rcp, not bit-exact, outside the parity bar)" if args.fast_numerics else "strict (bit-exact vs CPU oracle)",
+                       "numerics": "strict (bit-exact vs CPU oracle)",
                        "sharding": f"frames x{world}", "batches_in_flight": nfl, "process_group": args.dist_backend if mdist.group_info()["initialized"] else None,
                        "downsample": ("own pass per step" if not pipelined else
-                                      "pipelined: each step's last kernel carries the next step's downsample pass (meao_prefetch_batch)"
-                                      if not args.side_stream else
-                                      f"pipelined: the next step's downsample pass runs as its own kernel on a low-priority side stream "
-                                      f"(MEAO_DEBUG_DS_SIDE_STREAM {args.side_stream}); kernels overlap, per-kernel rows are not attributable")},
+                                      "pipelined: each step's last kernel carries the next step's downsample pass (meao_prefetch_batch)")},
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
             "depth_in_to_shaded_frame_out": shaded,
             "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],

@@ -51,8 +51,7 @@ namespace MiniEngineAO
         // hqLevels / sampleSet: variants the reference's shaders carry but its host never dispatches.
         public AmbientOcclusion(int pixelWidth, int pixelHeight, int device = 0,
                                 MeaoAoFormat aoFormat = MeaoAoFormat.R8, int maxBatch = 1,
-                                int hqLevels = 0, MeaoSampleSet sampleSet = MeaoSampleSet.Checker,
-                                MeaoLaunchMode launchMode = MeaoLaunchMode.Direct)
+                                int hqLevels = 0, MeaoSampleSet sampleSet = MeaoSampleSet.Checker)
         {
             Meao.meao_default_config(out _cfg);
             _cfg.device = device;
@@ -62,7 +61,6 @@ namespace MiniEngineAO
             _cfg.max_batch = maxBatch;
             _cfg.hq_levels = hqLevels;
             _cfg.sample_set = (int)sampleSet;
-            _cfg.launch_mode = (int)launchMode;
             Check(Meao.meao_create(ref _cfg, out _ctx));
         }
 

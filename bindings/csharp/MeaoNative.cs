@@ -1,4 +1,4 @@
-// MeaoNative.cs -- P/Invoke declarations for libmeao_hip.so (include/meao.h, ABI version 3).
+// MeaoNative.cs -- P/Invoke declarations for libmeao_hip.so (include/meao.h, ABI version 6).
 //
 // NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT: the build image has no dotnet/mono/csc
 // (SURVEY.md, "Environment facts").  tests/test_host_mirror.py cross-checks every
@@ -20,13 +20,11 @@ namespace MiniEngineAO.Native
 
     public enum MeaoAoFormat { R8 = 0, F16 = 1 }
     public enum MeaoF16Rounding { RtzClamp = 0, Rtne = 1 }
-    public enum MeaoNumerics { Strict = 0, Fast = 1 }
     public enum MeaoMem { Host = 0, Device = 1 }
     public enum MeaoDepthFormat { F32 = 0, Unorm16 = 1, Unorm24 = 2, F16 = 3 }
     public enum MeaoCompositeMode { Multiply = 0, AmbientOnly = 1, Debug = 2 }
     public enum MeaoFormat { F32 = 0, F16 = 1, Unorm8 = 2 }
     public enum MeaoSampleSet { Checker = 0, Exhaustive = 1 }
-    public enum MeaoLaunchMode { Direct = 0, Graph = 1 }
 
     [StructLayout(LayoutKind.Sequential)]
     public struct MeaoConfig
@@ -38,12 +36,10 @@ namespace MiniEngineAO.Native
         public int num_levels;
         public int ao_format;
         public int f16_rounding;
-        public int numerics;
         public int max_batch;
         public int depth_format;
         public int hq_levels;
         public int sample_set;
-        public int launch_mode;
         public int pipelined;
     }
 
@@ -98,7 +94,7 @@ namespace MiniEngineAO.Native
     public static class Meao
     {
         const string Lib = "meao_hip";   // libmeao_hip.so
-        public const int AbiVersion = 5;
+        public const int AbiVersion = 6;
         public const int MaxBatch = 64;
         public const int NumPasses = 7;
         public const int DebugOcclusionHq1 = 18;
@@ -156,7 +152,7 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_pool_gather_path(IntPtr pool, int member, int dst_device);   // 0 same device, 1 peer (xGMI), 2 staged
         [DllImport(Lib)] public static extern int meao_pool_synchronize(IntPtr pool);
         [DllImport(Lib)] public static extern int meao_hostile_frames(IntPtr ctx, out ulong mask);
-        [DllImport(Lib)] public static extern int meao_debug_set(IntPtr ctx, int key, int value);   // launch-structure overrides / fault injection (tests)
+        [DllImport(Lib)] public static extern int meao_debug_set(IntPtr ctx, int key, int value);   // launch-structure overrides (tests, A/B runs)
         [DllImport(Lib)] public static extern int meao_debug_view(IntPtr ctx, int frame, int debug_id, IntPtr dst, int out_loc, IntPtr stream);
         [DllImport(Lib)] public static extern int meao_composite(IntPtr ctx, int mode, IntPtr ao, IntPtr color_rgba16f, IntPtr gbuffer0_rgba8, int loc, IntPtr stream);
     }

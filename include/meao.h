@@ -32,7 +32,7 @@ extern "C" {
 #define MEAO_API
 #endif
 
-#define MEAO_ABI_VERSION 5
+#define MEAO_ABI_VERSION 6
 #define MEAO_MAX_BATCH 64      /* frames per batched launch */
 #define MEAO_NUM_PASSES 7      /* downsample, render, upsample x4, render_hq (see meao_pass) */
 
@@ -59,29 +59,9 @@ typedef enum meao_ao_format { MEAO_AO_R8 = 0, MEAO_AO_F16 = 1 } meao_ao_format;
  * hardware behaviour.  Only matters for sky texels (1e5) and the last mantissa bit. */
 typedef enum meao_f16_rounding { MEAO_F16_RTZ_CLAMP = 0, MEAO_F16_RTNE = 1 } meao_f16_rounding;
 
-/* STRICT (default): bit-exact against the CPU oracle (correctly rounded '/', explicit mad fusion
- * only).  FAST: every divide is the raw 1-ulp v_rcp_f32 times the numerator; NOT bit-exact --
- * AO texels may differ from STRICT by one storage step on a small fraction of texels; everything
- * else (fusion, storage conversions) is unchanged.  Applies with RTZ_CLAMP depth storage.
- * FAST is OUTSIDE the project's parity bar ("within 1 ULP fp16 of the reference path"): with F16 AO
- * storage it was measured up to 4 fp16 ulps away from STRICT (a 1-ulp weight difference can flip a
- * CompareDeltas decision downstream; tests/test_gpu_more.py allows 8).  It exists to price the exact
- * division sequences (+6 %), is never what bench.py reports, and is not a route to any parity or
- * roofline claim. */
-typedef enum meao_numerics { MEAO_NUMERICS_STRICT = 0, MEAO_NUMERICS_FAST = 1 } meao_numerics;
-
+/* Numerics (one mode, no switch): bit-exact against the CPU oracle -- correctly rounded '/', explicit mad fusion only
+ * (DESIGN.md section 2).  (ABI <= 5 had a FAST mode with raw 1-ulp reciprocals; it was outside the parity bar and is gone.) */
 typedef enum meao_mem { MEAO_MEM_HOST = 0, MEAO_MEM_DEVICE = 1 } meao_mem;
-
-/* How meao_execute* submits the passes of one call.  DIRECT: one kernel launch per pass.  GRAPH: the
- * launch sequence is captured once per (frame pointers, parameters) into a HIP graph and replayed
- * with a single hipGraphLaunch.  Same kernels, same results.  The context keeps the 8 most recent
- * graphs; meao_set_params / meao_resize drop them.  Falls back to DIRECT while profiling
- * (meao_set_profiling) or when the caller's stream is itself being captured.
- * Measured on MI355X / ROCm 7.2 (profiles/README.md): NOT faster than DIRECT for one frame per call
- * (1080p 49.9 vs 45.8 us back to back) -- the 6-7 dependent kernels are separated by GPU-side
- * barriers, not by host launch cost -- so DIRECT stays the default; the mode is kept for callers
- * that want one submission per frame. */
-typedef enum meao_launch_mode { MEAO_LAUNCH_DIRECT = 0, MEAO_LAUNCH_GRAPH = 1 } meao_launch_mode;
 
 /* Storage of the input depth buffer.  The reference first blits _CameraDepthTexture -- whatever
  * its format -- into an RFloat copy (Blit.shader:48-64 pass 0, AO.cs:608-614) unless D3D's
@@ -109,7 +89,9 @@ typedef enum meao_sample_set { MEAO_SAMPLES_CHECKER = 0, MEAO_SAMPLES_EXHAUSTIVE
 
 /* Kernel launches of one frame/batch, in stream order. */
 typedef enum meao_pass {
-    MEAO_PASS_DOWNSAMPLE = 0,  /* Downsample1.main + Downsample2.main fused  (AO.cs:627-657) */
+    MEAO_PASS_DOWNSAMPLE = 0,  /* Downsample1.main + Downsample2.main fused  (AO.cs:627-657): the four point-sampled levels.
+                                * LinearDepth (Downsample1.compute:46) is not written: its one reader, Upsample.main, evaluates
+                                * Linearize from the raw depth frame itself */
     MEAO_PASS_RENDER = 1,      /* Render.main_interleaved, all levels, one grid (AO.cs:519-522) */
     MEAO_PASS_UPSAMPLE_3 = 2,  /* Upsample.main_blendout L4 -> L3             (AO.cs:528).  With 4 levels and
                                 * hq_levels = 0 it is evaluated inside the L3 -> L2 launch (each tile computes the
@@ -132,7 +114,6 @@ typedef struct meao_config {
     int32_t num_levels;     /* 1..4; the reference always runs 4 (AO.cs:519-531) */
     int32_t ao_format;      /* meao_ao_format */
     int32_t f16_rounding;   /* meao_f16_rounding */
-    int32_t numerics;       /* meao_numerics */
     int32_t max_batch;      /* 1..MEAO_MAX_BATCH frames resident per launch */
     int32_t depth_format;   /* meao_depth_format of the depth pointers given to meao_execute* */
     /* Variants present in the reference's shaders but never dispatched by its host (0 = reference): */
@@ -143,7 +124,6 @@ typedef struct meao_config {
                              * LoResAO1 = min(LoResAO1, that render).  Wiring as in the Microsoft
                              * MiniEngine original (its quality levels = hq_levels 0..4). */
     int32_t sample_set;     /* meao_sample_set */
-    int32_t launch_mode;    /* meao_launch_mode */
     int32_t pipelined;      /* 1: allocate the second set of downsample buffers at meao_create, so that
                              * meao_prefetch_batch never allocates or synchronises (streams of frames);
                              * 0 (default): the first meao_prefetch_batch call does it, once */
@@ -241,12 +221,16 @@ MEAO_API const char *meao_last_error(const meao_ctx *ctx);
  *        (_CameraDepthTexture / ResolvedDepth, AO.cs:608-641).
  * ao_out: width*height AO texels in cfg.ao_format (the "AmbientOcclusion" RT, AO.cs:475).
  * Alignment of DEVICE pointers: none required.  When width % 4 == 0 and every depth pointer is
- *        aligned to 4 texels (16 bytes for F32 / UNORM24, 8 for the 16-bit formats) the downsample
- *        pass uses 4-texel vector loads, and when every ao_out pointer is aligned to 4 texels (4 bytes
- *        R8, 8 bytes F16) the last pass uses 4-texel stores; otherwise the scalar variants run
- *        (same results, slower).  hipMalloc / torch allocations are always aligned.
+ *        aligned to 4 texels (16 bytes for F32 / UNORM24, 8 for the 16-bit formats) the last pass
+ *        reads the depth frame with 4-texel vector loads (the downsample pass: width % 8 == 0), and when
+ *        every ao_out pointer is also aligned to 4 texels (4 bytes R8, 8 bytes F16) it uses 4-texel stores;
+ *        otherwise the scalar variants run (same results, slower).  hipMalloc / torch allocations are
+ *        always aligned.
+ * The depth frames are read by the FIRST and the LAST pass of the call (the downsample pass builds the four
+ *        levels from their even rows; the full-resolution upsample linearizes every texel itself instead of
+ *        reading it back from a LinearDepth buffer): they must stay unchanged until the call has completed.
  * Failure: meao_resize and the first meao_prefetch_batch allocate; when that fails the context is left
- *        exactly as it was (geometry, buffers, captured graphs, a ready prefetch).
+ *        exactly as it was (geometry, buffers, a ready prefetch).
  * Any depth value is accepted: NaN, +-inf, negative, > 1 or denormal raw depths are processed with
  *        IEEE division exactly like the reference's Linearize (Downsample1.compute:37-48) -- a frame
  *        containing such texels takes slower kernel bodies, results stay bit-exact vs the oracle.
@@ -259,8 +243,9 @@ MEAO_API int32_t meao_execute_batch(meao_ctx *ctx, int32_t n, const void *const 
                                     int32_t depth_loc, void *const *ao_out, int32_t out_loc,
                                     meao_stream stream);
 /* Pipelining for streams of frames.  Announces the DEVICE depth frames of the call after next: the
- * following meao_execute* carries their downsample pass inside its last (VALU-bound) upsample
- * kernel, where the pass's HBM traffic hides under arithmetic instead of costing ~20 % of a frame;
+ * following meao_execute* carries their downsample pass inside its last upsample kernel (f32 depth,
+ * width % 8 == 0, aligned frames; otherwise as one more launch behind it), where the pass's HBM traffic
+ * overlaps arithmetic instead of costing a launch between two VALU-bound ones;
  * the meao_execute* after that, if given exactly these n pointers, skips its own downsample pass.
  * Results are identical.  Rules: the announced buffers must hold their final contents before the
  * carrying execute is submitted and stay unchanged until the consuming one has run.  Enforced, not
@@ -279,7 +264,10 @@ MEAO_API int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream);
 /* ---- observability (replaces the _debug 1..17 views, AO.cs:787-820) --------------------- */
 /* Copies debug buffer `debug_id` of batch slot `frame` (as left by the last execute) to dst
  * in the reference's layout (TiledDepth: [16][h][w]).  dst may be NULL to query desc only.
- * Ids 18..21 (OcclusionHQ<k>) exist only for the levels cfg.hq_levels enables. */
+ * Ids 18..21 (OcclusionHQ<k>) exist only for the levels cfg.hq_levels enables.
+ * Ids 1 (LinearDepth) and 6..9 (TiledDepth<k>) are not buffers of the hot path: they are built here, on demand, bit-identical
+ * to what Downsample1 / Downsample2 would have stored -- id 1 from the DEPTH FRAME the last execute was given, which must
+ * therefore still be alive and unchanged (HOST frames are staged by the context and always are). */
 MEAO_API int32_t meao_get_intermediate(meao_ctx *ctx, int32_t frame, int32_t debug_id,
                                        void *dst, uint64_t dst_capacity, int32_t dst_loc,
                                        meao_desc *out_desc);
@@ -334,7 +322,7 @@ MEAO_API int32_t meao_composite_pending(const meao_ctx *ctx, int32_t *out_frames
 
 /* Per-pass device timing: when enabled, meao_execute* brackets every pass with HIP events on
  * the launch stream; meao_get_pass_times averages each pass over the executes that ran it since
- * the last reset (synchronises the stream); *out_samples = executes measured.
+ * the last reset (it waits for the stream of the last execute first); *out_samples = executes measured.
  * ms[MEAO_NUM_PASSES]; passes not run report 0.
  * enable: 0 = off; 1 = every execute; N > 1 = every Nth execute (the first one after the call included), the others run
  * without event records.  An event record is a marker packet between two launches; the events are created with
@@ -410,31 +398,15 @@ MEAO_API int32_t meao_hostile_frames(meao_ctx *ctx, uint64_t *out_mask);
 /* Launch-structure overrides for tests and A/B runs (the library reads no environment variables).  Every
  * structure gives bit-identical results; the defaults are what measured fastest.  FUSE_COARSE_BLEND 0 = three
  * separate blend launches; *_MAX_TILES = tile-count thresholds at or below which a call uses the nested
- * three-level blend launch / 128x8 render tiles / 64x32 final tiles / 128x8 downsample tiles (0 = never).
- * (Key 5 was FAIL_NEXT_ALLOCS, fault injection: no longer part of this ABI -- the `testhooks` variant library built with
- * -DMEAO_TESTING=1 exports meao_test_fail_next_allocs for the resize tests; the product returns INVALID_ARGUMENT for key 5.) */
+ * three-level blend launch / 128x8 render tiles / 64x32 final tiles / one-row-per-lane downsample tiles (0 = never).
+ * (ABI 6 retired the keys of launch structures that lost every A/B: DS_SHARE_IN_BLEND, DS_SIDE_STREAM, RENDER_FROM_DEPTH*;
+ * their patches are kept under profiles/.  Fault injection lives in the `testhooks` variant library only.) */
 typedef enum meao_debug_key {
     MEAO_DEBUG_FUSE_COARSE_BLEND = 0, MEAO_DEBUG_NESTED_MAX_TILES = 1, MEAO_DEBUG_RENDER_SMALL_MAX_TILES = 2,
-    MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4, MEAO_DEBUG_RESERVED_5 = 5,
-    MEAO_DEBUG_DS_SHARE_IN_BLEND = 6,  /* percent (0..100) of the next batch's downsample tiles (meao_prefetch_batch) carried by
-                                        * the L2 -> L1 blend launch instead of the last kernel */
-    MEAO_DEBUG_DS_SIDE_STREAM = 7,     /* 0 = off.  gate + 10 * shape: the announced batch's downsample pass runs as its own kernel on a
-                                        * second, low-priority stream of the context, released when the call's stream reaches `gate`
-                                        * (1 = the full-resolution upsample launch, 2 = L2 -> L1, 3 = the coarse blend launch, 4 = render);
-                                        * shape 0..4 = loads in flight per lane {16 + 120 VGPRs declared, 16, 8, 4, 8 + 120 VGPRs declared};
-                                        * + 100 * p: stream priority p = 0 lowest, 1 default, 2 highest; + 1000 * s + 10000 * b: only the
-                                        * first s tenths of the frames at `gate`, the rest at gate b (default 1).  Results identical. */
-    MEAO_DEBUG_RENDER_FROM_DEPTH = 8,  /* calls that run their own downsample pass (no meao_prefetch_batch), f32 depth, 36 samples: the render
-                                        * launch fills its windows from the RAW depth frame and does not wait for the downsample pass.
-                                        * 0 (default) = never; 1 = always, both in ONE launch (the pass as extra workgroups behind the
-                                        * render ones); 2 = always, as two launches on two streams of the context joined in front of the
-                                        * blend launch; 3 = form 1 for calls of at most RENDER_FROM_DEPTH_MAX_TILES render tiles.
-                                        * Measured slower than the stored-mip sequence at every call size (the gathered windows touch
-                                        * 2^level times the cache lines): an option, not the default. */
-    MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES = 9,  /* frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190); default 1024 */
-    MEAO_DEBUG_BLEND_TALL_MIN_TILES = 10, /* L2 -> L1 blend launches of at least this many 64x32 tiles (frames x tiles) use 64x64 tiles, either AO
+    MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4,
+    MEAO_DEBUG_BLEND_TALL_MIN_TILES = 5, /* L2 -> L1 blend launches of at least this many 64x32 tiles (frames x tiles) use 64x64 tiles, either AO
                                           * storage format; 0 = never.  Default: 4096, R8 storage only */
-    MEAO_DEBUG_PROFILE_PASS_MASK = 11    /* meao_set_profiling: bit k set = launch slot k (meao_pass) is bracketed with events; 0 = all (default).
+    MEAO_DEBUG_PROFILE_PASS_MASK = 6     /* meao_set_profiling: bit k set = launch slot k (meao_pass) is bracketed with events; 0 = all (default).
                                           * Each event record is a marker packet between two launches (1 - 4 % of a batched step for all
                                           * eight): a host that wants one kernel's duration in a throughput run asks for that slot only */
 } meao_debug_key;

@@ -48,8 +48,7 @@ public:
                      meao_ao_format aoFormat = MEAO_AO_R8, int32_t maxBatch = 1, int32_t numLevels = 4,
                      meao_f16_rounding f16Rounding = MEAO_F16_RTZ_CLAMP,
                      meao_depth_format depthFormat = MEAO_DEPTH_F32, int32_t hqLevels = 0,
-                     meao_sample_set sampleSet = MEAO_SAMPLES_CHECKER,
-                     meao_launch_mode launchMode = MEAO_LAUNCH_DIRECT)
+                     meao_sample_set sampleSet = MEAO_SAMPLES_CHECKER)
     {
         meao_default_config(&cfg_);
         cfg_.device = device;
@@ -62,7 +61,6 @@ public:
         cfg_.depth_format = depthFormat;
         cfg_.hq_levels = hqLevels;
         cfg_.sample_set = sampleSet;
-        cfg_.launch_mode = launchMode;
         const int32_t rc = meao_create(&cfg_, &ctx_);
         if (rc != MEAO_OK) throw Error(rc, meao_last_error(nullptr));
     }

@@ -22,7 +22,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # MEAO_LIB_PATH: an alternative build of the same library (A/B of kernel variants, tools/run_gpu_variants_ab.sh)
 LIB_PATH = os.environ.get("MEAO_LIB_PATH") or os.path.join(_PKG, "lib", "libmeao_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_BATCH = 64
 NUM_PASSES = 7
 PASS_NAMES = ("downsample", "render", "upsample_L4_to_L3", "upsample_L3_to_L2",
@@ -34,20 +34,16 @@ ERR_INVALID_ARGUMENT, ERR_HIP, ERR_OUT_OF_MEMORY = -1, -2, -3
 ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL = -4, -5, -6
 AO_R8, AO_F16 = 0, 1
 F16_RTZ_CLAMP, F16_RTNE = 0, 1
-NUMERICS_STRICT, NUMERICS_FAST = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 DEPTH_F32, DEPTH_UNORM16, DEPTH_UNORM24, DEPTH_F16 = 0, 1, 2, 3
 COMPOSITE_MULTIPLY, COMPOSITE_AMBIENT_ONLY, COMPOSITE_DEBUG = 0, 1, 2
 FMT_F32, FMT_F16, FMT_UNORM8 = 0, 1, 2
 SAMPLES_CHECKER, SAMPLES_EXHAUSTIVE = 0, 1
-LAUNCH_DIRECT, LAUNCH_GRAPH = 0, 1
 DEBUG_OCCLUSION_HQ1 = 18
-# meao_debug_key
-# (5 was FAIL_NEXT_ALLOCS until round 5: fault injection is no longer part of the production ABI -- meao_test_fail_next_allocs
+# meao_debug_key (ABI 6: the keys of the launch structures that lost every A/B are gone; fault injection -- meao_test_fail_next_allocs --
 # exists only in the `testhooks` variant library, built with -DMEAO_TESTING=1)
 (DEBUG_FUSE_COARSE_BLEND, DEBUG_NESTED_MAX_TILES, DEBUG_RENDER_SMALL_MAX_TILES, DEBUG_FINAL_SMALL_MAX_TILES,
- DEBUG_DS_SMALL_MAX_TILES, _DEBUG_RESERVED_5, DEBUG_DS_SHARE_IN_BLEND, DEBUG_DS_SIDE_STREAM, DEBUG_RENDER_FROM_DEPTH,
- DEBUG_RENDER_FROM_DEPTH_MAX_TILES, DEBUG_BLEND_TALL_MIN_TILES, DEBUG_PROFILE_PASS_MASK) = range(12)
+ DEBUG_DS_SMALL_MAX_TILES, DEBUG_BLEND_TALL_MIN_TILES, DEBUG_PROFILE_PASS_MASK) = range(7)
 POOL_PATH_SAME_DEVICE, POOL_PATH_PEER_DIRECT, POOL_PATH_STAGED = 0, 1, 2
 NUM_BUFFERS = 21
 
@@ -55,9 +51,9 @@ NUM_BUFFERS = 21
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("width", C.c_int32),
                 ("height", C.c_int32), ("num_levels", C.c_int32), ("ao_format", C.c_int32),
-                ("f16_rounding", C.c_int32), ("numerics", C.c_int32), ("max_batch", C.c_int32),
+                ("f16_rounding", C.c_int32), ("max_batch", C.c_int32),
                 ("depth_format", C.c_int32), ("hq_levels", C.c_int32), ("sample_set", C.c_int32),
-                ("launch_mode", C.c_int32), ("pipelined", C.c_int32)]
+                ("pipelined", C.c_int32)]
 
 
 class Params(C.Structure):

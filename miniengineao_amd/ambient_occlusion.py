@@ -34,11 +34,11 @@ class AmbientOcclusion:
 
     def __init__(self, width: int, height: int, *, device: int = 0, num_levels: int = 4,
                  ao_format: int = L.AO_R8, f16_rounding: int = L.F16_RTZ_CLAMP,
-                 max_batch: int = 1, depth_format: int = L.DEPTH_F32, numerics: int = L.NUMERICS_STRICT,
+                 max_batch: int = 1, depth_format: int = L.DEPTH_F32,
                  near_clip: float = 0.3, far_clip: float = 1000.0,
                  projection00: Optional[float] = None, reversed_z: bool = True,
                  hq_levels: int = 0, sample_set: int = L.SAMPLES_CHECKER, single_pass_stereo: bool = False,
-                 launch_mode: int = L.LAUNCH_DIRECT, pipelined: bool = False):
+                 pipelined: bool = False):
         """hq_levels / sample_set / single_pass_stereo: variants the reference's shaders and host carry
         but its command buffer never (or only in VR) uses; see include/meao.h.  ``width`` is the
         double-wide eye pair when single_pass_stereo is set (AO.cs:339)."""
@@ -49,9 +49,7 @@ class AmbientOcclusion:
         cfg.num_levels, cfg.ao_format, cfg.f16_rounding = num_levels, ao_format, f16_rounding
         cfg.max_batch = max_batch
         cfg.depth_format = depth_format
-        cfg.numerics = numerics
         cfg.hq_levels, cfg.sample_set = hq_levels, sample_set
-        cfg.launch_mode = launch_mode      # LAUNCH_GRAPH: one hipGraphLaunch per call (real-time single frames)
         cfg.pipelined = 1 if pipelined else 0   # second downsample set from the start (prefetch_device never allocates)
         self._cfg = cfg
         prm = L.Params()
@@ -233,7 +231,7 @@ class AmbientOcclusion:
         return m.value
 
     def debug_set(self, key: int, value: int) -> None:
-        """meao_debug_set: launch-structure overrides (identical results) and allocation fault injection."""
+        """meao_debug_set: launch-structure overrides (identical results)."""
         L.check(self._lib.meao_debug_set(self._ctx, key, value), self._ctx)
 
     def set_tracing(self, enable: bool) -> None:
@@ -292,13 +290,12 @@ class AmbientOcclusionPool:
     def __init__(self, width: int, height: int, devices: Sequence[int], *, max_batch: int = 1,
                  ao_format: int = L.AO_R8, near_clip: float = 0.3, far_clip: float = 1000.0,
                  projection00: Optional[float] = None, reversed_z: bool = True, intensity: float = 1.0,
-                 pipelined: bool = False, launch_mode: int = L.LAUNCH_DIRECT):
+                 pipelined: bool = False):
         self._lib = L.load()
         cfg = L.Config()
         self._lib.meao_default_config(C.byref(cfg))
         cfg.width, cfg.height, cfg.max_batch, cfg.ao_format = width, height, max_batch, ao_format
         cfg.pipelined = 1 if pipelined else 0
-        cfg.launch_mode = launch_mode
         self._cfg = cfg
         self.devices = list(devices)
         self._pool = C.c_void_p()

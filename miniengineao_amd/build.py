@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libmeao_hip.so")
 # The kernels are six translation units over shared device headers (meao_dev*.hpp): they compile in parallel and a
 # change to one family rebuilds one unit.  csrc/meao_kernels.hip is the same code as ONE unit (it includes the six):
 # variants that need device globals (`clocks`) and the ISA tools build that.
-KERNEL_UNITS = ["meao_k_downsample.hip", "meao_k_render.hip", "meao_k_render_depth.hip", "meao_k_upsample.hip",
+KERNEL_UNITS = ["meao_k_downsample.hip", "meao_k_render.hip", "meao_k_upsample.hip",
                 "meao_k_upsample_nested.hip", "meao_k_upsample_fused.hip", "meao_k_misc.hip"]
 HOST_UNITS = ["meao_plan.cpp", "meao_api.cpp", "meao_pool.cpp"]
 SOURCES = HOST_UNITS + KERNEL_UNITS

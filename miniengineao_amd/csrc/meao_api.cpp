@@ -42,70 +42,47 @@ struct meao_ctx {
     char *arena = nullptr;
     uint64_t slot_bytes = 0;
     uint64_t off_occ[4] = {}, off_comb[3] = {};
-    // Downsample outputs (LinearDepth, LowDepth1..4).  With meao_prefetch_batch in use the slot holds
-    // two such sets: the passes of a call read set `ds_cur` while its last kernel fills the other one
-    // with the next batch's downsample.
-    uint64_t off_ds_linear = 0, off_ds_low[4] = {}, ds_set_bytes = 0;
+    // Downsample outputs (LowDepth1..4; LinearDepth is never materialised on the hot path).  With meao_prefetch_batch in use the
+    // slot holds two such sets: the passes of a call read set `ds_cur` while its last kernel fills the other one with the next
+    // batch's downsample.
+    uint64_t off_ds_low[4] = {}, ds_set_bytes = 0;
     bool two_ds_sets = false;
     int ds_cur = 0;
-    uint64_t off_linear_of(int set) const { return off_ds_linear + ds_set_bytes * set; }
     uint64_t off_low_of(int set, int k) const { return off_ds_low[k] + ds_set_bytes * set; }
     int next_n = 0;                               // announced by meao_prefetch_batch, consumed by the next execute
     const void *next_depth[MEAO_MAX_BATCH] = {};
     int ready_n = 0, ready_set = 0;               // a set already downsampled from exactly these frames
     const void *ready_depth[MEAO_MAX_BATCH] = {};
     hipStream_t ready_stream = nullptr;           // the stream the carrying execute ran on
-    // Hostile-depth flags (meao_kernels.hip nice_denominator): [set][frame] words the downsample pass
-    // stamps with its generation when a frame holds texels outside the exact-division range.
+    // Hostile-depth flags (meao_dev_downsample.hpp nice_denominator): [set][frame] words the downsample pass
+    // stamps with its generation when a frame's levels hold texels outside the exact-division range.
     uint32_t *hostile = nullptr;
     uint32_t gen_counter = 0, set_gen[2] = {0, 0};
     uint32_t *hostile_of(int set) const { return hostile + set * MEAO_MAX_BATCH; }
     uint64_t off_hq[4] = {};                  // OcclusionHQ<k>: only the levels cfg.hq_levels enables
 
-    // lazily allocated: staging for HOST in/out, atlas scratch, selftest counter
+    // lazily allocated: staging for HOST in/out, scratch for the buffers built on demand (LinearDepth, TiledDepth<k>), selftest counter
     char *stage_depth = nullptr, *stage_out = nullptr, *stage_view = nullptr, *atlas_scratch = nullptr;
     uint64_t stage_depth_frame = 0, stage_out_frame = 0, atlas_scratch_bytes = 0;
     unsigned long long *counter = nullptr;
 
     // operands of every divide provably inside the exact range of the v_rcp_f32 sequences
-    // (meao_kernels.hip "Exact division"); recomputed by update_plan()
+    // (meao_dev.hpp "Exact division"); recomputed by update_plan()
     int exact_rcp_div = 0;
 
-    // Upsample L4->L3 evaluated inside the L3->L2 launch (upsample_two_level_kernel).  This and the four
-    // thresholds below choose between launch structures with identical results; meao_debug_set overrides
-    // them (tests, A/B runs) -- the library reads no environment variables.
-    bool fuse_coarse_blend = true;
-    int ds_small_max_tiles = 1024;     // stand-alone downsample pass: calls with at most this many 128x32 tiles use 128x8 tiles
+    // Launch structures with identical results, chosen by call size; meao_debug_set overrides the thresholds (tests, A/B runs) --
+    // the library reads no environment variables.
+    bool fuse_coarse_blend = true;     // Upsample L4->L3 evaluated inside the L3->L2 launch (upsample_two_level_kernel)
+    int ds_small_max_tiles = 640;      // stand-alone downsample pass: calls with at most this many 128x16 (LowDepth1 texels) tiles use 128x8 tiles
     int final_small_max_tiles = 2048;  // plain final pass: calls with at most this many 64x64 tiles (one 4K frame: 2040) use 64x32 tiles (r04 sweep: 60.3 vs 60.8 us)
     int render_small_max_tiles = 256;  // calls with at most this many 128x32 render tiles (frames x tiles) use 128x8 tiles
     int nested_max_tiles = 1024;       // calls with at most this many L2->L1 tiles (frames x tiles; one 4K frame: 1020) run the three blend passes as one launch
                                        // (with the round-4 blend_window_into_lds: 55.9 vs 56.6 us per pipelined 4K frame, a tie unpipelined; 512 before)
-    // Render with its windows filled from the RAW depth frame (meao_k_render_depth.hip): render no longer depends on the
-    // downsample pass.  0 = never (default); 1 = one launch for both (the pass as extra workgroups of the render launch);
-    // 2 = two launches on two streams, joined in front of the first blend launch; 3 = form 1 for calls of at most
-    // render_from_depth_max_tiles render tiles.  f32 depth, 36-sample set.  Built for one frame per call
-    // (AmbientOcclusion.cs:329-347) and measured there: NOT faster -- a window of LowDepth<k> gathered from the raw frame touches
-    // 2^k times the cache lines (4K frame: 61.0 us against 60.4; render + pass in one launch 33.0 us against 15.4 + 18.6;
-    // two streams 86 us: two event hand-overs) -- profiles/r05_from_depth_sweep.jsonl, LABNOTES round 5.  Bit-exact and tested.
-    int render_from_depth = 0;
-    int render_from_depth_max_tiles = 1024;      // frames x 128x32 render tiles (one 4K frame: 692, one 1080p frame: 190)
-    hipStream_t rfd_stream = nullptr;            // form 2
-    hipEvent_t rfd_fork = nullptr, rfd_join = nullptr;
     // L2 -> L1 launches of at least this many 64x32 tiles (frames x tiles; 4K: 1020 per frame) use 64x64 tiles with R8 AO storage
     // (upsample_blend_tall_kernel): 53.9 -> 52.5 us per 16 frames at 4K, 57.7 -> 56.3 at 1080p x 64, fp16 storage +-0
     // (profiles/r05_ab_blend_tall.jsonl).  MEAO_DEBUG_BLEND_TALL_MIN_TILES overrides it for both storage formats.
     int blend_tall_min_tiles = 4096;
     bool blend_tall_forced = false;
-    int ds_share_in_blend = 0;         // percent of the carried (next batch's) downsample tiles that ride in the L2->L1 blend launch instead of the last kernel
-    // MEAO_DEBUG_DS_SIDE_STREAM (0 = off): the announced next batch's downsample pass as its OWN kernel on a second,
-    // low-priority stream of the context, gated behind a point of this call's launch sequence, instead of riding inside
-    // the last upsample kernel.  value = gate + 10 * shape: gate 1 = in front of the full-resolution launch (co-runs with
-    // it), 2 = in front of L2->L1, 3 = in front of the coarse blend launch, 4 = in front of render; shape 0 = 16 loads
-    // per lane in flight, 120 VGPRs declared, 1 = 16 loads, 2 = 8 loads, 3 = 4 loads (the stand-alone pass's tile).
-    int ds_side_stream = 0;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t side_gate = nullptr, side_done = nullptr;
-    bool side_pending = false;         // a side-stream downsample was issued and no later execute has ordered itself behind it yet
 
     // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue),
     // and the stream its AO frames were produced on (where a flush that is not given a stream runs it)
@@ -117,23 +94,14 @@ struct meao_ctx {
 #endif
 
     const void *last_out[MEAO_MAX_BATCH] = {};   // device address of the last results (debug id 17)
+    const void *last_depth[MEAO_MAX_BATCH] = {}; // device address of the last call's raw depth frames (debug id 1 is built from them)
     int last_frames = 0;
-
-    // MEAO_LAUNCH_GRAPH: captured launch sequences, most recently used last
-    struct CapturedBatch {
-        int n = 0;
-        const void *depth[MEAO_MAX_BATCH] = {};
-        void *out[MEAO_MAX_BATCH] = {};
-        hipGraphExec_t exec = nullptr;
-        uint32_t generation = 0;
-    };
-    std::vector<CapturedBatch> graphs;
 
     // profiling: a ring of per-execute event sets (one start/end pair per launch slot); each entry
     // remembers which slots it used
     bool profiling = false;
     uint32_t profile_mask = ~0u;                 // MEAO_DEBUG_PROFILE_PASS_MASK: bit k = launch slot k is bracketed with events
-    int profile_period = 1, profile_phase = 0;   // meao_set_profiling(N > 1): every Nth execute is bracketed with events, the others run bare
+    uint32_t profile_period = 1, profile_phase = 0;   // meao_set_profiling(N > 1): every Nth execute is bracketed with events, the others run bare
     std::vector<hipEvent_t> events;              // kProfileRing * kProfSlots * 2
     int ring_fill = 0;
     uint32_t ran_mask[kProfileRing] = {};        // bit k: launch slot k ran in that execute
@@ -183,7 +151,6 @@ bool config_valid(const meao_config &c, std::string *why)
     if (c.depth_format < MEAO_DEPTH_F32 || c.depth_format > MEAO_DEPTH_F16) { *why = "unknown depth_format"; return false; }
     if (c.hq_levels < 0 || c.hq_levels > c.num_levels) { *why = "hq_levels must be 0..num_levels"; return false; }
     if (c.sample_set != MEAO_SAMPLES_CHECKER && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE) { *why = "unknown sample_set"; return false; }
-    if (c.launch_mode != MEAO_LAUNCH_DIRECT && c.launch_mode != MEAO_LAUNCH_GRAPH) { *why = "unknown launch_mode"; return false; }
     if (c.pipelined != 0 && c.pipelined != 1) { *why = "pipelined must be 0 or 1"; return false; }
     return true;
 }
@@ -192,7 +159,7 @@ uint64_t ao_elem(const meao_config &c) { return c.ao_format == MEAO_AO_R8 ? 1 : 
 
 // Where the intermediates of one frame live inside its slot; a pure function of (plan, cfg, two_ds_sets).
 struct SlotLayout {
-    uint64_t off_ds_linear = 0, off_ds_low[4] = {}, ds_set_bytes = 0, off_occ[4] = {}, off_comb[3] = {}, off_hq[4] = {}, slot_bytes = 0;
+    uint64_t off_ds_low[4] = {}, ds_set_bytes = 0, off_occ[4] = {}, off_comb[3] = {}, off_hq[4] = {}, slot_bytes = 0;
 };
 
 SlotLayout layout_slot(const Plan &p, const meao_config &cfg, bool two_ds_sets)
@@ -201,7 +168,6 @@ SlotLayout layout_slot(const Plan &p, const meao_config &cfg, bool two_ds_sets)
     uint64_t off = 0;
     auto take = [&](uint64_t bytes) { const uint64_t o = off; off = align_up(off + bytes); return o; };
     auto px = [&](int k) { return static_cast<uint64_t>(p.mip[k].w) * p.mip[k].h; };
-    l.off_ds_linear = take(px(0) * 2);
     for (int k = 1; k <= 4; ++k) l.off_ds_low[k - 1] = take(px(k) * 4);
     l.ds_set_bytes = off;
     if (two_ds_sets) off = 2 * off;          // second set: same layout, ds_set_bytes further
@@ -214,7 +180,6 @@ SlotLayout layout_slot(const Plan &p, const meao_config &cfg, bool two_ds_sets)
 
 void apply_layout(meao_ctx *ctx, const SlotLayout &l)
 {
-    ctx->off_ds_linear = l.off_ds_linear;
     ctx->ds_set_bytes = l.ds_set_bytes;
     ctx->slot_bytes = l.slot_bytes;
     std::memcpy(ctx->off_ds_low, l.off_ds_low, sizeof l.off_ds_low);
@@ -225,8 +190,9 @@ void apply_layout(meao_ctx *ctx, const SlotLayout &l)
 
 // Divides on the path: 1/LoResDB, 1/centre depth, {9,3,1,3}/(|dHi-dLo| + tol), (HiAO*sum)/total.
 // The exact v_rcp_f32 sequences need their operands inside verified ranges.  The DATA side of that
-// (every linear depth in [2^-24, 2^20] or the sky value, finite, not NaN) is checked per frame on the
-// device by the downsample pass (nice_denominator; hostile frames take the IEEE bodies).  The
+// (every linear depth in [2^-24, 2^20] or the sky value, finite, not NaN) is checked on the device: per frame
+// by the downsample pass for the texels the levels are made of (nice_denominator; hostile frames take the IEEE
+// bodies), per lane by the full-resolution upsample for the texels it linearizes itself.  The
 // PARAMETER side is checked here: weights are <= 9/tol, total and sum are >= noise strength.
 bool exact_rcp_div_applicable(const meao_config &c, const meao_params &p, const Plan &plan)
 {
@@ -240,26 +206,13 @@ bool exact_rcp_div_applicable(const meao_config &c, const meao_params &p, const 
     return true;
 }
 
-constexpr size_t kMaxCapturedBatches = 8;
-
 void drop_prefetch(meao_ctx *ctx) { ctx->next_n = 0; ctx->ready_n = 0; ctx->ready_stream = nullptr; }
-
-void drop_graphs(meao_ctx *ctx)
-{
-    if (!ctx->graphs.empty()) (void)hipStreamSynchronize(ctx->last_stream);   // a replay may be in flight
-    for (auto &g : ctx->graphs)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    ctx->graphs.clear();
-}
 
 void update_plan(meao_ctx *ctx)
 {
-    drop_graphs(ctx);   // captured kernel arguments embed the plan's constants and the arena addresses
     drop_prefetch(ctx); // a prefetched downsample was computed with the old Z-buffer parameters
     build_plan(ctx->cfg.width, ctx->cfg.height, ctx->cfg.num_levels, ctx->cfg.sample_set, ctx->prm, &ctx->plan);
     ctx->exact_rcp_div = exact_rcp_div_applicable(ctx->cfg, ctx->prm, ctx->plan) ? 1 : 0;
-    // MEAO_NUMERICS_FAST: raw v_rcp_f32 (2 = DIV_FAST in the kernels); RTZ storage only, like the exact mode
-    if (ctx->cfg.numerics == MEAO_NUMERICS_FAST && ctx->cfg.f16_rounding == MEAO_F16_RTZ_CLAMP) ctx->exact_rcp_div = 2;
 }
 
 void release_staging(meao_ctx *ctx)
@@ -282,7 +235,7 @@ void release_buffers(meao_ctx *ctx)
 
 // (Re)plans for cfg/two_ds_sets and replaces the arena.  The new geometry is planned on the side and its
 // arena allocated BEFORE anything of the context changes: on failure the context is untouched -- geometry,
-// buffers, captured graphs and a ready prefetch all stay as they were.
+// buffers and a ready prefetch all stay as they were.
 int reallocate(meao_ctx *ctx, const meao_config &cfg, bool two_ds_sets)
 {
     Plan plan{};
@@ -302,7 +255,7 @@ int reallocate(meao_ctx *ctx, const meao_config &cfg, bool two_ds_sets)
     if (e != hipSuccess) return fail_hip(ctx, e, "hipMalloc (intermediates)");
     ctx->cfg = cfg;
     ctx->two_ds_sets = two_ds_sets;
-    update_plan(ctx);           // drops captured graphs and a ready prefetch: they refer to the old arena
+    update_plan(ctx);           // drops a ready prefetch: it refers to the old arena
     apply_layout(ctx, lay);
     release_buffers(ctx);
     ctx->arena = fresh;
@@ -359,145 +312,154 @@ struct TraceRange {   // roctx range around one pass (no-op unless meao_set_trac
 
 bool aligned_to(const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// The launch sequence of one batch: what RebuildCommandBuffers records (AO.cs:511-531).
-int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream, bool capturing = false)
+// ------------------------------------------------------------------------------------------
+// One call = plan -> launch list -> submit.  The launch structure of a batch is DATA (a LaunchList); choosing it
+// (plan_launches), building the kernel arguments of a launch (ArgBuilder) and issuing it (submit_launches) are separate steps.
+
+// What RebuildCommandBuffers records (AO.cs:511-531), in the shapes this implementation launches it in.
+enum class Step {
+    Downsample,               // Downsample1 + Downsample2 (AO.cs:604-658): the four levels of THIS call's frames
+    Render,                   // Render.main_interleaved x levels, one grid (AO.cs:519-522)
+    RenderWithComposite,      // ... carrying the composite of an earlier call's frames (meao_composite_enqueue)
+    RenderHq,                 // Render.main (wide) for the levels cfg.hq_levels enables
+    Blend,                    // Upsample.main_blendout writing level `hi` (AO.cs:528-530)
+    BlendTwoLevel,            // L4 -> L3 evaluated inside the L3 -> L2 launch
+    BlendThreeLevel,          // L4 -> L3 and L3 -> L2 evaluated inside the L2 -> L1 launch (small calls)
+    Final,                    // Upsample.main: the result (AO.cs:531)
+    FinalWithNextDownsample,  // ... carrying the downsample pass of the announced next batch (meao_prefetch_batch)
+    DownsampleNext            // the announced batch's pass as a launch of its own behind the final one (where the fused form does not apply)
+};
+
+struct Launch {
+    Step step;
+    int slot;                 // meao_pass the launch is timed under; -1 = not timed
+    int hi;                   // Blend*: the level written
+    const char *range;        // roctx range name
+};
+
+struct LaunchList {
+    Launch v[12];
+    int n = 0;
+    void add(Step step, int slot, int hi, const char *range) { v[n++] = Launch{step, slot, hi, range}; }
+};
+
+struct BatchShape {           // what the structure of a call depends on
+    int frames;
+    bool prefetched;          // an earlier call carried this batch's downsample pass
+    bool carry_composite;     // a composite batch waits for a render launch to ride in
+    int next;                 // 0 = nothing announced; 1 = the announced pass rides in the final kernel; 2 = it runs as its own launch
+};
+
+LaunchList plan_launches(const meao_ctx *ctx, const BatchShape &b)
 {
-    const Plan &p = ctx->plan;
     const meao_config &c = ctx->cfg;
-    const int rtne = c.f16_rounding == MEAO_F16_RTNE;
-    hipEvent_t *ev = nullptr;
-    uint32_t ran = 0;
-    if (ctx->profiling && ctx->profile_phase++ % ctx->profile_period == 0) {
-        if (ctx->ring_fill == kProfileRing) fold_profile(ctx);
-        ev = &ctx->events[ctx->ring_fill * kProfSlots * 2];
+    const Plan &p = ctx->plan;
+    static const char *const kBlendRange[4] = {nullptr, "meao:upsample_L2_to_L1", "meao:upsample_L3_to_L2", "meao:upsample_L4_to_L3"};
+    LaunchList l;
+    if (!b.prefetched) l.add(Step::Downsample, MEAO_PASS_DOWNSAMPLE, 0, "meao:downsample");
+    if (b.carry_composite) l.add(Step::RenderWithComposite, MEAO_PASS_RENDER, 0, "meao:render+composite_of_previous_call");
+    else l.add(Step::Render, MEAO_PASS_RENDER, 0, "meao:render");
+    if (c.hq_levels > 0) l.add(Step::RenderHq, MEAO_PASS_RENDER_HQ, 0, "meao:render_hq");
+    const bool nestable = ctx->fuse_coarse_blend && c.num_levels == 4 && c.hq_levels == 0;
+    const int l1_tiles = ((p.mip[1].w + kUpsTileW - 1) / kUpsTileW) * ((p.mip[1].h + ups_tile_h(false) - 1) / ups_tile_h(false));
+    if (nestable && b.frames * l1_tiles <= ctx->nested_max_tiles) {
+        // a small frame or two per call (at most two workgroups per CU): all three blend passes in one launch -- their latency
+        // chains, not their arithmetic, are what such a call waits for (1080p: 39.2 -> 36.9 us per frame; at 4K, 1020 tiles, it
+        // is a wash).  Combined3 and Combined2 are still written
+        l.add(Step::BlendThreeLevel, MEAO_PASS_UPSAMPLE_1, 1, "meao:upsample_L4_to_L3+L3_to_L2+L2_to_L1");
+    } else {
+        // L4 -> L3 inside the L3 -> L2 launch: one launch, one latency-bound pass less (Combined3 is still written)
+        if (nestable) l.add(Step::BlendTwoLevel, MEAO_PASS_UPSAMPLE_2, 2, "meao:upsample_L4_to_L3+L3_to_L2");
+        else for (int hi = c.num_levels - 1; hi >= 2; --hi) l.add(Step::Blend, MEAO_PASS_UPSAMPLE_0 - hi, hi, kBlendRange[hi]);
+        if (c.num_levels >= 2) l.add(Step::Blend, MEAO_PASS_UPSAMPLE_1, 1, kBlendRange[1]);
     }
-    // one launch = one profiling slot: events right before and after it on ITS stream
-    const uint32_t profile_mask = ctx->profile_mask;
-    auto begin = [&](int slot, hipStream_t s) -> hipError_t {
-        return ev && (profile_mask >> slot & 1u) ? hipEventRecord(ev[slot * 2], s) : hipSuccess;
-    };
-    auto end = [&](int slot, hipStream_t s) -> hipError_t {
-        if (!(profile_mask >> slot & 1u)) return hipSuccess;
-        ran |= 1u << slot;
-        return ev ? hipEventRecord(ev[slot * 2 + 1], s) : hipSuccess;
-    };
+    if (b.next == 1) l.add(Step::FinalWithNextDownsample, MEAO_PASS_UPSAMPLE_0, 0, "meao:upsample_L1_to_L0+downsample_next");
+    else l.add(Step::Final, MEAO_PASS_UPSAMPLE_0, 0, "meao:upsample_L1_to_L0");
+    // (timed in the DOWNSAMPLE slot only in calls that did not run a pass of their own there)
+    if (b.next == 2) l.add(Step::DownsampleNext, b.prefetched ? MEAO_PASS_DOWNSAMPLE : -1, 0, "meao:downsample_next");
+    return l;
+}
 
-    // 4-texel vector loads / stores need 16-byte (f32, UNORM24), 8-byte (16-bit) aligned depth rows and
-    // 4- (R8) / 8-byte (F16) aligned AO rows: width % 4 == 0 and aligned base pointers (include/meao.h);
-    // anything else takes the scalar variants.
-    const uintptr_t depth_align = 4 * depth_elem(c.depth_format), out_align = 4 * ao_elem(c);
+// Kernel arguments of the launches of one call.
+struct ArgBuilder {
+    meao_ctx *ctx;
+    int n;
+    const void *const *depth_dev;
+    void *const *out_dev;
+    const uint32_t *hostile;      // flags and generation of the downsample set this call reads
+    uint32_t generation;
 
-    // ---- PushDownsampleCommands (AO.cs:604-658)
-    auto downsample_args = [&](int frames, const void *const *depth, int set, uint32_t generation, bool small_ok = false) {
+    const Plan &p() const { return ctx->plan; }
+    const meao_config &c() const { return ctx->cfg; }
+    int rtne() const { return ctx->cfg.f16_rounding == MEAO_F16_RTNE; }
+    // 4-texel vector loads / stores need 16-byte (f32, UNORM24), 8-byte (16-bit) aligned depth rows and 4- (R8) / 8-byte (F16)
+    // aligned AO rows: width % 4 == 0 (% 8 for the downsample pass, whose lanes take 8 raw texels) and aligned base pointers
+    // (include/meao.h); anything else takes the scalar variants.
+    uintptr_t depth_align() const { return 4 * depth_elem(ctx->cfg.depth_format); }
+    uintptr_t out_align() const { return 4 * ao_elem(ctx->cfg); }
+
+    // ---- PushDownsampleCommands (AO.cs:604-658).  lean: tiled for the tile the final kernel carries (kLeanMipW x kLeanMipRows),
+    // else for the stand-alone pass (small_ok: calls with few tiles use the one-row-per-lane tile)
+    DownsampleArgs downsample(int frames, const void *const *depth, int set, uint32_t gen, bool lean, bool small_ok) const
+    {
         DownsampleArgs ds{};
-        bool aligned = (p.mip[0].w & 3) == 0;
+        bool aligned = (p().mip[0].w & 7) == 0;
         for (int f = 0; f < frames; ++f) {
             ds.depth[f] = depth[f];
-            aligned = aligned && aligned_to(depth[f], depth_align);
+            aligned = aligned && aligned_to(depth[f], depth_align());
         }
         ds.vec_ok = aligned;
         ds.frames = frames;
-        ds.depth_format = c.depth_format;
-        ds.linear = slot_ptr<uint16_t>(ctx, ctx->off_linear_of(set));
+        ds.depth_format = c().depth_format;
         for (int k = 0; k < 4; ++k) ds.low[k] = slot_ptr<float>(ctx, ctx->off_low_of(set, k));
         ds.frame_stride = ctx->slot_bytes;
-        for (int k = 0; k < 5; ++k) { ds.w[k] = p.mip[k].w; ds.h[k] = p.mip[k].h; }
-        ds.zp0 = p.zbuffer_params[0];
-        ds.zp1 = p.zbuffer_params[1];
+        for (int k = 0; k < 5; ++k) { ds.w[k] = p().mip[k].w; ds.h[k] = p().mip[k].h; }
+        ds.zp0 = p().zbuffer_params[0];
+        ds.zp1 = p().zbuffer_params[1];
         ds.reversed_z = ctx->prm.reversed_z != 0;
-        ds.f16_rtne = rtne;
+        ds.f16_rtne = rtne();
         ds.exact_rcp_div = ctx->exact_rcp_div;
-        ds.tiles_x = (p.mip[0].w + kDsTileW - 1) / kDsTileW;
-        ds.tiles_y = (p.mip[0].h + kDsTileH - 1) / kDsTileH;
-        ds.row_passes = kDsTileH / kDsRowsPerPass;
-        if (small_ok && frames * ds.tiles_x * ds.tiles_y <= ctx->ds_small_max_tiles) {      // stand-alone pass of a small call
-            ds.row_passes = 1;
-            ds.tiles_y = (p.mip[0].h + kDsRowsPerPass - 1) / kDsRowsPerPass;
+        if (lean) {
+            ds.rows_per_lane = 1;
+            ds.tiles_x = (ds.w[1] + kLeanMipW - 1) / kLeanMipW;
+            ds.tiles_y = (ds.h[1] + kLeanMipRows - 1) / kLeanMipRows;
+        } else {
+            ds.rows_per_lane = kMipRowsPerLane;
+            ds.tiles_x = (ds.w[1] + kMipTileW - 1) / kMipTileW;
+            ds.tiles_y = (ds.h[1] + kMipRowsPerPass * kMipRowsPerLane - 1) / (kMipRowsPerPass * kMipRowsPerLane);
+            if (small_ok && frames * ds.tiles_x * ds.tiles_y <= ctx->ds_small_max_tiles) {
+                ds.rows_per_lane = 1;
+                ds.tiles_y = (ds.h[1] + kMipRowsPerPass - 1) / kMipRowsPerPass;
+            }
         }
         ds.hostile = ctx->hostile_of(set);
-        ds.generation = generation;
-        ds.tile_begin = 0;
-        ds.tile_end = ds.tiles_x * ds.tiles_y;
+        ds.generation = gen;
         return ds;
-    };
-    auto next_generation = [&]() { if (++ctx->gen_counter == 0) ++ctx->gen_counter; return ctx->gen_counter; };   // never 0
-
-    // A downsample pass of the previous call that ran on the side stream (MEAO_DEBUG_DS_SIDE_STREAM): everything this
-    // call launches is ordered behind it -- its readers if the announcement was right, and its own downsample pass,
-    // which may write the same set, if it was not.
-    if (ctx->side_pending) {
-        MEAO_HIP(ctx, hipStreamWaitEvent(stream, ctx->side_done, 0));
-        ctx->side_pending = false;
     }
-
-    // A previous call may already have downsampled exactly these frames (meao_prefetch_batch).  The
-    // prefetched set is only valid on the stream of the execute that carried it: stream order is what
-    // orders that kernel before this call's readers.
-    const bool prefetched = ctx->ready_n == n && ctx->ready_stream == stream &&
-                            std::memcmp(ctx->ready_depth, depth_dev, sizeof(void *) * n) == 0;
-    ctx->ds_cur = prefetched ? ctx->ready_set : 0;
-    ctx->ready_n = 0;
-    // Render straight from the raw depth (ctx->render_from_depth): 0 = no, 1 = render + downsample in one launch, 2 = two streams
-    int from_depth = 0;
-    if (!prefetched && ctx->render_from_depth != 0 && c.depth_format == MEAO_DEPTH_F32 && c.sample_set == MEAO_SAMPLES_CHECKER &&
-        ctx->pending_comp.frames == 0) {
-        int tiles32 = 0;
-        for (int l = 1; l <= c.num_levels; ++l)
-            tiles32 += ((p.mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p.mip[l].h + kRenTileH - 1) / kRenTileH);
-        if (ctx->render_from_depth == 3) from_depth = n * tiles32 <= ctx->render_from_depth_max_tiles ? 1 : 0;
-        else from_depth = ctx->render_from_depth;
-        if (from_depth == 2 && capturing) from_depth = 1;          // a captured sequence stays on one stream
-    }
-    DownsampleArgs own_ds{};
-    if (!prefetched) {
-        TraceRange tr(ctx, "meao:downsample");
-        ctx->set_gen[ctx->ds_cur] = next_generation();
-        // A captured sequence bakes its generation into the kernel arguments, so every replay stamps and tests
-        // the same value: the flag words are cleared in front of the downsample launch (a memset node), or one
-        // hostile frame would keep every later replay on the IEEE-division bodies.  Direct launches take a
-        // fresh generation per downsample and need no clearing.
-        if (capturing) MEAO_HIP(ctx, hipMemsetAsync(ctx->hostile_of(ctx->ds_cur), 0, sizeof(uint32_t) * n, stream));
-        own_ds = downsample_args(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur], true);
-        if (from_depth == 2) {      // the render launch goes to the second stream first; both read only the caller's depth
-            if (!ctx->rfd_stream) {
-                MEAO_HIP(ctx, hipStreamCreateWithFlags(&ctx->rfd_stream, hipStreamNonBlocking));
-                MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->rfd_fork, hipEventDisableTiming));
-                MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->rfd_join, hipEventDisableTiming));
-            }
-            MEAO_HIP(ctx, hipEventRecord(ctx->rfd_fork, stream));      // behind the previous call's readers of the Occlusion buffers
-            MEAO_HIP(ctx, hipStreamWaitEvent(ctx->rfd_stream, ctx->rfd_fork, 0));
-        }
-        if (from_depth != 1) {
-            MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, stream));
-            MEAO_HIP(ctx, launch_downsample(own_ds, n, stream));
-            MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, stream));
-        }
-    }
-    const uint32_t *hostile = ctx->hostile_of(ctx->ds_cur);
-    const uint32_t generation = ctx->set_gen[ctx->ds_cur];
 
     // ---- PushRenderCommands x num_levels (AO.cs:519-522): the levels [first, last] as one grid
-    auto render_args = [&](int first, int last, bool wide, bool allow_small = false) {
+    RenderArgs render(int first, int last, bool wide, bool allow_small) const
+    {
         RenderArgs rn{};
         int blocks = 0, count = 0;
         // few tiles (a 1080p frame or two): 128 x 8 tiles instead of 128 x 32 (render_small_kernel)
         int tile_h = kRenTileH;
-        if (allow_small && !wide && c.sample_set != MEAO_SAMPLES_EXHAUSTIVE) {
+        if (allow_small && !wide && c().sample_set != MEAO_SAMPLES_EXHAUSTIVE) {
             int tiles32 = 0;
             for (int l = first; l <= last; ++l)
-                tiles32 += ((p.mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p.mip[l].h + kRenTileH - 1) / kRenTileH);
+                tiles32 += ((p().mip[l].w + ren_tile_w(false) - 1) / ren_tile_w(false)) * ((p().mip[l].h + kRenTileH - 1) / kRenTileH);
             if (n * tiles32 <= ctx->render_small_max_tiles) tile_h = kRenTileHSmall;
         }
         rn.tile_h = tile_h;
         for (int l = first; l <= last; ++l) {
-            if (wide && !level_has_hq(c.num_levels, c.hq_levels, l)) continue;
+            if (wide && !level_has_hq(c().num_levels, c().hq_levels, l)) continue;
             RenderLevelArgs &L = rn.level[count++];
-            const RenderLevelPlan &rp = wide ? p.render_hq[l - 1] : p.render[l - 1];
+            const RenderLevelPlan &rp = wide ? p().render_hq[l - 1] : p().render[l - 1];
             L.src = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, l - 1));
             L.dst = slot_ptr<void>(ctx, wide ? ctx->off_hq[l - 1] : ctx->off_occ[l - 1]);
-            L.lw = p.mip[l].w; L.lh = p.mip[l].h;
-            L.sw = p.mip[l + 2].w; L.sh = p.mip[l + 2].h;
-            const int tile_w = wide ? kWideTileW : ren_tile_w(c.sample_set == MEAO_SAMPLES_EXHAUSTIVE);
+            L.lw = p().mip[l].w; L.lh = p().mip[l].h;
+            L.sw = p().mip[l + 2].w; L.sh = p().mip[l + 2].h;
+            const int tile_w = wide ? kWideTileW : ren_tile_w(c().sample_set == MEAO_SAMPLES_EXHAUSTIVE);
             L.tiles_x = (L.lw + tile_w - 1) / tile_w;
             L.tiles_y = (L.lh + tile_h - 1) / tile_h;
             L.block_begin = blocks;
@@ -514,40 +476,43 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         rn.frame_stride = ctx->slot_bytes;
         rn.num_levels = count;
         rn.blocks_per_frame = blocks;
-        rn.f16_rtne = rtne;
+        rn.f16_rtne = rtne();
         rn.exact_rcp_div = ctx->exact_rcp_div;
-        rn.exhaustive = c.sample_set == MEAO_SAMPLES_EXHAUSTIVE;
+        rn.exhaustive = c().sample_set == MEAO_SAMPLES_EXHAUSTIVE;
         rn.hostile = hostile;
         rn.generation = generation;
         return rn;
-    };
+    }
 
-    // ---- PushUpsampleCommands (AO.cs:750-785): the pass that writes level `hi`
-    static const char *const kUpsRange[4] = {"meao:upsample_L1_to_L0", "meao:upsample_L2_to_L1", "meao:upsample_L3_to_L2",
-                                             "meao:upsample_L4_to_L3"};
-    auto upsample_args = [&](int hi) {
+    // ---- PushUpsampleCommands (AO.cs:750-785): the pass that writes level `hi`.  carrying: the final pass of a call whose
+    // last kernel carries the next batch's downsample pass (always 64 x 64 tiles)
+    UpsampleArgs upsample(int hi, bool carrying = false) const
+    {
         UpsampleArgs up{};
-        const meao_upsample_constants &k = p.upsample[hi];   // low level = hi + 1
+        const meao_upsample_constants &k = p().upsample[hi];   // low level = hi + 1
         up.lo_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi));
         // LoResAO1: the coarsest level's Occlusion, else the Combined buffer of the previous pass
-        up.lo_ao = slot_ptr<void>(ctx, hi == c.num_levels - 1 ? ctx->off_occ[hi] : ctx->off_comb[hi]);
+        up.lo_ao = slot_ptr<void>(ctx, hi == c().num_levels - 1 ? ctx->off_occ[hi] : ctx->off_comb[hi]);
         // main_premin*: the Render.main output of the low level is min-combined in PrefetchData
-        up.lo_ao2 = level_has_hq(c.num_levels, c.hq_levels, hi + 1) ? slot_ptr<void>(ctx, ctx->off_hq[hi]) : nullptr;
+        up.lo_ao2 = level_has_hq(c().num_levels, c().hq_levels, hi + 1) ? slot_ptr<void>(ctx, ctx->off_hq[hi]) : nullptr;
         up.frame_stride = ctx->slot_bytes;
-        up.lw = p.mip[hi + 1].w; up.lh = p.mip[hi + 1].h;
-        up.hw = p.mip[hi].w; up.hh = p.mip[hi].h;
+        up.lw = p().mip[hi + 1].w; up.lh = p().mip[hi + 1].h;
+        up.hw = p().mip[hi].w; up.hh = p().mip[hi].h;
         up.tiles_x = (up.hw + kUpsTileW - 1) / kUpsTileW;
         up.tile_h = ups_tile_h(hi == 0);
         // few tiles (one 1080p frame): the plain final pass runs 64 x 32 tiles (upsample_final_small_kernel)
-        if (hi == 0 && ctx->next_n == 0 &&
-            n * up.tiles_x * ((up.hh + up.tile_h - 1) / up.tile_h) <= ctx->final_small_max_tiles)
+        if (hi == 0 && !carrying && n * up.tiles_x * ((up.hh + up.tile_h - 1) / up.tile_h) <= ctx->final_small_max_tiles)
             up.tile_h = kUpsTileHSmall;
+        // L2 -> L1 of a large batch: 64 x 64 tiles like the full-resolution pass (upsample_blend_tall_kernel)
+        if (hi == 1 && (c().ao_format == MEAO_AO_R8 || ctx->blend_tall_forced) &&
+            static_cast<int64_t>(n) * up.tiles_x * ((up.hh + up.tile_h - 1) / up.tile_h) >= ctx->blend_tall_min_tiles)
+            up.tile_h = kUpsTileHTall;
         up.tiles_y = (up.hh + up.tile_h - 1) / up.tile_h;
         up.noise_filter_strength = k.noise_filter_strength;
         up.step_size = k.step_size;
         up.blur_tolerance = k.blur_tolerance;
         up.upsample_tolerance = k.upsample_tolerance;
-        up.f16_rtne = rtne;
+        up.f16_rtne = rtne();
         up.exact_rcp_div = ctx->exact_rcp_div;
         up.hostile = hostile;
         up.generation = generation;
@@ -556,257 +521,145 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
             up.hi_depth = slot_ptr<float>(ctx, ctx->off_low_of(ctx->ds_cur, hi - 1));
             up.hi_ao = slot_ptr<void>(ctx, ctx->off_occ[hi - 1]);
             up.dst[0] = slot_ptr<void>(ctx, ctx->off_comb[hi - 1]);
-        } else {        // main: LinearDepth f16 as HiResDB, no HiResAO, write the result
-            up.hi_depth = slot_ptr<uint16_t>(ctx, ctx->off_linear_of(ctx->ds_cur));
+        } else {        // main: HiResDB from the raw depth frames (hi_depth()), no HiResAO, write the result
+            up.hi_depth = nullptr;
             up.hi_ao = nullptr;
             for (int f = 0; f < n; ++f) {
                 up.dst[f] = out_dev[f];
-                vec_ok = vec_ok && aligned_to(out_dev[f], out_align);
+                vec_ok = vec_ok && aligned_to(out_dev[f], out_align()) && aligned_to(depth_dev[f], depth_align());
             }
         }
         up.vec_ok = vec_ok;
         return up;
-    };
-    auto launch_blend = [&](int hi, hipStream_t s) -> int {   // hi = 3, 2, 1
-        const int pass = MEAO_PASS_UPSAMPLE_0 - hi;
-        TraceRange tr(ctx, kUpsRange[hi]);
-        UpsampleArgs up = upsample_args(hi);
-        // L2 -> L1 of a large batch: 64 x 64 tiles like the full-resolution pass (upsample_blend_tall_kernel)
-        if (hi == 1 && (c.ao_format == MEAO_AO_R8 || ctx->blend_tall_forced) &&
-            static_cast<int64_t>(n) * up.tiles_x * up.tiles_y >= ctx->blend_tall_min_tiles) {
-            up.tile_h = kUpsTileHTall;
-            up.tiles_y = (up.hh + up.tile_h - 1) / up.tile_h;
-        }
-        MEAO_HIP(ctx, begin(pass, s));
-        MEAO_HIP(ctx, launch_upsample(up, c.ao_format, false, n, s));
-        MEAO_HIP(ctx, end(pass, s));
-        return MEAO_OK;
-    };
-
-    // MEAO_DEBUG_DS_SIDE_STREAM: the announced batch's downsample pass as its own kernel(s) on the side stream, released when
-    // `stream` reaches a gate of this call: all frames at gate A, or the first `split` tenths of them there and the rest at a
-    // later gate B.  (The set they write was last read by the PREVIOUS call's kernels, all in front of every gate in stream
-    // order; the next execute waits for side_done before anything else.)
-    struct SidePlan { bool active = false; int total = 0, first_part = 0, issued = 0, gate_a = 0, gate_b = 0, shape = 0, prio = 0, other = 0; } side;
-    if (ctx->ds_side_stream > 0 && ctx->next_n > 0 && !capturing && c.depth_format == MEAO_DEPTH_F32 &&
-        downsample_args(ctx->next_n, ctx->next_depth, 1 - ctx->ds_cur, 0).vec_ok) {      // anything else stays with the last kernel (fused form)
-        const int v = ctx->ds_side_stream, split = v / 1000 % 10;
-        side.active = true;
-        side.total = ctx->next_n;
-        side.gate_a = v % 10; side.shape = v / 10 % 10; side.prio = v / 100 % 10;
-        side.gate_b = v / 10000 % 10 ? v / 10000 % 10 : 1;
-        side.first_part = (split == 0 || side.gate_b >= side.gate_a) ? side.total
-                                                                     : std::min(side.total, std::max(1, (side.total * split + 9) / 10));
-        side.other = 1 - ctx->ds_cur;
     }
-    auto side_downsample_at = [&](int g) -> int {
-        if (!side.active || side.issued == side.total) return MEAO_OK;
-        int first, count;
-        if (g == side.gate_a && side.issued == 0) { first = 0; count = side.first_part; }
-        else if (g == side.gate_b && side.issued == side.first_part) { first = side.issued; count = side.total - first; }
-        else return MEAO_OK;
-        if (!ctx->side_stream) {
-            int least = 0, greatest = 0;
-            MEAO_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            MEAO_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking,
-                                                      side.prio == 0 ? least : (side.prio == 1 ? 0 : greatest)));
-            MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->side_gate, hipEventDisableTiming));
-            MEAO_HIP(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
-        }
-        if (first == 0) ctx->set_gen[side.other] = next_generation();       // one generation for all parts
-        DownsampleArgs ds = downsample_args(count, ctx->next_depth + first, side.other, ctx->set_gen[side.other]);
-        ds.linear = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(ds.linear) + ctx->slot_bytes * first);    // frames [first, first + count)
-        for (int k = 0; k < 4; ++k) ds.low[k] = reinterpret_cast<float *>(reinterpret_cast<char *>(ds.low[k]) + ctx->slot_bytes * first);
-        ds.hostile += first;
-        ds.row_passes = side.shape <= 1 ? 16 : (side.shape == 2 || side.shape == 4 ? 8 : 4);       // shape 4: 8 loads, 120 VGPRs declared
-        ds.tiles_y = (p.mip[0].h + ds.row_passes * kDsRowsPerPass - 1) / (ds.row_passes * kDsRowsPerPass);
-        ds.tile_end = ds.tiles_x * ds.tiles_y;
-        TraceRange tr(ctx, "meao:downsample_next(side stream)");
-        MEAO_HIP(ctx, hipEventRecord(ctx->side_gate, stream));
-        MEAO_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_gate, 0));
-        // (the side kernel is timed in the DOWNSAMPLE slot only in calls that did not run a pass of their own there)
-        if (first == 0 && prefetched) MEAO_HIP(ctx, begin(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));
-        MEAO_HIP(ctx, launch_downsample_side(ds, count, side.shape == 0 || side.shape == 4, ctx->side_stream));
-        side.issued = first + count;
-        // recorded behind EVERY part: whenever side_pending is set, side_done orders a later call (or meao_synchronize) behind
-        // everything that was launched on the side stream so far -- also when a later part fails to launch
-        MEAO_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
-        ctx->side_pending = true;
-        if (side.issued == side.total) {
-            if (prefetched) MEAO_HIP(ctx, end(MEAO_PASS_DOWNSAMPLE, ctx->side_stream));      // the slot spans all parts (and the wait between them)
-            ctx->ready_n = ctx->next_n;
-            ctx->ready_set = side.other;
-            ctx->ready_stream = stream;
-            std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
-            ctx->next_n = 0;
-        }
-        return MEAO_OK;
-    };
 
+    // HiResDB of Upsample.main = LinearZ (DS1:37-48), which the final pass evaluates from this call's raw depth frames
+    HiDepthArgs hi_depth() const
+    {
+        HiDepthArgs hd{};
+        for (int f = 0; f < n; ++f) hd.raw[f] = depth_dev[f];
+        hd.depth_format = c().depth_format;
+        hd.reversed_z = ctx->prm.reversed_z != 0;
+        hd.zp0 = p().zbuffer_params[0];
+        hd.zp1 = p().zbuffer_params[1];
+        return hd;
+    }
+};
+
+uint32_t next_generation(meao_ctx *ctx) { if (++ctx->gen_counter == 0) ++ctx->gen_counter; return ctx->gen_counter; }   // never 0
+
+// The launch sequence of one batch.
+int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream)
+{
+    const meao_config &c = ctx->cfg;
+    hipEvent_t *ev = nullptr;
+    uint32_t ran = 0;
+    if (ctx->profiling) {
+        if (ctx->profile_phase == 0) {
+            if (ctx->ring_fill == kProfileRing) fold_profile(ctx);
+            ev = &ctx->events[ctx->ring_fill * kProfSlots * 2];
+        }
+        if (++ctx->profile_phase >= ctx->profile_period) ctx->profile_phase = 0;
+    }
+
+    // A previous call may already have downsampled exactly these frames (meao_prefetch_batch).  The
+    // prefetched set is only valid on the stream of the execute that carried it: stream order is what
+    // orders that kernel before this call's readers.
+    BatchShape shape{};
+    shape.frames = n;
+    shape.prefetched = ctx->ready_n == n && ctx->ready_stream == stream && std::memcmp(ctx->ready_depth, depth_dev, sizeof(void *) * n) == 0;
+    ctx->ds_cur = shape.prefetched ? ctx->ready_set : 0;
+    ctx->ready_n = 0;
+    if (!shape.prefetched) ctx->set_gen[ctx->ds_cur] = next_generation(ctx);      // direct launches take a fresh generation per pass: no flag clearing
     if (ctx->pending_comp.frames > 0 && c.sample_set == MEAO_SAMPLES_EXHAUSTIVE) {
         const int rc = flush_pending_composite(ctx, stream);     // the 68-sample render kernel carries nothing
         if (rc != MEAO_OK) return rc;
     }
-    { const int rc = side_downsample_at(4); if (rc != MEAO_OK) return rc; }
-    if (from_depth != 0) {
-        // one frame per call: windows from the raw depth; form 1 carries the downsample pass as extra workgroups, form 2 runs on
-        // the second stream next to the pass and is joined here, in front of the first reader of both
-        TraceRange tr(ctx, from_depth == 1 ? "meao:render_from_depth+downsample" : "meao:render_from_depth(second stream)");
-        hipStream_t rs = from_depth == 2 ? ctx->rfd_stream : stream;
-        MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, rs));
-        MEAO_HIP(ctx, launch_render_from_depth(render_args(1, c.num_levels, false, true), own_ds, from_depth == 1, c.ao_format, n, rs));
-        MEAO_HIP(ctx, end(MEAO_PASS_RENDER, rs));
-        if (from_depth == 2) {
-            MEAO_HIP(ctx, hipEventRecord(ctx->rfd_join, rs));
-            MEAO_HIP(ctx, hipStreamWaitEvent(stream, ctx->rfd_join, 0));
+    shape.carry_composite = ctx->pending_comp.frames > 0;
+
+    const ArgBuilder args{ctx, n, depth_dev, out_dev, ctx->hostile_of(ctx->ds_cur), ctx->set_gen[ctx->ds_cur]};
+    // The announced next batch: its pass rides in this call's last kernel where the fused form applies (f32 depth, 16-byte
+    // loads, a workgroup per carried tile), else it runs as a launch of its own behind it.  Either way the next call finds it done.
+    const int other = 1 - ctx->ds_cur;
+    DownsampleArgs next_ds{};
+    UpsampleArgs final_up = args.upsample(0);
+    const HiDepthArgs hi_depth = args.hi_depth();
+    if (ctx->next_n > 0) {
+        ctx->set_gen[other] = next_generation(ctx);
+        next_ds = args.downsample(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other], true, false);
+        const UpsampleArgs carrying = args.upsample(0, true);
+        if (fused_downsample_applicable(carrying, hi_depth, next_ds, n)) {
+            shape.next = 1;
+            final_up = carrying;
+        } else {
+            shape.next = 2;
+            next_ds = args.downsample(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other], false, true);
         }
-    } else {
-        TraceRange tr(ctx, ctx->pending_comp.frames > 0 ? "meao:render+composite_of_previous_call" : "meao:render");
-        MEAO_HIP(ctx, begin(MEAO_PASS_RENDER, stream));
-        if (ctx->pending_comp.frames > 0) {
+    }
+
+    const LaunchList list = plan_launches(ctx, shape);
+    for (int i = 0; i < list.n; ++i) {
+        const Launch &L = list.v[i];
+        TraceRange tr(ctx, L.range);
+        // one launch = one profiling slot: events right before and after it on its stream
+        const bool timed = L.slot >= 0 && (ctx->profile_mask >> L.slot & 1u);
+        if (timed && ev) MEAO_HIP(ctx, hipEventRecord(ev[L.slot * 2], stream));
+        switch (L.step) {
+        case Step::Downsample:
+            MEAO_HIP(ctx, launch_downsample(args.downsample(n, depth_dev, ctx->ds_cur, ctx->set_gen[ctx->ds_cur], false, true), n, stream));
+            break;
+        case Step::Render:
+            MEAO_HIP(ctx, launch_render(args.render(1, c.num_levels, false, true), c.ao_format, n, stream));
+            break;
+        case Step::RenderWithComposite:
             // the composite of frames an earlier call produced streams under this (VALU-bound) kernel
-            MEAO_HIP(ctx, launch_render_with_composite(render_args(1, c.num_levels, false), ctx->pending_comp, c.ao_format, n, stream));
+            MEAO_HIP(ctx, launch_render_with_composite(args.render(1, c.num_levels, false, false), ctx->pending_comp, c.ao_format, n, stream));
             ctx->pending_comp.frames = 0;
-        } else {
-            MEAO_HIP(ctx, launch_render(render_args(1, c.num_levels, false, true), c.ao_format, n, stream));
-        }
-        MEAO_HIP(ctx, end(MEAO_PASS_RENDER, stream));
-    }
-    if (c.hq_levels > 0) {   // Render.main (wide) on LowDepth<k> for the levels cfg.hq_levels enables, one grid
-        TraceRange tr(ctx, "meao:render_hq");
-        MEAO_HIP(ctx, begin(MEAO_PASS_RENDER_HQ, stream));
-        MEAO_HIP(ctx, launch_render_wide(render_args(1, c.num_levels, true), c.ao_format, n, stream));
-        MEAO_HIP(ctx, end(MEAO_PASS_RENDER_HQ, stream));
-    }
-    { const int rc = side_downsample_at(3); if (rc != MEAO_OK) return rc; }
-    bool blend_done = false;
-    const int l1_tiles = ((p.mip[1].w + kUpsTileW - 1) / kUpsTileW) * ((p.mip[1].h + ups_tile_h(false) - 1) / ups_tile_h(false));
-    if (ctx->fuse_coarse_blend && c.num_levels == 4 && c.hq_levels == 0 && n * l1_tiles <= ctx->nested_max_tiles) {
-        // a small frame or two per call (at most two workgroups per CU): all three blend passes in one launch --
-        // their latency chains, not their arithmetic, are what such a call waits for (1080p: 39.2 -> 36.9 us per
-        // frame; at 4K, 1020 tiles, it is a wash).  Combined3 and Combined2 are still written
-        TraceRange tr(ctx, "meao:upsample_L4_to_L3+L3_to_L2+L2_to_L1");
-        MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_1, stream));
-        MEAO_HIP(ctx, launch_upsample_three_level(upsample_args(1), upsample_args(2), upsample_args(3), c.ao_format, n, stream));
-        MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_1, stream));
-        blend_done = true;
-    } else if (ctx->fuse_coarse_blend && c.num_levels == 4 && c.hq_levels == 0) {
-        // L4 -> L3 inside the L3 -> L2 launch: one launch, one latency-bound pass less (Combined3 is still written)
-        TraceRange tr(ctx, "meao:upsample_L4_to_L3+L3_to_L2");
-        MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_2, stream));
-        MEAO_HIP(ctx, launch_upsample_two_level(upsample_args(2), upsample_args(3), c.ao_format, n, stream));
-        MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_2, stream));
-    } else {
-        for (int hi = c.num_levels - 1; hi >= 2; --hi) {
-            const int rc = launch_blend(hi, stream);
-            if (rc != MEAO_OK) return rc;
-        }
-    }
-    // Part of the announced next batch's downsample pass can ride in the L2 -> L1 blend launch (latency-bound, HBM and
-    // issue slots idle) instead of the last kernel: tiles [0, carried_in_blend) of every frame
-    { const int rc = side_downsample_at(2); if (rc != MEAO_OK) return rc; }
-    int carried_in_blend = 0;
-    uint32_t next_gen = 0;
-    if (c.num_levels >= 2 && !blend_done) {
-        const UpsampleArgs up1 = upsample_args(1);
-        if (ctx->next_n > 0 && ctx->ds_share_in_blend > 0 && ctx->next_n <= n && !side.active) {
-            next_gen = next_generation();
-            DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, 1 - ctx->ds_cur, next_gen);
-            const int blend_tiles = up1.tiles_x * up1.tiles_y, ds_tiles = ds.tiles_x * ds.tiles_y;
-            const int share = std::min(blend_tiles, static_cast<int>(static_cast<int64_t>(ds_tiles) * ctx->ds_share_in_blend / 100));
-            const int final_tiles = ((p.mip[0].w + kUpsTileW - 1) / kUpsTileW) * ((p.mip[0].h + ups_tile_h(true) - 1) / ups_tile_h(true));
-            if (share > 0 && ds.vec_ok && c.depth_format == MEAO_DEPTH_F32 && ds_tiles <= final_tiles) {   // the last kernel takes the rest in its split form
-                ds.tile_end = share;
-                TraceRange tr(ctx, "meao:upsample_L2_to_L1+part_of_downsample_next");
-                MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_1, stream));
-                MEAO_HIP(ctx, launch_upsample_blend_with_downsample(up1, ds, c.ao_format, n, stream));
-                MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_1, stream));
-                carried_in_blend = share;
+            break;
+        case Step::RenderHq:
+            MEAO_HIP(ctx, launch_render_wide(args.render(1, c.num_levels, true, false), c.ao_format, n, stream));
+            break;
+        case Step::Blend:
+            MEAO_HIP(ctx, launch_upsample(args.upsample(L.hi), nullptr, c.ao_format, n, stream));
+            break;
+        case Step::BlendTwoLevel:
+            MEAO_HIP(ctx, launch_upsample_two_level(args.upsample(2), args.upsample(3), c.ao_format, n, stream));
+            break;
+        case Step::BlendThreeLevel: {
+            UpsampleArgs outer = args.upsample(1);
+            if (outer.tile_h != ups_tile_h(false)) {        // the nested launch tiles L2 -> L1 with 64 x 32
+                outer.tile_h = ups_tile_h(false);
+                outer.tiles_y = (outer.hh + outer.tile_h - 1) / outer.tile_h;
             }
+            MEAO_HIP(ctx, launch_upsample_three_level(outer, args.upsample(2), args.upsample(3), c.ao_format, n, stream));
+            break;
         }
-        if (carried_in_blend == 0) {
-            const int rc = launch_blend(1, stream);
-            if (rc != MEAO_OK) return rc;
+        case Step::Final:
+            MEAO_HIP(ctx, launch_upsample(final_up, &hi_depth, c.ao_format, n, stream));
+            break;
+        case Step::FinalWithNextDownsample:
+            MEAO_HIP(ctx, launch_upsample_final_with_downsample(final_up, hi_depth, next_ds, c.ao_format, n, stream));
+            break;
+        case Step::DownsampleNext:
+            MEAO_HIP(ctx, launch_downsample(next_ds, ctx->next_n, stream));
+            break;
+        }
+        if (timed) {
+            ran |= 1u << L.slot;
+            if (ev) MEAO_HIP(ctx, hipEventRecord(ev[L.slot * 2 + 1], stream));
         }
     }
-    { const int rc = side_downsample_at(1); if (rc != MEAO_OK) return rc; }
-    {   // Upsample.main: the result
-        TraceRange tr(ctx, kUpsRange[0]);
-        const UpsampleArgs up = upsample_args(0);
-        MEAO_HIP(ctx, begin(MEAO_PASS_UPSAMPLE_0, stream));
-        if (ctx->next_n > 0) {
-            // carry the downsample of the announced next batch in this (VALU-bound) kernel
-            const int other = 1 - ctx->ds_cur;
-            ctx->set_gen[other] = carried_in_blend > 0 ? next_gen : next_generation();     // one generation for both carrying launches
-            DownsampleArgs ds = downsample_args(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other]);
-            ds.tile_begin = carried_in_blend;
-            MEAO_HIP(ctx, launch_upsample_final_with_downsample(up, ds, c.ao_format, n, stream));
-            ctx->ready_n = ctx->next_n;
-            ctx->ready_set = other;
-            ctx->ready_stream = stream;
-            std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
-            ctx->next_n = 0;
-        } else {
-            MEAO_HIP(ctx, launch_upsample(up, c.ao_format, true, n, stream));
-        }
-        MEAO_HIP(ctx, end(MEAO_PASS_UPSAMPLE_0, stream));
+    if (shape.next != 0) {
+        ctx->ready_n = ctx->next_n;
+        ctx->ready_set = other;
+        ctx->ready_stream = stream;
+        std::memcpy(ctx->ready_depth, ctx->next_depth, sizeof ctx->ready_depth);
+        ctx->next_n = 0;
     }
     if (ev) ctx->ran_mask[ctx->ring_fill++] = ran;
-    for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
+    for (int f = 0; f < n; ++f) { ctx->last_out[f] = out_dev[f]; ctx->last_depth[f] = depth_dev[f]; }
     ctx->last_frames = n;
     ctx->last_stream = stream;
-    return MEAO_OK;
-}
-
-// MEAO_LAUNCH_GRAPH: replay the captured launch sequence of this exact batch, capturing it first
-// if it is new.  The captured nodes are the very launches run_batch() makes.
-int submit_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *out_dev, hipStream_t stream)
-{
-    if (ctx->cfg.launch_mode != MEAO_LAUNCH_GRAPH || ctx->profiling || ctx->next_n > 0 || ctx->ready_n > 0 ||
-        ctx->pending_comp.frames > 0)
-        return run_batch(ctx, n, depth_dev, out_dev, stream);   // pipelined calls differ from call to call
-    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &status) != hipSuccess || status != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return run_batch(ctx, n, depth_dev, out_dev, stream);   // the caller's own capture records our launches
-    }
-    for (size_t i = 0; i < ctx->graphs.size(); ++i) {
-        const meao_ctx::CapturedBatch &g = ctx->graphs[i];
-        if (g.n != n || std::memcmp(g.depth, depth_dev, sizeof(void *) * n) != 0 ||
-            std::memcmp(g.out, out_dev, sizeof(void *) * n) != 0)
-            continue;
-        const meao_ctx::CapturedBatch hit = g;
-        ctx->graphs.erase(ctx->graphs.begin() + static_cast<long>(i));
-        ctx->graphs.push_back(hit);
-        MEAO_HIP(ctx, hipGraphLaunch(hit.exec, stream));
-        ctx->ds_cur = 0;                       // captured sequences always write and read downsample set 0
-        ctx->set_gen[0] = hit.generation;      // ... with the hostile-flag generation baked into their arguments
-        for (int f = 0; f < n; ++f) ctx->last_out[f] = out_dev[f];
-        ctx->last_frames = n;
-        ctx->last_stream = stream;
-        return MEAO_OK;
-    }
-    MEAO_HIP(ctx, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    const int rc = run_batch(ctx, n, depth_dev, out_dev, stream, true);
-    hipGraph_t graph = nullptr;
-    const hipError_t end = hipStreamEndCapture(stream, &graph);
-    if (rc != MEAO_OK || end != hipSuccess) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc != MEAO_OK ? rc : fail_hip(ctx, end, "hipStreamEndCapture");
-    }
-    meao_ctx::CapturedBatch g;
-    g.n = n;
-    g.generation = ctx->set_gen[0];
-    for (int f = 0; f < n; ++f) { g.depth[f] = depth_dev[f]; g.out[f] = out_dev[f]; }
-    const hipError_t inst = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (inst != hipSuccess) return fail_hip(ctx, inst, "hipGraphInstantiate");
-    if (ctx->graphs.size() >= kMaxCapturedBatches) {
-        (void)hipGraphExecDestroy(ctx->graphs.front().exec);
-        ctx->graphs.erase(ctx->graphs.begin());
-    }
-    ctx->graphs.push_back(g);
-    MEAO_HIP(ctx, hipGraphLaunch(g.exec, stream));
     return MEAO_OK;
 }
 
@@ -842,7 +695,6 @@ void meao_default_config(meao_config *cfg)
     cfg->num_levels = 4;
     cfg->ao_format = MEAO_AO_R8;
     cfg->f16_rounding = MEAO_F16_RTZ_CLAMP;
-    cfg->numerics = MEAO_NUMERICS_STRICT;
     cfg->max_batch = 1;
     cfg->depth_format = MEAO_DEPTH_F32;
     cfg->pipelined = 0;
@@ -933,8 +785,6 @@ int32_t meao_create(const meao_config *cfg, meao_ctx **out_ctx)
         return fail(nullptr, MEAO_ERR_INVALID_ARGUMENT, "meao_create: struct_size mismatch (ABI)");
     std::string why;
     if (!config_valid(*cfg, &why)) return fail(nullptr, MEAO_ERR_INVALID_ARGUMENT, "meao_create: " + why);
-    if (cfg->numerics != MEAO_NUMERICS_STRICT && cfg->numerics != MEAO_NUMERICS_FAST)
-        return fail(nullptr, MEAO_ERR_UNSUPPORTED, "meao_create: unknown numerics mode");
 
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -988,18 +838,11 @@ int32_t meao_destroy(meao_ctx *ctx)
     // typically ended by now (free the frames, then destroy); hosts that want it call meao_composite_flush first.
     ctx->pending_comp.frames = 0;
     (void)hipDeviceSynchronize();
-    drop_graphs(ctx);
     release_buffers(ctx);
     if (ctx->counter) (void)hipFree(ctx->counter);
     if (ctx->hostile) (void)hipFree(ctx->hostile);
     if (ctx->roctx_lib) (void)dlclose(ctx->roctx_lib);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    if (ctx->side_gate) (void)hipEventDestroy(ctx->side_gate);
-    if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
-    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    if (ctx->rfd_fork) (void)hipEventDestroy(ctx->rfd_fork);
-    if (ctx->rfd_join) (void)hipEventDestroy(ctx->rfd_join);
-    if (ctx->rfd_stream) (void)hipStreamDestroy(ctx->rfd_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     if (prev_device >= 0) (void)hipSetDevice(prev_device);
@@ -1096,7 +939,7 @@ int meao::execute_batch_internal(meao_ctx *ctx, int32_t n, const void *const *de
         for (int f = 0; f < n; ++f) out_dev[f] = ao_out[f];
     }
 
-    rc = submit_batch(ctx, n, depth_dev, out_dev, stream);
+    rc = run_batch(ctx, n, depth_dev, out_dev, stream);
     if (rc != MEAO_OK) return rc;
 
     if (out_loc == MEAO_MEM_HOST)
@@ -1148,31 +991,50 @@ int32_t meao_synchronize(meao_ctx *ctx, meao_stream stream)
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
     MEAO_HIP(ctx, hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : ctx->last_stream));
-    // a downsample pass of the next batch that the last call put on the side stream (MEAO_DEBUG_DS_SIDE_STREAM) reads the
-    // caller's announced depth frames and holds profiling events: "synchronized" includes it
-    if (ctx->side_pending && ctx->side_done) MEAO_HIP(ctx, hipEventSynchronize(ctx->side_done));
     return MEAO_OK;
 }
 
-// Device address of debug buffer `debug_id` of batch slot `frame` (TiledDepth is built on demand).
+// Scratch for the buffers the hot path never materialises (LinearDepth, TiledDepth<level>): at least `bytes`.
+static int reserve_scratch(meao_ctx *ctx, uint64_t bytes)
+{
+    if (ctx->atlas_scratch_bytes >= bytes) return MEAO_OK;
+    if (ctx->atlas_scratch) (void)hipFree(ctx->atlas_scratch);
+    ctx->atlas_scratch = nullptr;
+    ctx->atlas_scratch_bytes = 0;
+    MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->atlas_scratch), bytes));
+    ctx->atlas_scratch_bytes = bytes;
+    return MEAO_OK;
+}
+
+// Device address of debug buffer `debug_id` of batch slot `frame` (LinearDepth and TiledDepth are built on demand).
 static int locate_debug_buffer(meao_ctx *ctx, int32_t frame, int32_t debug_id, const meao_desc &d, hipStream_t s,
                                const void **out_src)
 {
     const char *slot = ctx->arena + ctx->slot_bytes * frame;
     const int nl = ctx->cfg.num_levels;
-    if (debug_id == 1) *out_src = slot + ctx->off_linear_of(ctx->ds_cur);
-    else if (debug_id <= 5) *out_src = slot + ctx->off_low_of(ctx->ds_cur, debug_id - 2);
+    if (debug_id == 1) {
+        // LinearDepth: materialised on demand from the raw depth frame of the last call (its one consumer on the hot path,
+        // the full-resolution upsample, evaluates Linearize itself).  The caller's depth frame must still be alive.
+        const int rc = reserve_scratch(ctx, d.bytes);
+        if (rc != MEAO_OK) return rc;
+        LinearDepthArgs la{};
+        la.depth = ctx->last_depth[frame];
+        la.dst = reinterpret_cast<uint16_t *>(ctx->atlas_scratch);
+        la.pixels = static_cast<int64_t>(d.width) * d.height;
+        la.depth_format = ctx->cfg.depth_format;
+        la.reversed_z = ctx->prm.reversed_z != 0;
+        la.f16_rtne = ctx->cfg.f16_rounding == MEAO_F16_RTNE;
+        la.zp0 = ctx->plan.zbuffer_params[0];
+        la.zp1 = ctx->plan.zbuffer_params[1];
+        MEAO_HIP(ctx, launch_linear_depth(la, s));
+        *out_src = ctx->atlas_scratch;
+    } else if (debug_id <= 5) *out_src = slot + ctx->off_low_of(ctx->ds_cur, debug_id - 2);
     else if (debug_id <= 9) {
         // TiledDepth<level>: materialised on demand from LowDepth<level> (the hot path samples
         // LowDepth directly and never builds the de-interleaved arrays).
         const int level = debug_id - 5;
-        if (ctx->atlas_scratch_bytes < d.bytes) {
-            if (ctx->atlas_scratch) (void)hipFree(ctx->atlas_scratch);
-            ctx->atlas_scratch = nullptr;
-            ctx->atlas_scratch_bytes = 0;
-            MEAO_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->atlas_scratch), d.bytes));
-            ctx->atlas_scratch_bytes = d.bytes;
-        }
+        const int rc = reserve_scratch(ctx, d.bytes);
+        if (rc != MEAO_OK) return rc;
         TileAtlasArgs ta{};
         ta.src = reinterpret_cast<const float *>(slot + ctx->off_low_of(ctx->ds_cur, level - 1));
         ta.dst = reinterpret_cast<uint16_t *>(ctx->atlas_scratch);
@@ -1293,6 +1155,9 @@ int32_t meao_get_pass_times(meao_ctx *ctx, float ms[MEAO_NUM_PASSES], int32_t *o
     if (!ctx || !ms) return MEAO_ERR_INVALID_ARGUMENT;
     int rc = use_device(ctx);
     if (rc != MEAO_OK) return rc;
+    // the documented contract: the call returns after the stream of the last execute has drained (executes that recorded no
+    // events -- meao_set_profiling(N > 1), PROFILE_PASS_MASK -- included; the timing events themselves carry no fence)
+    MEAO_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
     fold_profile(ctx);
     // mean over the executes that actually ran the pass (a prefetched downsample does not dilute it)
     for (int k = 0; k < MEAO_NUM_PASSES; ++k)
@@ -1434,38 +1299,12 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_RENDER_SMALL_MAX_TILES: ctx->render_small_max_tiles = value; break;
     case MEAO_DEBUG_FINAL_SMALL_MAX_TILES: ctx->final_small_max_tiles = value; break;
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
-    case MEAO_DEBUG_RENDER_FROM_DEPTH:
-        if (value < 0 || value > 3) return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: RENDER_FROM_DEPTH is 0..3");
-        ctx->render_from_depth = value;
-        break;
-    case MEAO_DEBUG_RENDER_FROM_DEPTH_MAX_TILES: ctx->render_from_depth_max_tiles = value; break;
     case MEAO_DEBUG_PROFILE_PASS_MASK: ctx->profile_mask = value == 0 ? ~0u : static_cast<uint32_t>(value); break;
     case MEAO_DEBUG_BLEND_TALL_MIN_TILES:
         ctx->blend_tall_min_tiles = value <= 0 ? 0x7fffffff : value;
         ctx->blend_tall_forced = true;
         break;
-    case MEAO_DEBUG_DS_SHARE_IN_BLEND: ctx->ds_share_in_blend = value < 0 ? 0 : (value > 100 ? 100 : value); break;
-    case MEAO_DEBUG_DS_SIDE_STREAM:
-        if (value < 0 || value % 10 > 4 || (value > 0 && value % 10 == 0) || value / 10 % 10 > 4 || value / 100 % 10 > 2 || value / 10000 % 10 > 4 || value >= 100000)
-            return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: DS_SIDE_STREAM value");
-        if (ctx->side_stream && value / 100 % 10 != ctx->ds_side_stream / 100 % 10) {       // the stream's priority is fixed at creation
-            const int rc = use_device(ctx);
-            if (rc != MEAO_OK) return rc;
-            (void)hipStreamSynchronize(ctx->side_stream);
-            (void)hipStreamDestroy(ctx->side_stream);
-            (void)hipEventDestroy(ctx->side_gate);
-            (void)hipEventDestroy(ctx->side_done);
-            ctx->side_stream = nullptr; ctx->side_gate = ctx->side_done = nullptr;
-            ctx->side_pending = false;
-        }
-        ctx->ds_side_stream = value;
-        break;
     default: return fail(ctx, MEAO_ERR_INVALID_ARGUMENT, "meao_debug_set: unknown key");
-    }
-    if (!ctx->graphs.empty()) {      // captured sequences embed the launch structure
-        const int rc = use_device(ctx);
-        if (rc != MEAO_OK) return rc;
-        drop_graphs(ctx);
     }
     return MEAO_OK;
 }

@@ -250,8 +250,7 @@ __device__ __forceinline__ T *at_byte_offset(T *uniform_base, uint32_t byte_offs
 // and are re-verified on the running device by meao_selftest(4..6).  The host selects this mode
 // only when the operands are provably inside those ranges (RTZ depth storage, so no inf from sky
 // texels; tolerances inside the component's ranges), otherwise DIV_IEEE (hipcc's expansion).
-// DIV_FAST (MEAO_NUMERICS_FAST, not bit-exact): the raw 1-ulp v_rcp_f32 without correction steps.
-enum { DIV_EXACT_RCP = 0, DIV_IEEE = 1, DIV_FAST = 2 };
+enum { DIV_EXACT_RCP = 0, DIV_IEEE = 1 };
 
 template <int DIV>
 __device__ __forceinline__ float rcp_strict(float x)
@@ -260,8 +259,6 @@ __device__ __forceinline__ float rcp_strict(float x)
         const float r = __builtin_amdgcn_rcpf(x);
         const float e = mad(-x, r, 1.0f);
         return mad(e, r, r);
-    } else if constexpr (DIV == DIV_FAST) {
-        return __builtin_amdgcn_rcpf(x);
     } else {
         return 1.0f / x;
     }
@@ -276,8 +273,6 @@ __device__ __forceinline__ float div_const(float x, float k_value = static_cast<
         const float q = k_value * r;
         const float e = mad(-x, q, k_value);
         return mad(e, r, q);
-    } else if constexpr (DIV == DIV_FAST) {
-        return static_cast<float>(K) * __builtin_amdgcn_rcpf(x);
     } else {
         return static_cast<float>(K) / x;
     }
@@ -291,8 +286,6 @@ __device__ __forceinline__ float div_strict(float a, float b)
         const float q = a * r;
         const float e = mad(-b, q, a);
         return mad(e, r, q);
-    } else if constexpr (DIV == DIV_FAST) {
-        return a * __builtin_amdgcn_rcpf(b);
     } else {
         return a / b;
     }

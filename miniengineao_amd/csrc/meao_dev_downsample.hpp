@@ -1,5 +1,5 @@
-// meao_dev_downsample.hpp -- the downsample tile (Downsample1.main + Downsample2.main fused): generic and lean forms, used by the
-// downsample kernels and by the upsample / render kernels that carry a downsample tile.
+// meao_dev_downsample.hpp -- Linearize and the downsample tile (Downsample1.main + Downsample2.main fused): the generic form of the
+// stand-alone pass and the lean form the last upsample kernel of a pipelined call carries.
 #pragma once
 
 #include "meao_dev.hpp"
@@ -8,16 +8,13 @@ namespace meao {
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// Downsample: linearize + point-downsample to L1..L4.   Tile 128 x 32 full-res texels.
+// Downsample: linearize + point-downsample to L1..L4.
 //
-// Closed form of DS1+DS2: LinearZ = lin(x,y); DS2x[i,j] = lin(2i,2j);
-// DS4x = lin(4i,4j); DS8x = lin(8i,8j); DS16x = lin(16i,16j) -- every level keeps the
-// top-left texel of its block, so a lane decides what to store from its own coordinates and
-// no LDS exchange is needed.
-
-// The pass is pure streaming: its loads and its two big stores are non-temporal, so that the lines
-// do not displace what the upsample tiles sharing the kernel (meao_prefetch_batch) re-read from L2
-// (A/B: 344 -> 339 us for the fused kernel, no change stand-alone).
+// Closed form of DS1+DS2: LinearZ = lin(x,y); DS2x[i,j] = lin(2i,2j); DS4x = lin(4i,4j); DS8x = lin(8i,8j);
+// DS16x = lin(16i,16j) -- every level keeps the top-left texel of its block, so a lane decides what to store from its own
+// coordinates and no LDS exchange is needed.  Since round 6 LinearZ is not stored: its only reader, HiResDB of Upsample.main
+// (UPS:217-223), evaluates lin(x,y) itself (meao_dev_upsample.hpp, hi_depth_quad), so the pass touches the EVEN rows of the frame
+// only -- 27.6 MB per 4K frame instead of 60.8 -- and the 16.6 MB of LinearZ are neither written nor read back.
 
 template <int DIV>
 __device__ __forceinline__ float linearize(float depth, float zp0, float zp1, float sky_depth)
@@ -32,124 +29,109 @@ __device__ __forceinline__ float linearize(float depth, float zp0, float zp1, fl
 // "Nice" depth: the denominator of Linearize lies in [2^-20, 2^24], i.e. the linear depth is a
 // normal number in [2^-24, 2^20] (non-zero after the f16 store, finite, not NaN).  Every exact
 // v_rcp_f32 sequence downstream (centre depth, 1 / LoResDB, the bilateral weights, the final
-// quotient) has its operands inside its verified range when all texels of a frame are nice.  A frame
-// with any other texel -- NaN, +-inf, negative, > 1 with a conventional Z buffer, depths below
+// quotient) has its operands inside its verified range when all texels it consumes are nice.  A frame
+// whose LEVELS hold any other texel -- NaN, +-inf, negative, > 1 with a conventional Z buffer, depths below
 // 2^-24 -- is marked hostile by the downsample pass and takes the IEEE-division bodies of the later
 // kernels (the reference divides with IEEE '/', Downsample1.compute:37-48; inputs are never sanitised).
+// Texels that only the full-resolution pass sees (odd rows / columns) are tested there, per lane.
 __device__ __forceinline__ bool nice_denominator(float den)
 {
     return __builtin_amdgcn_fmed3f(den, 0x1p-20f, 0x1p24f) == den;   // false for NaN
 }
 
-// First half of a downsample tile: the raw depth texels of this lane, 4 per row in each of the 4 row passes.
-// F32_ONLY: the caller has established a.depth_format == MEAO_DEPTH_F32 (no format switch in the code).
-// PASSES row passes of kDsRowsPerPass rows: 4 = the 32-row tile, 1 = the 8-row tile of small calls.
-// CLAMP_ROWS (f32, 16-byte loads): rows past the frame re-read its last row instead of being skipped, so that every load
-// is unconditional and the one wait for them sits in front of the finish loop, not inside its first row's branch (at the
-// join behind that branch the compiler otherwise waits with vmcnt(0) for the first row's STORES as well).
-template <bool VEC, bool F32_ONLY = false, int PASSES = kDsTileH / kDsRowsPerPass, bool CLAMP_ROWS = false>
-__device__ __forceinline__ void downsample_tile_load(const DownsampleArgs &a, int tile, int frame,
-                                                     float (&v)[PASSES][4], const unsigned tid = threadIdx.x)
+// The same for four denominators at once: two unsigned min / max chains on their bit patterns (negative values and NaNs are
+// the largest unsigned words) instead of four v_med3 + four compares.
+__device__ __forceinline__ bool nice_denominators(float d0, float d1, float d2, float d3)
 {
-    const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-    const void *__restrict__ depth = a.depth[frame];
-    const int W = a.w[0], H = a.h[0];
-    const int x0 = tile_x * kDsTileW + (tid % kDsLanesPerRow) * 4;
-    const int yb = tile_y * (PASSES * kDsRowsPerPass) + (tid / kDsLanesPerRow);
-    if (x0 >= W) return;
+    const uint32_t b0 = __builtin_bit_cast(uint32_t, d0), b1 = __builtin_bit_cast(uint32_t, d1);
+    const uint32_t b2 = __builtin_bit_cast(uint32_t, d2), b3 = __builtin_bit_cast(uint32_t, d3);
+    const uint32_t lo = min(min(min(b0, b1), b2), b3), hi = max(max(max(b0, b1), b2), b3);
+    return lo >= 0x35800000u && hi <= 0x4B800000u;
+}
 
-    // The depth-copy blit of the reference (Blit.shader pass 0) is folded into this load: the
-    // texel format is decoded here (wave-uniform switch), 4 texels per lane per row.
-    if constexpr (CLAMP_ROWS) {
-        static_assert(VEC && F32_ONLY, "the clamped form is the 16-byte f32 one");
-#pragma unroll
-        for (int k = 0; k < PASSES; ++k) {
-            const int y = min(yb + k * kDsRowsPerPass, H - 1);
-            const float4v q = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(static_cast<const float *>(depth) + static_cast<size_t>(y) * W + x0));
-            v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
-        }
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-        const int y = yb + k * kDsRowsPerPass;
-        v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.5f;
-        if (y < H) {
-            const size_t at = static_cast<size_t>(y) * W + x0;
-            if (F32_ONLY || a.depth_format == MEAO_DEPTH_F32) {
-                const float *row = static_cast<const float *>(depth) + at;
-                if constexpr (VEC) {
-                    const float4v q = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(row));
-                    v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (x0 + e < W) v[k][e] = row[e];
-                }
-            } else if (a.depth_format == MEAO_DEPTH_UNORM24) {
-                const uint32_t *row = static_cast<const uint32_t *>(depth) + at;
-                uint32_t u[4] = {0, 0, 0, 0};
-                if constexpr (VEC) {
-                    const uint4v q = *reinterpret_cast<const uint4v *>(row);
-                    u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (x0 + e < W) u[e] = row[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[k][e] = unorm_to_f32<24>(u[e] & 0xffffffu);
-            } else {   // 16-bit texels: UNORM16 or F16
-                const uint16_t *row = static_cast<const uint16_t *>(depth) + at;
-                uint16_t u[4] = {0, 0, 0, 0};
-                if constexpr (VEC) {
-                    const ushort4v q = *reinterpret_cast<const ushort4v *>(row);
-                    u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (x0 + e < W) u[e] = row[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[k][e] = a.depth_format == MEAO_DEPTH_UNORM16 ? unorm_to_f32<16>(u[e]) : f16_bits_to_f32(u[e]);
-            }
+// One raw depth texel of any meao_depth_format (the depth-copy blit of the reference, Blit.shader pass 0, folded into the load).
+__device__ __forceinline__ float raw_depth_texel(const void *depth, int format, size_t at)
+{
+    if (format == MEAO_DEPTH_F32) return static_cast<const float *>(depth)[at];
+    if (format == MEAO_DEPTH_UNORM24) return unorm_to_f32<24>(static_cast<const uint32_t *>(depth)[at] & 0xffffffu);
+    const uint16_t u = static_cast<const uint16_t *>(depth)[at];
+    return format == MEAO_DEPTH_UNORM16 ? unorm_to_f32<16>(u) : f16_bits_to_f32(u);
+}
+
+// Four consecutive raw texels from an address aligned to four texels, decoded (wave-uniform switch on the format).
+__device__ __forceinline__ void raw_depth_quad(const void *depth, int format, size_t at, float (&v)[4], bool non_temporal)
+{
+    if (format == MEAO_DEPTH_F32) {
+        const float4v *p = reinterpret_cast<const float4v *>(static_cast<const float *>(depth) + at);
+        const float4v q = non_temporal ? __builtin_nontemporal_load(p) : *p;
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else if (format == MEAO_DEPTH_UNORM24) {
+        const uint4v q = *reinterpret_cast<const uint4v *>(static_cast<const uint32_t *>(depth) + at);
+        v[0] = unorm_to_f32<24>(q.x & 0xffffffu); v[1] = unorm_to_f32<24>(q.y & 0xffffffu);
+        v[2] = unorm_to_f32<24>(q.z & 0xffffffu); v[3] = unorm_to_f32<24>(q.w & 0xffffffu);
+    } else {
+        const ushort4v q = *reinterpret_cast<const ushort4v *>(static_cast<const uint16_t *>(depth) + at);
+        if (format == MEAO_DEPTH_UNORM16) {
+            v[0] = unorm_to_f32<16>(q.x); v[1] = unorm_to_f32<16>(q.y); v[2] = unorm_to_f32<16>(q.z); v[3] = unorm_to_f32<16>(q.w);
+        } else {
+            v[0] = f16_bits_to_f32(q.x); v[1] = f16_bits_to_f32(q.y); v[2] = f16_bits_to_f32(q.z); v[3] = f16_bits_to_f32(q.w);
         }
     }
 }
 
-// Second half: linearize, store LinearZ and the four point-sampled levels.
-template <bool RTNE, bool VEC, int DIV, int PASSES = kDsTileH / kDsRowsPerPass>
-__device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, int tile, int frame,
-                                                       const float (&v)[PASSES][4], const unsigned tid = threadIdx.x)
+// ------------------------------------------------------------------------------------------
+// The generic tile (stand-alone pass; every depth format, any width): kMipTileW x (8 * ROWS) texels of LowDepth1.  A lane takes
+// 4 consecutive LowDepth1 texels -- raw texels 2j, 2j+2, 2j+4, 2j+6 of raw row 2i -- in each of its ROWS rows (i, i + 8, ...):
+// with 16-byte loads two per row, all of them in flight before the first is used.
+// VEC: W % 8 == 0 and every frame aligned to 4 texels.
+template <bool VEC, int DIV, int ROWS>
+__device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int tile, int frame)
 {
+    const unsigned tid = threadIdx.x;
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-    uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
+    const int j0 = tile_x * kMipTileW + static_cast<int>(tid % kMipLanesPerRow) * 4;     // LowDepth1 column of the lane's first texel
+    const int ib = tile_y * (kMipRowsPerPass * ROWS) + static_cast<int>(tid / kMipLanesPerRow);
+    const int W = a.w[0], w1 = a.w[1], h1 = a.h[1];
+    if (j0 >= w1) return;
+    const void *__restrict__ depth = a.depth[frame];
+    const int format = a.depth_format;
+    float v[ROWS][4];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int i = ib + kMipRowsPerPass * k;
+        v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.5f;
+        if (i < h1) {
+            const size_t at = static_cast<size_t>(2 * i) * W + 2 * j0;
+            if constexpr (VEC) {
+                float q0[4], q1[4];
+                raw_depth_quad(depth, format, at, q0, true);
+                raw_depth_quad(depth, format, at + 4, q1, true);
+                v[k][0] = q0[0]; v[k][1] = q0[2]; v[k][2] = q1[0]; v[k][3] = q1[2];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j0 + e < w1) v[k][e] = raw_depth_texel(depth, format, at + 2 * e);
+            }
+        }
+    }
     float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
     float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
     float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
     float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
-    const int W = a.w[0], H = a.h[0];
     const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
-    const int x0 = tile_x * kDsTileW + (tid % kDsLanesPerRow) * 4;
-    const int yb = tile_y * (PASSES * kDsRowsPerPass) + (tid / kDsLanesPerRow);
-    if (x0 >= W) return;
     const float zp0 = a.zp0, zp1 = a.zp1;
 #pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-        const int y = yb + k * kDsRowsPerPass;
-        if (y >= H) continue;
+    for (int k = 0; k < ROWS; ++k) {
+        const int i = ib + kMipRowsPerPass * k;
+        if (i >= h1) continue;
         float lin[4];
         if constexpr (DIV == DIV_EXACT_RCP) {
             // the exact reciprocal sequence is only valid for a "nice" denominator; anything else
             // (hostile input) is divided with IEEE '/' and marks the frame for the later kernels
-            bool nice = true;
+            if (__builtin_expect(nice_denominators(mad(zp0, v[k][0], zp1), mad(zp0, v[k][1], zp1), mad(zp0, v[k][2], zp1), mad(zp0, v[k][3], zp1)), 1)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                nice = nice && nice_denominator(mad(zp0, v[k][e], zp1));
-                lin[e] = linearize<DIV_EXACT_RCP>(v[k][e], zp0, zp1, sky_depth);
-            }
-            if (__builtin_expect(!nice, 0)) {
+                for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_EXACT_RCP>(v[k][e], zp0, zp1, sky_depth);
+            } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[k][e], zp0, zp1, sky_depth);
                 a.hostile[frame] = a.generation;     // racing stores of the same value
@@ -158,176 +140,118 @@ __device__ __forceinline__ void downsample_tile_finish(const DownsampleArgs &a, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[k][e], zp0, zp1, sky_depth);
         }
-
-        uint16_t *lrow = linear + static_cast<size_t>(y) * W + x0;    // LinearZ[st] = dist (DS1:46)
+        float *p1 = low1 + static_cast<size_t>(i) * w1 + j0;                          // DS2x (DS1:64-70)
         if constexpr (VEC) {
-            ushort4v h;
-            h.x = f32_to_f16_bits<RTNE>(lin[0]); h.y = f32_to_f16_bits<RTNE>(lin[1]);
-            h.z = f32_to_f16_bits<RTNE>(lin[2]); h.w = f32_to_f16_bits<RTNE>(lin[3]);
-            __builtin_nontemporal_store(h, reinterpret_cast<ushort4v *>(lrow));
+            __builtin_nontemporal_store(float4v{lin[0], lin[1], lin[2], lin[3]}, reinterpret_cast<float4v *>(p1));
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (x0 + e < W) lrow[e] = f32_to_f16_bits<RTNE>(lin[e]);
+                if (j0 + e < w1) p1[e] = lin[e];
         }
-        if ((y & 1) == 0) {                                           // DS2x (DS1:64-70)
-            float *p = low1 + static_cast<size_t>(y >> 1) * a.w[1] + (x0 >> 1);
-            if constexpr (VEC) {
-                __builtin_nontemporal_store(float2v{lin[0], lin[2]}, reinterpret_cast<float2v *>(p));
-            } else {
-                p[0] = lin[0];
-                if (x0 + 2 < W) p[1] = lin[2];
-            }
-            if ((y & 3) == 0) {                                       // DS4x (DS1:73-77)
-                low2[static_cast<size_t>(y >> 2) * a.w[2] + (x0 >> 2)] = lin[0];
-                if ((y & 7) == 0 && (x0 & 7) == 0) {                  // DS8x (DS2:35-40)
-                    low3[static_cast<size_t>(y >> 3) * a.w[3] + (x0 >> 3)] = lin[0];
-                    if ((y & 15) == 0 && (x0 & 15) == 0)              // DS16x (DS2:43-49)
-                        low4[static_cast<size_t>(y >> 4) * a.w[4] + (x0 >> 4)] = lin[0];
-                }
+        if ((i & 1) == 0) {                                                           // DS4x (DS1:73-77)
+            float *p2 = low2 + static_cast<size_t>(i >> 1) * a.w[2] + (j0 >> 1);
+            p2[0] = lin[0];
+            if (j0 + 2 < w1) p2[1] = lin[2];
+            if ((i & 3) == 0) {                                                       // DS8x (DS2:35-40)
+                low3[static_cast<size_t>(i >> 2) * a.w[3] + (j0 >> 2)] = lin[0];
+                if ((i & 7) == 0 && (j0 & 7) == 0)                                    // DS16x (DS2:43-49)
+                    low4[static_cast<size_t>(i >> 3) * a.w[4] + (j0 >> 3)] = lin[0];
             }
         }
     }
 }
 
-template <bool RTNE, bool VEC, int DIV, int PASSES = kDsTileH / kDsRowsPerPass>
-__device__ __forceinline__ void downsample_tile(const DownsampleArgs &a, int tile, int frame, const unsigned tid = threadIdx.x)
-{
-    // tid: the lane's index inside the 256-lane tile (workgroups of 512 threads process two tiles, meao_k_render_depth.hip)
-    float v[PASSES][4];
-    downsample_tile_load<VEC, false, PASSES>(a, tile, frame, v, tid);
-    downsample_tile_finish<RTNE, VEC, DIV, PASSES>(a, tile, frame, v, tid);
-}
-
-// The pass as a CO-RUNNER of the VALU-bound launches (meao_debug_set MEAO_DEBUG_DS_SIDE_STREAM): its own kernel on a second,
-// low-priority stream.  Two things differ from the stand-alone pass, which waits on memory and does not care:
-//  * a co-resident workgroup gets its memory-level parallelism from a deep per-lane queue (PASSES 16-byte loads in flight:
-//    a 128 x 8*PASSES tile) instead of from occupancy -- the launches it runs next to leave it one wave slot per SIMD;
-//  * its VALU instructions are taken from kernels that are bound by VALU issue, so there are as few as possible: ~8 per texel
-//    instead of ~18.  Rows are dealt to waves so that a row's parity is wave-uniform (wave w: rows w and w + 4 of every
-//    8-row pass): the waves of odd rows skip the mip stores with a scalar branch, only wave 0 ever sees L2..L4; the range
-//    test of the four denominators is two unsigned min / max chains on their bit patterns (negative values and NaNs are the
-//    largest unsigned words) instead of four v_med3 + four compares; the far-plane select runs only where a lane holds a
-//    far-plane texel; one 32-bit byte offset per buffer, advanced by a uniform stride per row pass (saddr addressing).
-// Same bits as downsample_tile (tests/test_gpu_more.py::test_next_downsample_on_the_side_stream, hostile frames included).
-// PAD_VGPRS: the kernel declares 120 VGPRs whatever it uses, so that exactly one of its workgroups fits next to seven
-// upsample workgroups and the registers a finishing upsample workgroup frees (56) can only go to the next upsample one.
-// lane geometry of the lean tile: rows w and w + 4 of every 8-row pass for wave w (a row's parity is wave-uniform)
-struct LeanDsLane {
-    int wave, row, y0;
-    uint32_t x0;
-    __device__ __forceinline__ LeanDsLane(const DownsampleArgs &a, int tile, int passes)
+// ------------------------------------------------------------------------------------------
+// The lean tile: what the last upsample kernel of a pipelined call carries for the NEXT batch (meao_prefetch_batch).  f32 depth,
+// W % 8 == 0, 16-byte aligned frames.  64 x 16 texels of LowDepth1 (the even rows of 128 x 32 raw texels) = one tile per 64 x 64
+// upsample tile at the usual frame sizes (1080p: 510 of either, 4K: 2 040, 8K: 8 160): a lane holds two 16-byte loads (8 VGPRs)
+// across the bilateral phase of its upsample tile.  Its VALU instructions are taken from a kernel that also has arithmetic to
+// do, so there are as few as possible: rows are dealt to waves so that a row's residue mod 4 is wave-uniform (wave w: rows w,
+// w + 4, w + 8, w + 12) -- the waves of odd rows skip the coarser levels with a scalar branch, only wave 0 ever sees L3 and L4;
+// the range test is nice_denominators; the far-plane select runs only where a lane holds a far-plane texel; one 32-bit byte
+// offset per buffer (saddr addressing).  Same bits as downsample_tile.
+constexpr int kLeanW = kLeanMipW, kLeanRows = kLeanMipRows;
+struct LeanMipLane {
+    int wave, row, i;            // i: LowDepth1 row
+    uint32_t j0;                 // LowDepth1 column of the lane's first texel
+    __device__ __forceinline__ LeanMipLane(const DownsampleArgs &a, int tile)
     {
         const uint32_t tid = threadIdx.x;
         wave = __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6));
         const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-        x0 = static_cast<uint32_t>(tile_x) * kDsTileW + (tid & 31u) * 4u;
-        row = wave + 4 * static_cast<int>((tid >> 5) & 1u);
-        y0 = tile_y * (passes * kDsRowsPerPass) + row;
+        j0 = static_cast<uint32_t>(tile_x) * kLeanW + (tid & 15u) * 4u;
+        row = wave + 4 * static_cast<int>((tid >> 4) & 3u);
+        i = tile_y * kLeanRows + row;
     }
 };
 
-// FULL: every row of the tile is inside the frame (otherwise rows past it re-read its last row and are never used)
-template <int PASSES, bool FULL>
-__device__ __forceinline__ void downsample_lean_load(const DownsampleArgs &a, int tile, int frame, float4v (&q)[PASSES])
+// FULL: every row of the tile is inside the level (otherwise rows past it re-read its last row and are never used)
+template <bool FULL>
+__device__ __forceinline__ void downsample_lean_load(const DownsampleArgs &a, int tile, int frame, float4v (&q)[2])
 {
-    const LeanDsLane L(a, tile, PASSES);
+    const LeanMipLane L(a, tile);
     const uint32_t W = static_cast<uint32_t>(a.w[0]);
-    if (L.x0 >= W) return;
+    if (L.j0 >= static_cast<uint32_t>(a.w[1])) return;
     const float *__restrict__ depth = static_cast<const float *>(a.depth[frame]);
-    const uint32_t t0 = static_cast<uint32_t>(L.y0) * W + L.x0, t_step = 8u * W;       // texel index of (x0, y0 + 8k) is t0 + k * 8W
-#pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-        uint32_t t = t0 + static_cast<uint32_t>(k) * t_step;
-        if constexpr (!FULL) t = static_cast<uint32_t>(min(L.y0 + 8 * k, a.h[0] - 1)) * W + L.x0;
-        q[k] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(depth, t * 4u)));
-    }
+    const int i = FULL ? L.i : min(L.i, a.h[1] - 1);
+    const uint32_t t = static_cast<uint32_t>(2 * i) * W + 2u * L.j0;       // texel index in the frame (< 2^30)
+    q[0] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(depth, t * 4u)));
+    q[1] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(at_byte_offset(depth, t * 4u + 16u)));
 }
 
-template <bool RTNE, int DIV, int PASSES, bool FULL>
-__device__ __forceinline__ void downsample_lean_finish(const DownsampleArgs &a, int tile, int frame, const float4v (&q)[PASSES])
+template <int DIV, bool FULL>
+__device__ __forceinline__ void downsample_lean_finish(const DownsampleArgs &a, int tile, int frame, const float4v (&q)[2])
 {
-    const LeanDsLane L(a, tile, PASSES);
-    const int wave = L.wave, row = L.row, y0 = L.y0;
-    const uint32_t x0 = L.x0, W = static_cast<uint32_t>(a.w[0]);
-    const int H = a.h[0];
-    if (x0 >= W) return;
-    uint16_t *__restrict__ linear = frame_ptr(a.linear, a.frame_stride, frame);
+    const LeanMipLane L(a, tile);
+    const int wave = L.wave, row = L.row, i = L.i;
+    const uint32_t j0 = L.j0, w1 = static_cast<uint32_t>(a.w[1]);
+    if (j0 >= w1) return;
+    if constexpr (!FULL) { if (i >= a.h[1]) return; }
     float *__restrict__ low1 = frame_ptr(a.low[0], a.frame_stride, frame);
     float *__restrict__ low2 = frame_ptr(a.low[1], a.frame_stride, frame);
     float *__restrict__ low3 = frame_ptr(a.low[2], a.frame_stride, frame);
     float *__restrict__ low4 = frame_ptr(a.low[3], a.frame_stride, frame);
     const float zp0 = a.zp0, zp1 = a.zp1;
     const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
-    const uint32_t w1 = a.w[1], w2 = a.w[2], w3 = a.w[3], w4 = a.w[4];
-    const uint32_t t0 = static_cast<uint32_t>(y0) * W + x0, t_step = 8u * W;
-    const uint32_t o1 = (static_cast<uint32_t>(y0 >> 1) * w1 + (x0 >> 1)) * 4u, o2 = (static_cast<uint32_t>(y0 >> 2) * w2 + (x0 >> 2)) * 4u;
-    const uint32_t o3 = (static_cast<uint32_t>(y0 >> 3) * w3 + (x0 >> 3)) * 4u, o4 = (static_cast<uint32_t>(y0 >> 4) * w4 + (x0 >> 4)) * 4u;
+    const float v[4] = {q[0].x, q[0].z, q[1].x, q[1].z};
+    float lin[4];
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        float den[4];
 #pragma unroll
-    for (int k = 0; k < PASSES; ++k) {
-        if constexpr (!FULL) { if (y0 + 8 * k >= H) break; }
-        const float v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-        float lin[4];
-        if constexpr (DIV == DIV_EXACT_RCP) {
-            float den[4];
-            uint32_t bits[4];
+        for (int e = 0; e < 4; ++e) den[e] = mad(zp0, v[e], zp1);
+        if (__builtin_expect(nice_denominators(den[0], den[1], den[2], den[3]), 1)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { den[e] = mad(zp0, v[e], zp1); bits[e] = __builtin_bit_cast(uint32_t, den[e]); }
-            // all four denominators in [2^-20, 2^24] (nice_denominator): as unsigned words, negative values and NaNs are the largest
-            const uint32_t lo = min(min(min(bits[0], bits[1]), bits[2]), bits[3]), hi = max(max(max(bits[0], bits[1]), bits[2]), bits[3]);
-            if (__builtin_expect(lo >= 0x35800000u && hi <= 0x4B800000u, 1)) {
+            for (int e = 0; e < 4; ++e) {
+                const float r = __builtin_amdgcn_rcpf(den[e]);
+                lin[e] = mad(mad(-den[e], r, 1.0f), r, r);                  // rcp_strict: DS1:40
+            }
+            const bool far = (v[0] == sky_depth) | (v[1] == sky_depth) | (v[2] == sky_depth) | (v[3] == sky_depth);
+            if (__builtin_expect(far, 0)) {                                 // DS1:41-45
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float r = __builtin_amdgcn_rcpf(den[e]);
-                    lin[e] = mad(mad(-den[e], r, 1.0f), r, r);                  // rcp_strict: DS1:40
-                }
-                const bool far = (v[0] == sky_depth) | (v[1] == sky_depth) | (v[2] == sky_depth) | (v[3] == sky_depth);
-                if (__builtin_expect(far, 0)) {                                 // DS1:41-45
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lin[e] = v[e] == sky_depth ? 1e5f : lin[e];
-                    asm volatile("" : "+v"(lin[0]), "+v"(lin[1]), "+v"(lin[2]), "+v"(lin[3]));   // stays a branch: rare lanes only
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[e], zp0, zp1, sky_depth);
-                a.hostile[frame] = a.generation;     // racing stores of the same value
+                for (int e = 0; e < 4; ++e) lin[e] = v[e] == sky_depth ? 1e5f : lin[e];
+                asm volatile("" : "+v"(lin[0]), "+v"(lin[1]), "+v"(lin[2]), "+v"(lin[3]));   // stays a branch: rare lanes only
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[e], zp0, zp1, sky_depth);
+            for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(v[e], zp0, zp1, sky_depth);
+            a.hostile[frame] = a.generation;     // racing stores of the same value
         }
-        const uint32_t t = t0 + static_cast<uint32_t>(k) * t_step;
-        typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
-        uint2v h;                                                                // LinearZ[st] = dist (DS1:46)
-        if constexpr (RTNE) {
-            h.x = f32_to_f16_bits<true>(lin[0]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[1])) << 16);
-            h.y = f32_to_f16_bits<true>(lin[2]) | (static_cast<uint32_t>(f32_to_f16_bits<true>(lin[3])) << 16);
-        } else {
-            h.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[0], lin[1]));
-            h.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lin[2], lin[3]));
-        }
-        __builtin_nontemporal_store(h, reinterpret_cast<uint2v *>(at_byte_offset(linear, t * 2u)));
-        if ((wave & 1) == 0) {                                                   // even rows (wave-uniform): DS2x (DS1:64-70)
-            __builtin_nontemporal_store(float2v{lin[0], lin[2]},
-                                        reinterpret_cast<float2v *>(at_byte_offset(low1, o1 + static_cast<uint32_t>(k) * (16u * w1))));
-            if (wave == 0) {                                                     // rows 0, 4 of the pass: DS4x (DS1:73-77)
-                *at_byte_offset(low2, o2 + static_cast<uint32_t>(k) * (8u * w2)) = lin[0];
-                if (row == 0 && (x0 & 7u) == 0) {                                // DS8x (DS2:35-40)
-                    *at_byte_offset(low3, o3 + static_cast<uint32_t>(k) * (4u * w3)) = lin[0];
-                    if ((k & 1) == 0 && (x0 & 15u) == 0)                         // DS16x (DS2:43-49)
-                        *at_byte_offset(low4, o4 + static_cast<uint32_t>(k / 2) * (4u * w4)) = lin[0];
-                }
-            }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(v[e], zp0, zp1, sky_depth);
+    }
+    const uint32_t ui = static_cast<uint32_t>(i);
+    __builtin_nontemporal_store(float4v{lin[0], lin[1], lin[2], lin[3]},                              // DS2x (DS1:64-70)
+                                reinterpret_cast<float4v *>(at_byte_offset(low1, (ui * w1 + j0) * 4u)));
+    if ((wave & 1) == 0) {                                                   // even rows (wave-uniform): DS4x (DS1:73-77)
+        __builtin_nontemporal_store(float2v{lin[0], lin[2]}, reinterpret_cast<float2v *>(at_byte_offset(
+                                        low2, ((ui >> 1) * static_cast<uint32_t>(a.w[2]) + (j0 >> 1)) * 4u)));
+        if (wave == 0) {                                                     // rows 0, 4, 8, 12 of the tile: DS8x (DS2:35-40)
+            *at_byte_offset(low3, ((ui >> 2) * static_cast<uint32_t>(a.w[3]) + (j0 >> 2)) * 4u) = lin[0];
+            if ((row & 7) == 0 && (j0 & 7u) == 0)                            // DS16x (DS2:43-49)
+                *at_byte_offset(low4, ((ui >> 3) * static_cast<uint32_t>(a.w[4]) + (j0 >> 3)) * 4u) = lin[0];
         }
     }
-}
-
-template <bool RTNE, int DIV, int PASSES, bool FULL>
-__device__ __forceinline__ void downsample_side_tile(const DownsampleArgs &a, int tile, int frame)
-{
-    float4v q[PASSES];
-    downsample_lean_load<PASSES, FULL>(a, tile, frame, q);
-    downsample_lean_finish<RTNE, DIV, PASSES, FULL>(a, tile, frame, q);
 }
 
 

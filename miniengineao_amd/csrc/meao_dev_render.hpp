@@ -2,7 +2,6 @@
 #pragma once
 
 #include "meao_dev.hpp"
-#include "meao_dev_downsample.hpp"      // linearize, nice_denominator (render_tile<FROM_DEPTH>)
 
 namespace meao {
 namespace {
@@ -229,18 +228,8 @@ struct NoRenderHook {
     __device__ __forceinline__ void end(int) {}
 };
 
-// FROM_DEPTH (one frame per call, meao_k_render_depth.hip): the window is filled from the caller's RAW depth buffer instead of
-// LowDepth<level>.  LowDepth_k[i, j] is Linearize(depth[2^k i, 2^k j]) (DS1:37-78, DS2:35-50: every level keeps the top-left
-// texel of its block), a pure function of the input, so a tile can evaluate it itself -- the same reciprocal sequence, the
-// same f16 round trip, the same padding rule, hence the same bits -- and the render launch no longer waits for the
-// downsample launch.  What the frame's hostile flag decides in the stored-mip form (IEEE division for the whole frame) is
-// decided per texel here: a denominator outside [2^-20, 2^24] is divided with IEEE '/' as the downsample pass does, and a
-// centre depth the exact reciprocal is not verified for (0 or NaN after the f16 round trip) likewise.  Exact sequences and
-// IEEE '/' agree wherever the former are valid, so every mixture gives the reference's bits.
-template <int AOFMT, bool RTNE, int DIV, bool EXH, typename Hook = NoRenderHook, int TILE_H = kRenTileH, int THREADS = ren_tile_w(EXH) * 4,
-          bool FROM_DEPTH = false>
-__device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, int frame, int block, Hook hook = Hook(),
-                                            const DownsampleArgs *raw = nullptr)
+template <int AOFMT, bool RTNE, int DIV, bool EXH, typename Hook = NoRenderHook, int TILE_H = kRenTileH, int THREADS = ren_tile_w(EXH) * 4>
+__device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, int frame, int block, Hook hook = Hook())
 {
     typedef AoTexel<AOFMT> AO;
     constexpr int kRenTileW = ren_tile_w(EXH), kRenThreads = THREADS, kRenLdsW = kRenTileW + 2 * kRenApron;
@@ -254,7 +243,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     b -= L.block_begin;
     const int X0 = (b % L.tiles_x) * kRenTileW, Y0 = (b / L.tiles_x) * kRenTileH;
     const int lw = L.lw, lh = L.lh;
-    const float *__restrict__ src = FROM_DEPTH ? nullptr : frame_ptr(L.src, a.frame_stride, frame);
+    const float *__restrict__ src = frame_ptr(L.src, a.frame_stride, frame);
 
     PhaseClock clk(24);      // 24: window loaded, converted, in LDS; 25: barrier; 26..29: texel-loop iterations
     __builtin_amdgcn_s_setprio(3);
@@ -265,66 +254,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
     // be outside the level) belongs to slice (vx&3, vy&3), slice texel (vx>>2, vy>>2); the
     // reference clamps the slice texel per slice (REN:118 Gather + clamp sampler) and finds
     // Linearize(out-of-range) / 0 in atlas texels beyond the level (DS1:39-46, DS2:35).
-    if constexpr (FROM_DEPTH) {
-        // level[lv] is level lv + 1 (the launch renders levels 1..num_levels): texel (px, py) of it is raw texel (px << s, py << s)
-        const int shift = lv + 1;
-        const float pad = through_f16<RTNE>(L.pad_value);
-        const float *__restrict__ depth = static_cast<const float *>(raw->depth[frame]);
-        const uint32_t W = static_cast<uint32_t>(raw->w[0]);
-        const float zp0 = raw->zp0, zp1 = raw->zp1, sky_depth = raw->reversed_z != 0 ? 0.0f : 1.0f;
-        constexpr int kQuadsX = kRenLdsW / 4, kQuads = kQuadsX * kRenLdsH, kRounds = (kQuads + kRenThreads - 1) / kRenThreads;
-        constexpr bool kEven = kQuads % kRenThreads == 0;
-        // Phase 1: every load of this thread's quads back to back (texels beyond the level re-read its last column / row and
-        // are replaced by the padding value in phase 2, so that no load is conditional)
-        float rawv[kRounds][4];
-        uint32_t inside[kRounds];            // bit e: element e of the quad is a texel of the level
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-            const int q = min(static_cast<int>(threadIdx.x) + r * kRenThreads, kQuads - 1);
-            const int qx = q % kQuadsX, qy = q / kQuadsX;
-            const int px0 = clampi((X0 >> 2) - (kRenApron >> 2) + qx, 0, L.sw - 1) * 4;
-            const int vy = Y0 - kRenApron + qy;
-            const int py = clampi(vy >> 2, 0, L.sh - 1) * 4 + (vy & 3);
-            const uint32_t row = (static_cast<uint32_t>(min(py, lh - 1)) << shift) * W;     // texel index in the frame (< 2^30)
-            inside[r] = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int px = px0 + e;
-                if (py < lh && px < lw) inside[r] |= 1u << e;
-                rawv[r][e] = *at_byte_offset(depth, (row + (static_cast<uint32_t>(min(px, lw - 1)) << shift)) * 4u);
-            }
-        }
-        terms_storage.load(L);
-        dst = frame_ptr(static_cast<typename AO::type *>(L.dst), a.frame_stride, frame);
-        asm volatile("" : "+s"(dst));
-        // Phase 2: Linearize (DS1:37-48), the f16 round trip of the atlas store, one 16-byte LDS store per quad
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-            const int q = static_cast<int>(threadIdx.x) + r * kRenThreads;
-            const int qx = q % kQuadsX, qy = q / kQuadsX;
-            float lin[4];
-            if constexpr (DIV == DIV_EXACT_RCP) {
-                bool nice = true;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    nice = nice && nice_denominator(mad(zp0, rawv[r][e], zp1));
-                    lin[e] = linearize<DIV_EXACT_RCP>(rawv[r][e], zp0, zp1, sky_depth);
-                }
-                if (__builtin_expect(!nice, 0)) {       // hostile texels: IEEE '/', as downsample_tile_finish divides them
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV_IEEE>(rawv[r][e], zp0, zp1, sky_depth);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(rawv[r][e], zp0, zp1, sky_depth);
-            }
-            const float2v lo = through_f16_pair<RTNE>(lin[0], lin[1]), hi = through_f16_pair<RTNE>(lin[2], lin[3]);
-            float4v t;
-            t.x = (inside[r] & 1u) ? lo.x : pad; t.y = (inside[r] & 2u) ? lo.y : pad;
-            t.z = (inside[r] & 4u) ? hi.x : pad; t.w = (inside[r] & 8u) ? hi.y : pad;
-            if (kEven || q < kQuads) *reinterpret_cast<float4v *>(&tile[qy * kRenLdsW + qx * 4]) = t;
-        }
-    } else {
+    {
         const float pad = through_f16<RTNE>(L.pad_value);
         const bool vec_ok = (lw & 3) == 0;
         constexpr int kQuadsX = kRenLdsW / 4, kQuads = kQuadsX * kRenLdsH, kRounds = (kQuads + kRenThreads - 1) / kRenThreads;
@@ -394,13 +324,6 @@ __device__ __forceinline__ void render_tile(const RenderArgs &a, float *tile, in
             const float *centre = &tile[(ly + kRenApron) * kRenLdsW + 2 * txl + kRenApron];
             const float2v c = *reinterpret_cast<const float2v *>(centre);
             float2v inv_depth = float2v{rcp_strict<DIV>(c.x), rcp_strict<DIV>(c.y)};   // REN:140
-            if constexpr (FROM_DEPTH && DIV == DIV_EXACT_RCP) {
-                // no frame flag here: 0 and NaN (what hostile depth leaves behind the f16 round trip, RTZ storage) are the centre
-                // depths outside the exact reciprocal's verified range -- IEEE '/' for those, per lane
-                const bool ok = __builtin_fabsf(c.x) >= 0x1p-100f && __builtin_fabsf(c.x) <= 0x1p100f &&
-                                __builtin_fabsf(c.y) >= 0x1p-100f && __builtin_fabsf(c.y) <= 0x1p100f;
-                if (__builtin_expect(!ok, 0)) inv_depth = float2v{rcp_strict<DIV_IEEE>(c.x), rcp_strict<DIV_IEEE>(c.y)};
-            }
             float2v out;     // one pair in flight ahead of the one evaluated; a second one changed nothing (r02 A/B)
             if constexpr (!EXH) out = accumulate_terms_pipelined<4 * kRenLdsW, 4, 1>(terms, centre, inv_depth);
             else out = accumulate_terms<EXH, 4 * kRenLdsW, 4>(terms, centre, inv_depth);

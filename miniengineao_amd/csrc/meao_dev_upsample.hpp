@@ -2,6 +2,10 @@
 #pragma once
 
 #include "meao_dev.hpp"
+#ifndef MEAO_X_NO_REDO
+#define MEAO_X_NO_REDO 0
+#endif
+#include "meao_dev_downsample.hpp"      // linearize, nice_denominators, raw_depth_texel: HiResDB of the final pass
 
 namespace meao {
 namespace {
@@ -255,6 +259,148 @@ __device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float 
     return code;
 }
 
+// HiResDB of Upsample.main for four consecutive hi-res texels: LinearZ = f16(Linearize(depth)) (DS1:37-48 through the HalfUAV
+// store AO.cs:454, read back by UPS:217-223) from the raw depth texels d[] -- the buffer itself is never materialised (round 6).
+// Returns false when a denominator is outside the range the exact reciprocal (and everything downstream of it in the bilateral
+// step) is verified for: the caller then redoes its texels with IEEE '/' (final_lane_redo_ieee), which is what the reference
+// divides with everywhere.  hd[] of such a quad is not used.
+template <bool RTNE, int DIV>
+__device__ __forceinline__ bool hi_depth_quad(const float (&d)[4], float zp0, float zp1, float sky_depth, float (&hd)[4])
+{
+    float lin[4];
+    bool nice = true;
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        float den[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) den[e] = mad(zp0, d[e], zp1);
+        nice = nice_denominators(den[0], den[1], den[2], den[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r = __builtin_amdgcn_rcpf(den[e]);
+            lin[e] = mad(mad(-den[e], r, 1.0f), r, r);                      // rcp_strict: DS1:40
+        }
+        const bool far = (d[0] == sky_depth) | (d[1] == sky_depth) | (d[2] == sky_depth) | (d[3] == sky_depth);
+        if (__builtin_expect(far, 0)) {                                     // DS1:41-45
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lin[e] = d[e] == sky_depth ? 1e5f : lin[e];
+            asm volatile("" : "+v"(lin[0]), "+v"(lin[1]), "+v"(lin[2]), "+v"(lin[3]));   // stays a branch: rare lanes only
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lin[e] = linearize<DIV>(d[e], zp0, zp1, sky_depth);
+    }
+    const float2v lo = through_f16_pair<RTNE>(lin[0], lin[1]), hi = through_f16_pair<RTNE>(lin[2], lin[3]);
+    hd[0] = lo.x; hd[1] = lo.y; hd[2] = hi.x; hd[3] = hi.y;
+    return nice;
+}
+
+// Four raw depth texels as loaded (undecoded): f32 / UNORM24 fill all four words, the 16-bit formats the first two.
+template <bool RAW_F32>
+__device__ __forceinline__ void decode_raw_quad(const uint4v &q, int format, float (&d)[4])
+{
+    if (RAW_F32 || format == MEAO_DEPTH_F32) {
+        // (the whole vector is cast: __builtin_bit_cast(float, q.y) on a vector-element lvalue reads the bytes at the address of
+        // the VECTOR, i.e. element 0, with this compiler -- found by the first GPU run of round 6)
+        const float4v f = __builtin_bit_cast(float4v, q);
+        d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+    } else if (format == MEAO_DEPTH_UNORM24) {
+        d[0] = unorm_to_f32<24>(q.x & 0xffffffu); d[1] = unorm_to_f32<24>(q.y & 0xffffffu);
+        d[2] = unorm_to_f32<24>(q.z & 0xffffffu); d[3] = unorm_to_f32<24>(q.w & 0xffffffu);
+    } else if (format == MEAO_DEPTH_UNORM16) {
+        d[0] = unorm_to_f32<16>(q.x & 0xffffu); d[1] = unorm_to_f32<16>(q.x >> 16);
+        d[2] = unorm_to_f32<16>(q.y & 0xffffu); d[3] = unorm_to_f32<16>(q.y >> 16);
+    } else {
+        d[0] = f16_bits_to_f32(static_cast<uint16_t>(q.x & 0xffffu)); d[1] = f16_bits_to_f32(static_cast<uint16_t>(q.x >> 16));
+        d[2] = f16_bits_to_f32(static_cast<uint16_t>(q.y & 0xffffu)); d[3] = f16_bits_to_f32(static_cast<uint16_t>(q.y >> 16));
+    }
+}
+
+template <bool RAW_F32>
+__device__ __forceinline__ uint4v load_raw_quad(const void *frame_base, int format, uint32_t texel)
+{
+    typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+    if (RAW_F32 || format == MEAO_DEPTH_F32 || format == MEAO_DEPTH_UNORM24)      // the frame is read once: streamed past the caches' LRU
+        return __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(at_byte_offset(static_cast<const char *>(frame_base), texel * 4u)));
+    const uint2v h = __builtin_nontemporal_load(reinterpret_cast<const uint2v *>(at_byte_offset(static_cast<const char *>(frame_base), texel * 2u)));
+    return uint4v{h.x, h.y, 0u, 0u};
+}
+
+// HiResDB of ALL the hi-res texels of a lane (QUADS quads of four) at once, from the hoisted raw loads, as packed f16 pairs --
+// what a LinearDepth buffer would have handed the bilateral phase, so that phase stays what it was.  One straight-line block:
+// the denominators and the Newton steps are packed f32 FMAs (v_pk_fma_f32: two texels per issue), the 4 * QUADS reciprocals
+// are issued back to back (an isolated v_rcp_f32 costs the SIMD ~3 cycles more than one behind another), the far-plane select
+// runs only in waves that hold a far-plane texel (wave-uniform branch: no exec masking inside straight-line code).
+// Hostile depth: instead of range-testing 4 * QUADS denominators, the test reads the RESULT.  With a denominator the exact
+// reciprocal is not verified for, the f16 word is inf / NaN / negative / -0 (den = 0, +-inf, NaN, < 0, denormal: the Newton
+// step turns the first four into NaN) -- i.e. >= 0x7c00 as an unsigned 16-bit word -- or it is exactly what IEEE '/' gives:
+// 65504 for every den in (0, 2^-16) whose reciprocal is finite (round toward zero), +0 for den > 2^24.  A non-negative finite
+// HiResDB keeps every operand of the bilateral step inside the exact sequences' ranges (x = |hi - lo| + tolerance with lo a
+// nice level texel).  So: one packed unsigned max over the words, one compare per lane.  Returns false = redo the lane (IEEE).
+template <bool RTNE, int DIV, bool RAW_F32, int QUADS>
+__device__ __forceinline__ bool hi_depth_words(const uint4v (&raw)[QUADS], int format, float zp0, float zp1, float sky_depth,
+                                               uint32_t (&words)[QUADS][2])
+{
+    float d[QUADS][4];
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) decode_raw_quad<RAW_F32>(raw[q], format, d[q]);
+    if constexpr (DIV == DIV_EXACT_RCP) {
+        static_assert(!RTNE, "exact divisions only ever run with round-toward-zero depth storage");
+        float2v den[QUADS][2], r[QUADS][2], lin[QUADS][2];
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) den[q][h] = fma2(splat(zp0), float2v{d[q][2 * h], d[q][2 * h + 1]}, splat(zp1));      // DS1:40
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float rx, ry;
+                asm volatile("v_rcp_f32 %0, %1" : "=v"(rx) : "v"(den[q][h].x));
+                asm volatile("v_rcp_f32 %0, %1" : "=v"(ry) : "v"(den[q][h].y));
+                r[q][h] = float2v{rx, ry};
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        bool far = false;
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                lin[q][h] = fma2(fma2(-den[q][h], r[q][h], splat(1.0f)), r[q][h], r[q][h]);                                      // rcp_strict
+                far = far | (d[q][2 * h] == sky_depth) | (d[q][2 * h + 1] == sky_depth);
+            }
+        if (__builtin_amdgcn_ballot_w64(far) != 0) {                                                                              // DS1:41-45
+#pragma unroll
+            for (int q = 0; q < QUADS; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    lin[q][h].x = d[q][2 * h] == sky_depth ? 1e5f : lin[q][h].x;
+                    lin[q][h].y = d[q][2 * h + 1] == sky_depth ? 1e5f : lin[q][h].y;
+                }
+        }
+        ushort2v top = {0, 0};
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const auto p = __builtin_amdgcn_cvt_pkrtz(lin[q][h].x, lin[q][h].y);                                              // the HalfUAV store, AO.cs:454
+                words[q][h] = __builtin_bit_cast(uint32_t, p);
+                top = __builtin_elementwise_max(top, __builtin_bit_cast(ushort2v, p));
+            }
+        return top.x < 0x7c00u && top.y < 0x7c00u;
+    } else {
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t lo = f32_to_f16_bits<RTNE>(linearize<DIV>(d[q][2 * h], zp0, zp1, sky_depth));
+                const uint32_t hi = f32_to_f16_bits<RTNE>(linearize<DIV>(d[q][2 * h + 1], zp0, zp1, sky_depth));
+                words[q][h] = lo | (hi << 16);
+            }
+        return true;
+    }
+}
+
 // One tile of Upsample.main (FINAL) / main_blendout; every thread of the workgroup must call it
 // (barriers inside; lanes outside the image leave after the last one).
 // (Eight workgroups per CU were measured in round 4: the LoResDB window kept in the registers its loads filled and written behind
@@ -274,14 +420,15 @@ struct UpsLds {
 
 // The global loads of an interior tile (no horizontal clamping, 16-byte loads everywhere, no second AO input): its low-res
 // window as 16-byte row quads [LX0 - 4 + 4k, +4) -- depth and AO -- and the hi-res operands of the bilateral phase
-// (f16 depth in the full-resolution pass, f32 depth + AO in the blend passes).  Issued at the top of the tile.
+// (the RAW depth texels of the caller's frame in the full-resolution pass, f32 depth + AO in the blend passes).  Issued at the
+// top of the tile.
 template <int AOFMT, bool FINAL, int TILE_H>
 struct UpsLoads {
     typedef AoTexel<AOFMT> AO;
     static constexpr int kItems = 10 * UpsTile<TILE_H>::kRawH, kRounds = (kItems + kThreads - 1) / kThreads, kPasses = TILE_H / 32;
     float4v wd[kRounds];
     typename AO::type4 wa[kRounds];
-    ushort4v hd16[kPasses][2];
+    uint4v hraw[kPasses][2];            // FINAL: four raw depth texels, undecoded (load_raw_quad)
     float4v hd32[kPasses][2];
     // four AO texels as ONE integer: a <4 x i8> value is split into bytes where it is loaded, which puts the wait for it there
     typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type ao_bits_t;
@@ -297,8 +444,8 @@ __device__ __forceinline__ bool ups_tile_is_interior(const UpsampleArgs &a, int 
 
 // Hi-res operands.  CLAMPED: every lane loads (out-of-frame lanes re-read the frame's last row / quad and never use it),
 // so that the code is branch-free and the compiler's s_waitcnt counts stay exact.
-template <int AOFMT, bool FINAL, int TILE_H, bool CLAMPED>
-__device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
+template <int AOFMT, bool FINAL, int TILE_H, bool CLAMPED, bool RAW_F32>
+__device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, const HiDepthArgs *hi, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
 {
     const int tid = thread_index_opaque();
     typedef AoTexel<AOFMT> AO;
@@ -313,12 +460,12 @@ __device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, int til
         for (int f = 0; f < 2; ++f) {
             const int hy_raw = HY0 + 2 * ((tid >> 4) + 16 * pass) + f;
             const int hy = CLAMPED ? min(hy_raw, hh - 1) : hy_raw;
+            if constexpr (FINAL && !CLAMPED) L.hraw[pass][f] = uint4v{0x3f000000u, 0x3f000000u, 0x3f000000u, 0x3f000000u};   // texels past the frame: a clean depth, never used
             if (CLAMPED || (hhx0 < hw && hy < hh)) {
                 // texel index in the level (< 2^27): 32-bit byte offsets from the frame's uniform bases (saddr addressing)
                 const uint32_t hrow = static_cast<uint32_t>(hy * hw + hhx0);
                 if constexpr (FINAL) {
-                    L.hd16[pass][f] = __builtin_nontemporal_load(reinterpret_cast<const ushort4v *>(at_byte_offset(
-                        frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame), hrow * 2u)));
+                    L.hraw[pass][f] = load_raw_quad<RAW_F32>(hi->raw[frame], hi->depth_format, hrow);
                 } else {
                     L.hd32[pass][f] = *reinterpret_cast<const float4v *>(at_byte_offset(
                         frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame), hrow * 4u));
@@ -332,8 +479,8 @@ __device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, int til
 // All loads of an interior tile: window first, hi-res operands behind them.  The window comes from L2 (written by the
 // previous pass), the hi-res operands of the final pass from HBM; vmcnt retires loads in issue order, so with the hi-res
 // loads in front the window wait would last an HBM latency.
-template <int AOFMT, bool FINAL, int TILE_H>
-__device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
+template <int AOFMT, bool FINAL, int TILE_H, bool RAW_F32>
+__device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, const HiDepthArgs *hi, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
 {
     const int tid = thread_index_opaque();
     typedef UpsLoads<AOFMT, FINAL, TILE_H> Loads;
@@ -353,7 +500,7 @@ __device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, 
         L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(lo_ao, idx * static_cast<uint32_t>(sizeof(ao_t))));
     }
     __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
-    ups_issue_hoisted<AOFMT, FINAL, TILE_H, true>(a, tile, frame, L);
+    ups_issue_hoisted<AOFMT, FINAL, TILE_H, true, RAW_F32>(a, hi, tile, frame, L);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -372,8 +519,10 @@ struct NoHook {
     __device__ __forceinline__ void before_bilateral() const {}
 };
 
-template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
-__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
+// RAW_F32 (FINAL): the caller's depth frames are f32 -- no format switch in the code (the other formats take the generic instance)
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, bool NESTED = false, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL), bool RAW_F32 = true>
+__device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook(),
+                                              const HiDepthArgs *hi = nullptr)
 {
     const int tid = thread_index_opaque();
     typedef AoTexel<AOFMT> AO;
@@ -416,6 +565,10 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     ao_t *__restrict__ dst = FINAL ? static_cast<ao_t *>(a.dst[frame])
                                    : frame_ptr(static_cast<ao_t *>(a.dst[0]), a.frame_stride, frame);
     asm volatile("" : "+s"(dst));
+    // Linearize constants of the final pass's HiResDB (fetched here for the same reason)
+    const float zp0 = FINAL ? hi->zp0 : 0.0f, zp1 = FINAL ? hi->zp1 : 0.0f;
+    const float sky_depth = (FINAL && hi->reversed_z == 0) ? 1.0f : 0.0f;
+    const int raw_format = (FINAL && !RAW_F32) ? hi->depth_format : MEAO_DEPTH_F32;
 
     PhaseClock clk(FINAL ? 0 : 8);
     __builtin_amdgcn_s_setprio(3);
@@ -424,20 +577,20 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     constexpr int kPasses = kTileH / 32;
     typedef UpsLoads<AOFMT, FINAL, TILE_H> Loads;
     Loads L;
-    auto &hoist_hd16 = L.hd16;
+    auto &hoist_hraw = L.hraw;
     auto &hoist_hd32 = L.hd32;
     auto &hoist_ha = L.ha;
     const bool hoist_ok = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;
     // interior tile, 16-byte loads everywhere, no second AO input: window loads first (ups_issue_interior_loads)
     const bool window_first = !NESTED && (MEAO_X_HOT_PATH_ONLY || ups_tile_is_interior<FINAL, TILE_H>(a, tile));
-    if (hoist_ok && !window_first) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false>(a, tile, frame, L);
+    if (hoist_ok && !window_first) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false, RAW_F32>(a, hi, tile, frame, L);
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
     // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
     const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
     if (window_first) {
         constexpr int kItems = Loads::kItems, kRounds = Loads::kRounds;
-        if constexpr (!NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H>(a, tile, frame, L);
+        if constexpr (!NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H, RAW_F32>(a, hi, tile, frame, L);
         auto &wd = L.wd;
         auto &wa = L.wa;
 #pragma unroll
@@ -572,6 +725,21 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         for (int n = 0; n < T::kVRun; ++n) s_vb[(r0 + n) * T::kBlurPitch + c] = o[n];
     }
     clk.mark(4);         // 4: V-blur
+    // ---- HiResDB of the lane's 16 (8) texels from the hoisted raw depth loads (hi_depth_words), in front of the last barrier: the
+    // loads went out at the top of the tile and have long landed; the bilateral phase finds packed f16 words, as it did when
+    // LinearDepth was a buffer
+    uint32_t hd_words[2 * kPasses][2];
+    bool lane_clean = true;
+    if constexpr (FINAL) {
+        if (hoist_ok) {
+            uint4v rawq[2 * kPasses];
+#pragma unroll
+            for (int pass = 0; pass < kPasses; ++pass)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) rawq[2 * pass + f] = hoist_hraw[pass][f];
+            lane_clean = hi_depth_words<RTNE, DIV, RAW_F32, 2 * kPasses>(rawq, raw_format, zp0, zp1, sky_depth, hd_words);
+        }
+    }
     __syncthreads();
     clk.mark(5);         // 5: barrier
     if constexpr (Hook::kBeforeBilateral) {
@@ -580,7 +748,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
 #pragma unroll
         for (int pass = 0; pass < kPasses; ++pass) {
             if constexpr (FINAL) {
-                asm volatile("" : : "v"(hoist_hd16[pass][0]), "v"(hoist_hd16[pass][1]));
+                // (the raw depth quads were consumed in front of the barrier: nothing of this tile is in flight any more)
             } else {
                 asm volatile("" : : "v"(hoist_hd32[pass][0]), "v"(hoist_hd32[pass][1]), "v"(hoist_ha[pass][0]), "v"(hoist_ha[pass][1]));
             }
@@ -612,11 +780,12 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         constexpr bool WHOLE = decltype(whole_tile)::value;
         const bool vec_ok = WHOLE || vec_ok_frame;
         if (!WHOLE && hx0 >= hw) return;
+        bool redo = !lane_clean;   // FINAL, exact divisions: a raw depth texel of this lane is outside their verified range (hi_depth_words / _quad)
 #pragma unroll       // the hoisted operands live in registers: static indices
         for (int pass = 0; pass < kTileH / 32; ++pass) {
             const int ty = (tid >> 4) + 16 * pass;
             const int hy0 = HY0 + 2 * ty;
-            if (!WHOLE && hy0 >= hh) return;
+            if (!WHOLE && hy0 >= hh) break;
 
             float vb[3][4], dl[3][4];   // blurred AO / low depth at virtual (LY0-1+ty+rr, LX0-1+2tx+cc)
 #pragma unroll
@@ -636,14 +805,16 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 const size_t hrow = static_cast<size_t>(hy) * hw + hx0;
                 float hd[4], ha[4] = {1.0f, 1.0f, 1.0f, 1.0f};                  // HiSSAOs = 1 in "main" (UPS:222)
                 if constexpr (FINAL) {
-                    const uint16_t *p = frame_ptr(static_cast<const uint16_t *>(a.hi_depth), a.frame_stride, frame) + hrow;
+                    // HiResDB = f16(Linearize(raw depth)), evaluated here (hi_depth_quad); LinearDepth is not a buffer
                     if (vec_ok) {
-                        const ushort4v q = hoist_hd16[pass][f];
-                        hd[0] = f16_bits_to_f32(q.x); hd[1] = f16_bits_to_f32(q.y);
-                        hd[2] = f16_bits_to_f32(q.z); hd[3] = f16_bits_to_f32(q.w);
+                        const uint32_t w0 = hd_words[2 * pass + f][0], w1 = hd_words[2 * pass + f][1];
+                        hd[0] = f16_bits_to_f32(static_cast<uint16_t>(w0 & 0xffffu)); hd[1] = f16_bits_to_f32(static_cast<uint16_t>(w0 >> 16));
+                        hd[2] = f16_bits_to_f32(static_cast<uint16_t>(w1 & 0xffffu)); hd[3] = f16_bits_to_f32(static_cast<uint16_t>(w1 >> 16));
                     } else {
+                        float rawd[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) hd[e] = (hx0 + e < hw) ? f16_bits_to_f32(p[e]) : 1.0f;
+                        for (int e = 0; e < 4; ++e) rawd[e] = (hx0 + e < hw) ? raw_depth_texel(hi->raw[frame], raw_format, hrow + e) : 0.5f;
+                        redo |= !hi_depth_quad<RTNE, DIV>(rawd, zp0, zp1, sky_depth, hd);
                     }
                 } else {
                     const float *p = frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame) + hrow;
@@ -736,6 +907,35 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             }
             clk.mark(6 + pass);  // 6, 7: bilateral pass 0 / 1 (64-row tiles) incl. its stores being issued
         }
+        if constexpr (FINAL && DIV == DIV_EXACT_RCP && !MEAO_X_HOT_PATH_ONLY && !MEAO_X_NO_REDO) {
+            // Hostile raw depth in a frame whose LEVELS are clean (the frame flag only covers the texels the levels are made of): this
+            // lane's texels once more with IEEE '/' throughout, as the reference divides -- exact sequences and IEEE '/' agree wherever
+            // the former are valid, so redoing the lane's clean texels too changes nothing.  A compact loop, not unrolled: cold code.
+            if (__builtin_expect(redo, 0)) {
+#pragma unroll 1
+                for (int t = 0; t < 8 * (kTileH / 32); ++t) {
+                    const int pass = t >> 3, f = (t >> 2) & 1, e = t & 3;
+                    const int ty = (tid >> 4) + 16 * pass;
+                    const int hy = HY0 + 2 * ty + f, hx = hx0 + e;
+                    if (hx >= hw || hy >= hh) continue;
+                    const size_t at = static_cast<size_t>(hy) * hw + hx;
+                    const float rawv = raw_depth_texel(hi->raw[frame], raw_format, at);
+                    const float hdv = through_f16<RTNE>(linearize<DIV_IEEE>(rawv, zp0, zp1, sky_depth));
+                    const int cc = ((e + 1) >> 1) + 1, rr = f + 1;                        // as above
+                    const int comp = (e & 1) ? (f ? 3 : 0) : (f ? 2 : 1);
+                    float gd[4], ga[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int g = (comp + i) & 3;
+                        const int r = ty + rr - (g >> 1), c = 2 * tx + cc - ((g == 0 || g == 3) ? 1 : 0);      // gy[g], gx[g]
+                        gd[i] = dep_at(r + 2, c + 2);
+                        ga[i] = s_vb[r * T::kBlurPitch + c];
+                    }
+                    dst[at] = AO::template encode<RTNE>(bilateral_upsample<DIV_IEEE>(hdv, 1.0f, gd[0], gd[1], gd[2], gd[3],
+                                                                                      ga[0], ga[1], ga[2], ga[3], bilateral_k));
+                }
+            }
+        }
     };
     // (the copy exists for clean frames only -- the IEEE-division bodies of a hostile frame are four times as long -- and not in the
     // nested launches, which have no registers for it: 3 spilled VGPRs in the two-level kernel, no gain measured there)
@@ -746,16 +946,17 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
 }
 
 // The (rare) hostile-frame variant of a tile: the same code with IEEE division.
-template <int AOFMT, bool RTNE, bool FINAL, int DIV, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL)>
-__device__ __forceinline__ void upsample_tile_checked(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook())
+template <int AOFMT, bool RTNE, bool FINAL, int DIV, typename Hook = NoHook, int TILE_H = ups_tile_h(FINAL), bool RAW_F32 = true>
+__device__ __forceinline__ void upsample_tile_checked(const UpsampleArgs &a, float *smem, int tile, int frame, Hook hook = Hook(),
+                                                      const HiDepthArgs *hi = nullptr)
 {
     if constexpr (DIV == DIV_EXACT_RCP) {
         if (frame_is_hostile(a.hostile, a.generation, frame)) {       // wave-uniform, decided per frame
-            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE, false, Hook, TILE_H>(a, smem, tile, frame, hook);
+            upsample_tile<AOFMT, RTNE, FINAL, DIV_IEEE, false, Hook, TILE_H, RAW_F32>(a, smem, tile, frame, hook, hi);
             return;
         }
     }
-    upsample_tile<AOFMT, RTNE, FINAL, DIV, false, Hook, TILE_H>(a, smem, tile, frame, hook);
+    upsample_tile<AOFMT, RTNE, FINAL, DIV, false, Hook, TILE_H, RAW_F32>(a, smem, tile, frame, hook, hi);
 }
 
 

@@ -1,5 +1,6 @@
-// meao_k_misc.hip -- atlas rebuild, debug views, composite, device self-tests.
+// meao_k_misc.hip -- LinearDepth / atlas rebuild for the debug views, debug views, composite, device self-tests.
 #include "meao_dev_upsample.hpp"
+#include "meao_dev_downsample.hpp"
 #include "meao_dev_composite.hpp"
 
 namespace meao {
@@ -20,6 +21,18 @@ __global__ __launch_bounds__(kThreads) void tile_atlas_kernel(const TileAtlasArg
         const float v = (x < a.lw && y < a.lh) ? a.src[static_cast<size_t>(y) * a.lw + x] : a.pad_value;
         a.dst[i] = f32_to_f16_bits<RTNE>(v);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// LinearDepth for debug id 1: LinearZ[st] = Linearize(Depth[st]) through the HalfUAV store (DS1:37-48, AO.cs:454).  The hot
+// path never builds the buffer (the full-resolution upsample evaluates the same expression per texel); here every texel is
+// divided with IEEE '/', which the exact reciprocal sequences equal wherever they are used.
+template <bool RTNE>
+__global__ __launch_bounds__(kThreads) void linear_depth_kernel(const LinearDepthArgs a)
+{
+    const float sky_depth = a.reversed_z != 0 ? 0.0f : 1.0f;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < a.pixels; i += static_cast<int64_t>(gridDim.x) * kThreads)
+        a.dst[i] = f32_to_f16_bits<RTNE>(linearize<DIV_IEEE>(raw_depth_texel(a.depth, a.depth_format, static_cast<size_t>(i)), a.zp0, a.zp1, sky_depth));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -191,6 +204,14 @@ hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s)
     const int blocks = (n + kThreads - 1) / kThreads;
     if (a.f16_rtne) tile_atlas_kernel<true><<<dim3(blocks < 4096 ? blocks : 4096), dim3(kThreads), 0, s>>>(a);
     else tile_atlas_kernel<false><<<dim3(blocks < 4096 ? blocks : 4096), dim3(kThreads), 0, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_linear_depth(const LinearDepthArgs &a, hipStream_t s)
+{
+    const dim3 grid(static_cast<int>(std::min<int64_t>((a.pixels + kThreads - 1) / kThreads, 256 * 32))), block(kThreads);
+    if (a.f16_rtne) linear_depth_kernel<true><<<grid, block, 0, s>>>(a);
+    else linear_depth_kernel<false><<<grid, block, 0, s>>>(a);
     return hipGetLastError();
 }
 

@@ -263,12 +263,10 @@ static hipError_t launch_render_any(const RenderArgs &a, int ao_format, int fram
     const dim3 grid(a.blocks_per_frame, frames, 1);
     if (ao_format == MEAO_AO_R8) {
         if (a.f16_rtne) launch_render_t<WIDE, MEAO_AO_R8, true, DIV_IEEE>(a, grid, s);
-        else if (a.exact_rcp_div == 2) launch_render_t<WIDE, MEAO_AO_R8, false, DIV_FAST>(a, grid, s);
         else if (a.exact_rcp_div) launch_render_t<WIDE, MEAO_AO_R8, false, DIV_EXACT_RCP>(a, grid, s);
         else launch_render_t<WIDE, MEAO_AO_R8, false, DIV_IEEE>(a, grid, s);
     } else {
         if (a.f16_rtne) launch_render_t<WIDE, MEAO_AO_F16, true, DIV_IEEE>(a, grid, s);
-        else if (a.exact_rcp_div == 2) launch_render_t<WIDE, MEAO_AO_F16, false, DIV_FAST>(a, grid, s);
         else if (a.exact_rcp_div) launch_render_t<WIDE, MEAO_AO_F16, false, DIV_EXACT_RCP>(a, grid, s);
         else launch_render_t<WIDE, MEAO_AO_F16, false, DIV_IEEE>(a, grid, s);
     }
@@ -292,12 +290,10 @@ hipError_t launch_render_with_composite(const RenderArgs &a, const CompositeBatc
     const dim3 grid(a.blocks_per_frame, frames, 1);
     if (ao_format == MEAO_AO_R8) {
         if (a.f16_rtne) launch_render_composite_t<MEAO_AO_R8, true, DIV_IEEE>(a, c, grid, s);
-        else if (a.exact_rcp_div == 2) launch_render_composite_t<MEAO_AO_R8, false, DIV_FAST>(a, c, grid, s);
         else if (a.exact_rcp_div) launch_render_composite_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(a, c, grid, s);
         else launch_render_composite_t<MEAO_AO_R8, false, DIV_IEEE>(a, c, grid, s);
     } else {
         if (a.f16_rtne) launch_render_composite_t<MEAO_AO_F16, true, DIV_IEEE>(a, c, grid, s);
-        else if (a.exact_rcp_div == 2) launch_render_composite_t<MEAO_AO_F16, false, DIV_FAST>(a, c, grid, s);
         else if (a.exact_rcp_div) launch_render_composite_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(a, c, grid, s);
         else launch_render_composite_t<MEAO_AO_F16, false, DIV_IEEE>(a, c, grid, s);
     }

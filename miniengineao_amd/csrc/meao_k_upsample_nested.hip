@@ -94,12 +94,10 @@ hipError_t launch_upsample_two_level(const UpsampleArgs &outer, const UpsampleAr
     const dim3 grid(outer.tiles_x * outer.tiles_y, 1, frames);
     if (ao_format == MEAO_AO_R8) {
         if (outer.f16_rtne) launch_upsample_two_level_t<MEAO_AO_R8, true, DIV_IEEE>(outer, inner, grid, s);
-        else if (outer.exact_rcp_div == 2) launch_upsample_two_level_t<MEAO_AO_R8, false, DIV_FAST>(outer, inner, grid, s);
         else if (outer.exact_rcp_div) launch_upsample_two_level_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(outer, inner, grid, s);
         else launch_upsample_two_level_t<MEAO_AO_R8, false, DIV_IEEE>(outer, inner, grid, s);
     } else {
         if (outer.f16_rtne) launch_upsample_two_level_t<MEAO_AO_F16, true, DIV_IEEE>(outer, inner, grid, s);
-        else if (outer.exact_rcp_div == 2) launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_FAST>(outer, inner, grid, s);
         else if (outer.exact_rcp_div) launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(outer, inner, grid, s);
         else launch_upsample_two_level_t<MEAO_AO_F16, false, DIV_IEEE>(outer, inner, grid, s);
     }
@@ -119,12 +117,10 @@ hipError_t launch_upsample_three_level(const UpsampleArgs &outer, const Upsample
     const dim3 grid(outer.tiles_x * outer.tiles_y, 1, frames);
     if (ao_format == MEAO_AO_R8) {
         if (outer.f16_rtne) launch_upsample_three_level_t<MEAO_AO_R8, true, DIV_IEEE>(outer, mid, inner, grid, s);
-        else if (outer.exact_rcp_div == 2) launch_upsample_three_level_t<MEAO_AO_R8, false, DIV_FAST>(outer, mid, inner, grid, s);
         else if (outer.exact_rcp_div) launch_upsample_three_level_t<MEAO_AO_R8, false, DIV_EXACT_RCP>(outer, mid, inner, grid, s);
         else launch_upsample_three_level_t<MEAO_AO_R8, false, DIV_IEEE>(outer, mid, inner, grid, s);
     } else {
         if (outer.f16_rtne) launch_upsample_three_level_t<MEAO_AO_F16, true, DIV_IEEE>(outer, mid, inner, grid, s);
-        else if (outer.exact_rcp_div == 2) launch_upsample_three_level_t<MEAO_AO_F16, false, DIV_FAST>(outer, mid, inner, grid, s);
         else if (outer.exact_rcp_div) launch_upsample_three_level_t<MEAO_AO_F16, false, DIV_EXACT_RCP>(outer, mid, inner, grid, s);
         else launch_upsample_three_level_t<MEAO_AO_F16, false, DIV_IEEE>(outer, mid, inner, grid, s);
     }

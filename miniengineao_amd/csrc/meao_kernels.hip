@@ -1,11 +1,12 @@
 // meao_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the multi-scale SSAO hot path.
 //
 // One workgroup = 256 threads = 4 wave64 (render: 512).  Kernels (stream order, one launch each per batch):
-//   downsample_kernel  Downsample1.main + Downsample2.main   (DS1:52-81, DS2:32-51)
+//   downsample_kernel  Downsample1.main + Downsample2.main   (DS1:52-81, DS2:32-51): the four point-sampled levels.  LinearZ
+//                      (DS1:46) is not stored -- its one reader, the full-resolution upsample, evaluates it from the raw depth
 //   render_kernel      Render.main_interleaved, all levels   (REN:112-177)
 //   render_with_composite_kernel   the same, carrying the composite of an earlier call in its texel loop
 //   render_wide_kernel Render.main on LowDepth<k> (opt-in hq_levels variant)
-//   upsample_kernel    Upsample.main / main_blendout [/ main_premin*]   (UPS:185-233)
+//   upsample_kernel / upsample_final_kernel    Upsample.main_blendout / main [/ main_premin*]   (UPS:185-233)
 //   upsample_two_level_kernel / upsample_three_level_kernel   main_blendout L3->L2 (L2->L1) with the
 //                      pass(es) below evaluated inside the same launch
 //   upsample_final_with_next_downsample_kernel   Upsample.main of this batch + the downsample pass
@@ -55,7 +56,6 @@
 #define MEAO_UNITY_BUILD 1
 #include "meao_k_downsample.hip"
 #include "meao_k_render.hip"
-#include "meao_k_render_depth.hip"
 #include "meao_k_upsample.hip"
 #include "meao_k_upsample_nested.hip"
 #include "meao_k_upsample_fused.hip"

@@ -9,11 +9,13 @@
 namespace meao {
 
 // ---------------------------------------------------------------------------------------
-// Downsample (Downsample1.main + Downsample2.main fused; no LDS, pure streaming)
+// Downsample (Downsample1.main + Downsample2.main fused; no LDS, pure streaming).  Since round 6 the pass writes the four
+// point-sampled levels ONLY: LowDepth<k>[i, j] = Linearize(depth[2^k i, 2^k j]), so it reads the even rows of the frame and
+// nothing else.  LinearDepth (DS1:46, f16) had one consumer, HiResDB of Upsample.main (UPS:217-223): that pass linearizes the
+// raw depth itself (UpsampleArgs::hi_raw), and debug id 1 is built on demand (launch_linear_depth).
 struct DownsampleArgs {
     const void *depth[MEAO_MAX_BATCH];   // caller-owned raw depth (depth_format), one pointer per frame
     int32_t depth_format;                // meao_depth_format
-    uint16_t *linear;                    // LinearDepth f16 L0, frame 0
     float *low[4];                       // LowDepth1..4 f32, frame 0
     uint64_t frame_stride;               // bytes between consecutive frames' intermediates
     int32_t w[5], h[5];                  // mip 0..4 dims
@@ -21,16 +23,20 @@ struct DownsampleArgs {
     int32_t reversed_z;
     int32_t f16_rtne;
     int32_t exact_rcp_div;
-    int32_t tiles_x, tiles_y;
-    int32_t row_passes;       // row passes per tile: kDsTileH / kDsRowsPerPass, or 1 (downsample_small_kernel; stand-alone pass of small calls)
-    int32_t frames;                      // used by the fused kernels only (the plain launch has grid.z = frames)
-    int32_t tile_begin, tile_end;        // fused kernels: the tiles (per frame) this launch carries are [tile_begin, tile_end)
-    int32_t vec_ok;                      // width % 4 == 0 and every depth pointer aligned for 4-texel loads
-    // hostile[frame] = generation when a texel of the frame is outside the range the exact
-    // v_rcp_f32 sequences are verified for (NaN, inf, negative, tiny); read by the later kernels
+    int32_t tiles_x, tiles_y;            // tiles of kMipTileW x (8 * rows_per_lane) LowDepth1 texels (stand-alone pass), or of
+                                         // kLeanMipW x kLeanMipRows (the tile the last upsample kernel carries)
+    int32_t rows_per_lane;               // kMipRowsPerLane, or 1 (stand-alone pass of small calls: twice the workgroups)
+    int32_t frames;                      // used by the fused kernel only (the plain launch has grid.z = frames)
+    int32_t vec_ok;                      // width % 8 == 0 and every depth pointer aligned for 4-texel loads
+    // hostile[frame] = generation when a texel the LEVELS are made of is outside the range the exact v_rcp_f32 sequences are
+    // verified for (NaN, inf, negative, tiny); read by the later kernels.  (The full-resolution upsample tests the texels it
+    // linearizes itself, per lane.)
     uint32_t *hostile;
     uint32_t generation;
 };
+// a lane of the pass: 4 consecutive LowDepth1 texels (= 8 raw texels of an even row) in rows r, r + 8, ...
+constexpr int kMipTileW = 128, kMipLanesPerRow = kMipTileW / 4, kMipRowsPerPass = 256 / kMipLanesPerRow, kMipRowsPerLane = 2;
+constexpr int kLeanMipW = 64, kLeanMipRows = 16;        // meao_dev_downsample.hpp kLeanW / kLeanRows
 
 // ---------------------------------------------------------------------------------------
 // Render (Render.main_interleaved for all levels in one grid)
@@ -41,9 +47,6 @@ constexpr int ren_tile_w(bool exhaustive) { return exhaustive ? 64 : 128; }
 constexpr int kRenTileH = 32;
 constexpr int kRenTileHSmall = 8;               // calls with fewer 128 x 32 tiles than CUs: four times the workgroups, one texel-loop iteration each
 constexpr int kWideTileW = 64;                                 // Render.main (wide) keeps 64 x 32, 256 threads
-// downsample tile 128 x 32 (A/B against 256 x 16 and 512 x 8: profiles/r02_ab_v20_ds_tile_shape.jsonl) -- 4096 texels, 256 lanes x 4 row passes
-constexpr int kDsTileW = 128, kDsTileH = 4096 / kDsTileW;
-constexpr int kDsLanesPerRow = kDsTileW / 4, kDsRowsPerPass = 256 / kDsLanesPerRow;     // a lane covers 4 texels of a row
 constexpr int kRenApron = 16;                   // 4 slice texels * interleave 4
 constexpr int kRenLdsH = kRenTileH + 2 * kRenApron;            // rows of the staged window; columns: tile width + 2 * apron
 
@@ -93,7 +96,7 @@ struct UpsampleArgs {
     const float *lo_depth;     // LoResDB  f32
     const void *lo_ao;         // LoResAO1
     const void *lo_ao2;        // LoResAO2 of main_premin* (min-combined in PrefetchData), or nullptr
-    const void *hi_depth;      // HiResDB  f32, or f16 in the final pass
+    const void *hi_depth;      // HiResDB  f32 (blend passes); unused in the final pass, which linearizes the raw depth itself (HiDepthArgs)
     const void *hi_ao;         // HiResAO, nullptr in the final pass
     void *dst[MEAO_MAX_BATCH]; // per-frame destination (caller-owned in the final pass)
     uint64_t frame_stride;     // applies to lo_*, hi_* (context-owned intermediates)
@@ -103,9 +106,20 @@ struct UpsampleArgs {
     float noise_filter_strength, step_size, blur_tolerance, upsample_tolerance;
     int32_t f16_rtne;
     int32_t exact_rcp_div;     // operands proven inside the exact range of the v_rcp_f32 sequences
-    int32_t vec_ok;            // hw % 4 == 0 and, in the final pass, every dst pointer aligned for 4-texel stores
+    int32_t vec_ok;            // hw % 4 == 0 and, in the final pass, every dst and raw depth pointer aligned for 4-texel accesses
     const uint32_t *hostile;   // as in RenderArgs
     uint32_t generation;
+};
+
+// Final pass (Upsample.main): HiResDB = LinearZ = f16(Linearize(depth)) (DS1:37-48, UPS:217-223) is evaluated from the caller's raw
+// depth frame inside the bilateral phase -- same reciprocal sequence, same f16 round trip, hostile texels divided with IEEE '/'
+// per lane -- instead of being read back from a LinearDepth buffer nothing else reads.  UpsampleArgs::vec_ok then also says
+// that every raw[] pointer is aligned for 4-texel loads.
+struct HiDepthArgs {
+    const void *raw[MEAO_MAX_BATCH];   // caller-owned raw depth of the frames being upsampled
+    int32_t depth_format;              // meao_depth_format
+    int32_t reversed_z;
+    float zp0, zp1;                    // ZBufferParams.xy
 };
 
 // ---------------------------------------------------------------------------------------
@@ -119,17 +133,10 @@ struct TileAtlasArgs {
 };
 
 hipError_t launch_downsample(const DownsampleArgs &a, int frames, hipStream_t s);
-// The pass as its own kernel meant to co-run with the full-resolution upsample launch from a second stream: tiles of
-// 128 x 8 * a.row_passes texels (row_passes 4, 8 or 16 loads in flight per lane), optionally declaring 120 VGPRs.
-hipError_t launch_downsample_side(const DownsampleArgs &a, int frames, bool pad_vgprs, hipStream_t s);
 hipError_t launch_render(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
 hipError_t launch_render_wide(const RenderArgs &a, int ao_format, int frames, hipStream_t s);
-// Render with its windows filled from the raw depth frames of `d` (f32, 36-sample set) instead of LowDepth<level>; with_downsample:
-// the same launch runs the downsample pass `d` describes as extra workgroups (meao_k_render_depth.hip).
-hipError_t launch_render_from_depth(const RenderArgs &a, const DownsampleArgs &d, bool with_downsample, int ao_format, int frames,
-                                    hipStream_t s);
-hipError_t launch_upsample(const UpsampleArgs &a, int ao_format, bool hi_depth_f16, int frames,
-                           hipStream_t s);
+// hi: the raw depth frames of the final pass (Upsample.main), nullptr = a blend pass (main_blendout)
+hipError_t launch_upsample(const UpsampleArgs &a, const HiDepthArgs *hi, int ao_format, int frames, hipStream_t s);
 // Two blend passes in one launch: `inner` (e.g. L4 -> L3) is evaluated per tile of `outer` (L3 -> L2) for the
 // window of its output that the tile reads; inner's target is still written (each tile stores its own part).
 hipError_t launch_upsample_two_level(const UpsampleArgs &outer, const UpsampleArgs &inner, int ao_format, int frames,
@@ -137,13 +144,21 @@ hipError_t launch_upsample_two_level(const UpsampleArgs &outer, const UpsampleAr
 // one or two frames per call: L4->L3 and L3->L2 inside the L2->L1 launch (outer = L2->L1, mid = L3->L2, inner = L4->L3)
 hipError_t launch_upsample_three_level(const UpsampleArgs &outer, const UpsampleArgs &mid, const UpsampleArgs &inner, int ao_format,
                                        int frames, hipStream_t s);
-// Upsample.main of this batch + the downsample pass of the next one in a single kernel.
-hipError_t launch_upsample_final_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format,
+// Upsample.main of this batch + the downsample pass of the next one in a single kernel (f32 depth, d.vec_ok, one carried
+// tile per upsample tile: fused_downsample_applicable).
+bool fused_downsample_applicable(const UpsampleArgs &a, const HiDepthArgs &hi, const DownsampleArgs &d, int frames);
+hipError_t launch_upsample_final_with_downsample(const UpsampleArgs &a, const HiDepthArgs &hi, const DownsampleArgs &d, int ao_format,
                                                  int frames, hipStream_t s);
-// Upsample.main_blendout (L2 -> L1) carrying downsample tiles [0, d.tile_end) of the next batch.
-hipError_t launch_upsample_blend_with_downsample(const UpsampleArgs &a, const DownsampleArgs &d, int ao_format, int frames,
-                                                 hipStream_t s);
 hipError_t launch_tile_atlas(const TileAtlasArgs &a, hipStream_t s);
+// LinearDepth (debug id 1) on demand: dst[i] = f16(Linearize(depth[i])) for one frame (DS1:37-48).
+struct LinearDepthArgs {
+    const void *depth;
+    uint16_t *dst;
+    int64_t pixels;
+    int32_t depth_format, reversed_z, f16_rtne;
+    float zp0, zp1;
+};
+hipError_t launch_linear_depth(const LinearDepthArgs &a, hipStream_t s);
 // Debug view (PushDebugBlitCommands): src in `src_format` (meao_format), [slices][sh][sw] -> dst AO W x H.
 struct DebugViewArgs {
     const void *src;

@@ -44,7 +44,7 @@ def test_product_library_does_not_link_the_oracle():
 
 def test_struct_layouts_match_header():
     # every member is a 4-byte scalar except meao_desc.bytes (u64, naturally aligned)
-    assert C.sizeof(L.Config) == 14 * 4 and C.sizeof(L.Params) == 11 * 4
+    assert C.sizeof(L.Config) == 12 * 4 and C.sizeof(L.Params) == 11 * 4
     assert C.sizeof(L.Desc) == 32 and L.Desc.bytes.offset == 24
     assert C.sizeof(L.RenderConstants) == 28 * 4 and C.sizeof(L.UpsampleConstants) == 8 * 4
     for struct, cname in ((L.Config, "meao_config"), (L.Params, "meao_params"), (L.Desc, "meao_desc")):
@@ -66,7 +66,7 @@ def test_defaults_are_the_reference_defaults(meao_lib):
     assert p.blur_tolerance == np.float32(-4.6) and p.struct_size == C.sizeof(L.Params)
     c = L.Config()
     meao_lib.meao_default_config(C.byref(c))
-    assert (c.num_levels, c.ao_format, c.f16_rounding, c.numerics, c.max_batch) == (4, L.AO_R8, L.F16_RTZ_CLAMP, 0, 1)
+    assert (c.num_levels, c.ao_format, c.f16_rounding, c.max_batch) == (4, L.AO_R8, L.F16_RTZ_CLAMP, 1)
 
 
 def _params(meao_lib, s):
@@ -175,10 +175,8 @@ def test_argument_validation(meao_lib):
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
     bad = L.Config.from_buffer_copy(cfg); bad.sample_set = 2
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
-    bad = L.Config.from_buffer_copy(cfg); bad.launch_mode = 2
+    bad = L.Config.from_buffer_copy(cfg); bad.pipelined = 2
     assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_INVALID_ARGUMENT
-    bad = L.Config.from_buffer_copy(cfg); bad.numerics = 7
-    assert meao_lib.meao_create(C.byref(bad), C.byref(ctx)) == L.ERR_UNSUPPORTED
     assert meao_lib.meao_destroy(None) == 0
     assert meao_lib.meao_execute(None, None, 0, None, 0, None) == L.ERR_INVALID_ARGUMENT
     assert meao_lib.meao_prefetch_batch(None, 1, None) == L.ERR_INVALID_ARGUMENT

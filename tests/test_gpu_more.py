@@ -51,52 +51,6 @@ def test_randomized_configurations(oracle, seed):
         ao.close()
 
 
-@pytest.mark.parametrize("variant", [dict(), dict(hq_levels=2, sample_set=1, ao_format=1)])
-def test_graph_launch_mode(oracle, variant):
-    """MEAO_LAUNCH_GRAPH: captured once per (pointers, parameters), replayed afterwards; a property
-    change, a resize and new pointers each force a new capture; more pointer sets than the context
-    keeps (8) evict the oldest.  Results stay bit-exact throughout."""
-    import torch
-    dev = torch.device("cuda", 0)
-    w, h = 322, 182
-    s = H.settings(oracle, w, h, **variant)
-    ao = H.component(s, launch_mode=L.LAUNCH_GRAPH)
-    dt = torch.uint8 if s.ao_format == 0 else torch.int16
-    try:
-        frames = [synth.make("S2", w, h, seed=40 + k) for k in range(10)]
-        wants = [oracle.run(f, s, result_only=True)["result"] for f in frames]
-        d_in = [torch.from_numpy(f).to(dev) for f in frames]
-        d_out = [torch.zeros((h, w), dtype=dt, device=dev) for _ in frames]
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        for rep in range(3):                                   # 10 pointer sets > 8 cached graphs
-            for k in range(10):
-                d_out[k].zero_()
-                ao.execute_device([d_in[k].data_ptr()], [d_out[k].data_ptr()], stream)
-            torch.cuda.synchronize(dev)
-            for k in range(10):
-                got = d_out[k].cpu().numpy().view(wants[k].dtype)
-                assert np.array_equal(got, wants[k]), (rep, k)
-        for i in H.valid_debug_ids(s.num_levels, s.hq_levels):    # intermediates of the last replay (frame 9)
-            assert np.array_equal(ao.debug_buffer(i), oracle.run(frames[9], s)[H.NAMES[i]]), i
-        ao.intensity = 0.5                                     # CheckPropertiesChanged -> graphs dropped
-        s2 = H.settings(oracle, w, h, intensity=0.5, **variant)
-        for rep in range(2):
-            ao.execute_device([d_in[0].data_ptr()], [d_out[0].data_ptr()], stream)
-            torch.cuda.synchronize(dev)
-            assert np.array_equal(d_out[0].cpu().numpy().view(wants[0].dtype), oracle.run(frames[0], s2, result_only=True)["result"])
-        ao.resize(130, 70)                                     # screen-size change
-        s3 = H.settings(oracle, 130, 70, intensity=0.5, **variant)
-        ao.projection00 = s3.proj00
-        small = synth.make("S2", 130, 70, seed=3)
-        for rep in range(2):                                   # host path: staging pointers are stable -> replay
-            assert np.array_equal(ao.render(small), oracle.run(small, s3, result_only=True)["result"])
-        ao.set_profiling(True)                                 # profiling falls back to direct launches
-        assert np.array_equal(ao.render(small), oracle.run(small, s3, result_only=True)["result"])
-        assert ao.pass_times_ms()[1] == 1
-    finally:
-        ao.close()
-
-
 def test_device_pointers_and_streams_with_torch(oracle):
     """The path bench.py uses: torch owns device memory and the stream, the library gets raw
     addresses; batched, asynchronous, results identical to the host-pointer path."""
@@ -199,30 +153,6 @@ def test_8k_fp16_full_frame(oracle):
     finally:
         ao.close()
     assert np.array_equal(got, want), H.diff_report("result", got, want)
-
-
-@pytest.mark.parametrize("ao_format", [0, 1])
-def test_fast_numerics_stays_within_one_storage_step(oracle, ao_format):
-    """MEAO_NUMERICS_FAST (raw v_rcp_f32 divides) is NOT the parity path; it must stay within one
-    storage step of STRICT on almost every texel: R8 -> |diff| <= 1 code on < 1 % of texels;
-    F16 -> exact on > 99 %, the rest within a few fp16 ulps (a 1-ulp weight difference can flip a
-    CompareDeltas decision or a truncation in a later pass; measured: 0.45 % of texels, max 4 ulps)."""
-    from miniengineao_amd import AmbientOcclusion
-    w, h = 1280, 720
-    depth = synth.make("S2", w, h, seed=123)
-    s = H.settings(oracle, w, h, ao_format=ao_format)
-    want = oracle.run(depth, s, nthreads=8, result_only=True)["result"].astype(np.int64)
-    ao = AmbientOcclusion(w, h, ao_format=ao_format, numerics=L.NUMERICS_FAST, near_clip=s.near_clip,
-                          far_clip=s.far_clip, projection00=s.proj00)
-    try:
-        got = ao.render(depth).astype(np.int64)
-    finally:
-        ao.close()
-    diff = np.abs(got - want)               # f16 bit patterns of positive values are ordered like ints
-    if ao_format == 0:
-        assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
-    else:
-        assert diff.max() <= 8 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
 
 
 @pytest.mark.parametrize("variant", [dict(), dict(ao_format=1, f16_rounding=1), dict(hq_levels=1, num_levels=3)])
@@ -372,77 +302,6 @@ def test_both_render_tilings_are_bit_exact(oracle, small_tiles, variant, w, h, b
         ao.close()
 
 
-@pytest.mark.parametrize("form", [1, 2])
-@pytest.mark.parametrize("small_tiles", [0, 1000000])
-@pytest.mark.parametrize("w,h,batch,variant", [
-    (203, 117, 1, dict()), (640, 360, 2, dict()), (1921, 1081, 1, dict()), (515, 301, 1, dict(ao_format=1, f16_rounding=1)),
-    (322, 182, 3, dict(ao_format=1)), (256, 128, 2, dict(num_levels=2)), (131, 77, 1, dict(num_levels=1)), (37, 29, 1, dict()),
-    (1280, 720, 1, dict(hq_levels=2)), (644, 364, 1, dict(numerics=1))])
-def test_render_from_the_raw_depth_frame_is_bit_exact(oracle, form, small_tiles, w, h, batch, variant):
-    """One frame per call (AmbientOcclusion.cs:329-347): render_tile<FROM_DEPTH> fills its windows from the caller's depth frame
-    (Linearize + f16 round trip + padding inside the tile) -- form 1: the downsample pass as extra workgroups of the same launch,
-    form 2: both launches on two streams.  Every buffer of every frame, one of them hostile, against the oracle; both render
-    tilings; R8 / F16, RTZ / RTNE, 1-4 levels, the wide-render variant behind it, widths that are not multiples of 4."""
-    numerics = variant.get("numerics", 0)
-    variant = {k: v for k, v in variant.items() if k != "numerics"}
-    debug = {L.DEBUG_RENDER_FROM_DEPTH: form, L.DEBUG_RENDER_SMALL_MAX_TILES: small_tiles, L.DEBUG_DS_SMALL_MAX_TILES: small_tiles}
-    s = H.settings(oracle, w, h, **variant)
-    frames = [synth.make("S2", w, h, seed=90 + f) for f in range(batch)]
-    frames[-1] = H.hostile_frame(w, h, 79, density=0.01)
-    if numerics:            # MEAO_NUMERICS_FAST has no oracle: it must at least equal its own stored-mip form
-        a = H.component(s, max_batch=batch, numerics=numerics, debug=debug)
-        b = H.component(s, max_batch=batch, numerics=numerics, debug={L.DEBUG_RENDER_FROM_DEPTH: 0})
-        try:
-            clean = [synth.make("S2", w, h, seed=90 + f) for f in range(batch)]
-            for x, y in zip(a.render_batch(clean), b.render_batch(clean)):
-                assert np.array_equal(x, y)
-            for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
-                assert np.array_equal(a.debug_buffer(i), b.debug_buffer(i)), H.NAMES[i]
-        finally:
-            a.close()
-            b.close()
-        return
-    ao = H.component(s, max_batch=batch, debug=debug)
-    try:
-        for _ in range(2):
-            outs = ao.render_batch(frames)
-            for f in range(batch):
-                want = oracle.run(frames[f], s)
-                ok, bad = H.nan_aware_equal(outs[f], want["result"])
-                assert ok, (f, int(bad.sum()))
-                for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
-                    ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
-                    assert ok, (H.NAMES[i], f, int(bad.sum()))
-    finally:
-        ao.close()
-
-
-@pytest.mark.parametrize("form", [1, 2])
-def test_render_from_depth_inside_a_captured_launch_sequence(oracle, form):
-    """MEAO_LAUNCH_GRAPH with the raw-depth render: the captured sequence is the one-launch form (form 2 would fork to a second
-    stream; a captured sequence stays on one) and replays bit-exactly, hostile frame included."""
-    import torch
-    dev = torch.device("cuda", 0)
-    w, h = 644, 364
-    s = H.settings(oracle, w, h)
-    frames = [synth.make("S2", w, h, seed=11), H.hostile_frame(w, h, 12, density=0.004)]
-    want = [oracle.run(f, s, result_only=True)["result"] for f in frames]
-    dd = [torch.from_numpy(f).to(dev) for f in frames]
-    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in frames]
-    st = torch.cuda.Stream(dev)
-    ao = H.component(s, max_batch=2, launch_mode=L.LAUNCH_GRAPH, debug={L.DEBUG_RENDER_FROM_DEPTH: form})
-    try:
-        for _ in range(3):                      # capture, replay, replay
-            ao.execute_device([t.data_ptr() for t in dd], [t.data_ptr() for t in out], st.cuda_stream)
-            st.synchronize()
-            for f in range(2):
-                ok, bad = H.nan_aware_equal(out[f].cpu().numpy(), want[f])
-                assert ok, (f, int(bad.sum()))
-            assert ao.hostile_frames() == 2
-    finally:
-        ao.close()
-
-
 @pytest.mark.parametrize("variant", [dict(), dict(ao_format=1, f16_rounding=1), dict(num_levels=2), dict(hq_levels=2)])
 @pytest.mark.parametrize("w,h,batch", [(644, 364, 3), (1280, 720, 2), (203, 117, 2), (2048, 1152, 1)])
 def test_l2_to_l1_blend_with_64x64_tiles_is_bit_exact(oracle, variant, w, h, batch):
@@ -521,35 +380,6 @@ def test_profiling_of_selected_passes_only(oracle):
         ao.close()
 
 
-def test_render_from_depth_is_an_option_and_falls_back(oracle):
-    """The default is the stored-mip sequence (a separate downsample launch is timed); RENDER_FROM_DEPTH 3 lets small calls take the
-    one-launch form -- no separate downsample time -- while larger ones and non-f32 depth keep the stored-mip form; results
-    identical either way."""
-    w, h = 640, 360
-    s = H.settings(oracle, w, h)
-    depth = synth.make("S2", w, h, seed=3)
-    want = oracle.run(depth, s, result_only=True)["result"]
-    ao = H.component(s)
-    try:
-        for mode, max_tiles, rides_in_render in ((None, None, False), (3, 1024, True), (3, 1, False), (1, 1, True), (0, 1024, False)):
-            if mode is not None:
-                ao.debug_set(L.DEBUG_RENDER_FROM_DEPTH, mode)
-                ao.debug_set(L.DEBUG_RENDER_FROM_DEPTH_MAX_TILES, max_tiles)
-            ao.set_profiling(True)
-            assert np.array_equal(ao.render(depth), want)
-            ms = dict(zip(L.PASS_NAMES, ao.pass_times_ms()[0]))
-            assert (ms["downsample"] == 0) == rides_in_render and ms["render"] > 0, (mode, max_tiles, ms)
-    finally:
-        ao.close()
-    s16 = H.settings(oracle, w, h, depth_format=oracle.DEPTH_UNORM16)
-    d16 = oracle.encode_depth(depth, oracle.DEPTH_UNORM16)
-    ao = H.component(s16, depth_format=L.DEPTH_UNORM16, debug={L.DEBUG_RENDER_FROM_DEPTH: 1})
-    try:
-        assert np.array_equal(ao.render(d16), oracle.run(d16, s16, result_only=True)["result"])
-    finally:
-        ao.close()
-
-
 # ---- round 2: contract enforcement, robustness of the boundary ------------------------------------
 
 def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
@@ -566,9 +396,7 @@ def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
     db = [torch.from_numpy(f).to(dev) for f in b_frames]
     out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
     s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    # (RENDER_FROM_DEPTH 0: a call this small would otherwise run its own pass inside the render launch, where no separate
-    # downsample time exists to observe)
-    ao = H.component(s, max_batch=2, pipelined=True, debug={L.DEBUG_RENDER_FROM_DEPTH: 0})
+    ao = H.component(s, max_batch=2, pipelined=True)
     try:
         ao.set_profiling(True)
         for consumer in (s2, s1):                      # other stream first, then the carrying stream
@@ -585,33 +413,6 @@ def test_prefetched_downsample_is_not_used_from_another_stream(oracle):
             for f in range(2):
                 assert np.array_equal(out[f].cpu().numpy(), want_b[f]), (f, consumer is s2)
             ao.set_profiling(True)
-    finally:
-        ao.close()
-
-
-def test_graph_replay_after_prefetched_batch_reads_the_right_downsample_set(oracle):
-    """a direct pipelined call leaves ds_cur = 1; a later graph replay writes set 0 and the
-    debug buffers must come from set 0."""
-    import torch
-    dev = torch.device("cuda", 0)
-    w, h = 192, 96
-    s = H.settings(oracle, w, h)
-    f0, f1 = synth.make("S2", w, h, seed=81), synth.make("S1", w, h)
-    want0 = oracle.run(f0, s)
-    d0, d1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
-    out = torch.zeros((h, w), dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream(dev).cuda_stream
-    ao = H.component(s, max_batch=1, launch_mode=L.LAUNCH_GRAPH, pipelined=True)
-    try:
-        ao.execute_device([d0.data_ptr()], [out.data_ptr()], st)       # captured (set 0)
-        ao.prefetch_device([d1.data_ptr()])
-        ao.execute_device([d0.data_ptr()], [out.data_ptr()], st)       # direct: carries d1's downsample into set 1
-        ao.execute_device([d1.data_ptr()], [out.data_ptr()], st)       # direct: consumes set 1 -> ds_cur = 1
-        ao.execute_device([d0.data_ptr()], [out.data_ptr()], st)       # graph replay -> set 0
-        torch.cuda.synchronize(dev)
-        assert np.array_equal(out.cpu().numpy(), want0["result"])
-        for i in (1, 2, 5, 6, 9):
-            assert np.array_equal(ao.debug_buffer(i), want0[H.NAMES[i]]), H.NAMES[i]
     finally:
         ao.close()
 
@@ -683,35 +484,6 @@ def test_tracing_ranges_can_be_switched_on(oracle):
 
 # ---- round 3 ------------------------------------------------------------------------------------------
 
-def test_graph_replay_leaves_the_ieee_bodies_after_a_hostile_frame(oracle):
-    """a captured sequence bakes its hostile-flag generation into the kernel arguments; the flag
-    words are cleared inside the graph, so a replay over clean data is back on the exact-reciprocal bodies
-    (meao_hostile_frames) after a replay over hostile data -- and both are bit-exact."""
-    import torch
-    dev = torch.device("cuda", 0)
-    w, h = 256, 128
-    s = H.settings(oracle, w, h)
-    clean = [synth.make("S2", w, h, seed=300 + f) for f in range(2)]
-    hostile = [H.hostile_frame(w, h, 31, density=0.003), clean[1]]
-    d = [torch.from_numpy(f).to(dev) for f in clean]          # the graph is keyed by these pointers
-    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
-    st = torch.cuda.current_stream(dev).cuda_stream
-    ao = H.component(s, max_batch=2, launch_mode=L.LAUNCH_GRAPH)
-    try:
-        dp, op = [t.data_ptr() for t in d], [t.data_ptr() for t in out]
-        for frames, want_mask in ((clean, 0), (hostile, 1), (clean, 0), (hostile, 1), (clean, 0)):
-            for t, f in zip(d, frames):
-                t.copy_(torch.from_numpy(f))
-            torch.cuda.synchronize(dev)
-            ao.execute_device(dp, op, st)                       # first round captures, the rest replay
-            assert ao.hostile_frames() == want_mask
-            for f in range(2):
-                ok, bad = H.nan_aware_equal(out[f].cpu().numpy(), oracle.run(frames[f], s, result_only=True)["result"])
-                assert ok, (f, int(bad.sum()))
-    finally:
-        ao.close()
-
-
 def test_hostile_frames_mask_in_direct_and_pipelined_calls(oracle):
     import torch
     dev = torch.device("cuda", 0)
@@ -733,133 +505,3 @@ def test_hostile_frames_mask_in_direct_and_pipelined_calls(oracle):
     finally:
         ao.close()
 
-
-@pytest.mark.parametrize("share", [15, 30, 100])
-@pytest.mark.parametrize("w,h,batch", [(512, 256, 2), (1280, 720, 3), (644, 364, 2)])
-def test_carried_downsample_split_between_blend_and_last_kernel(oracle, share, w, h, batch):
-    """MEAO_DEBUG_DS_SHARE_IN_BLEND: part of the next batch's downsample tiles ride in the L2 -> L1 blend launch, the
-    rest in the last kernel; three pipelined steps, every buffer of every frame (one hostile) against the oracle."""
-    import torch
-    dev = torch.device("cuda", 0)
-    s = H.settings(oracle, w, h)
-    seqs = [[synth.make("S2", w, h, seed=900 + 10 * k + f) for f in range(batch)] for k in range(3)]
-    seqs[1][0] = H.hostile_frame(w, h, 55, density=0.002)
-    dd = [[torch.from_numpy(f).to(dev) for f in b] for b in seqs]
-    out = [[torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in b] for b in seqs]
-    st = torch.cuda.current_stream(dev).cuda_stream
-    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_SHARE_IN_BLEND: share, L.DEBUG_RENDER_FROM_DEPTH: 0})
-    try:
-        ao.set_profiling(True)
-        for k in range(3):
-            if k + 1 < 3:
-                ao.prefetch_device([t.data_ptr() for t in dd[k + 1]])
-            ao.execute_device([t.data_ptr() for t in dd[k]], [t.data_ptr() for t in out[k]], st)
-            torch.cuda.synchronize(dev)
-            for f in range(batch):
-                want = oracle.run(seqs[k][f], s)
-                ok, bad = H.nan_aware_equal(out[k][f].cpu().numpy(), want["result"])
-                assert ok, (k, f, int(bad.sum()))
-                for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
-                    ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
-                    assert ok, (H.NAMES[i], k, f, int(bad.sum()))
-            assert ao.hostile_frames() == (1 if k == 1 else 0)
-        ms, n = ao.pass_times_ms()
-        assert n == 3 and ms[0] > 0        # only the first step ran a stand-alone downsample pass
-    finally:
-        ao.close()
-
-
-@pytest.mark.parametrize("mode", [1, 2, 4, 11, 21, 33, 5004, 25014, 3104])
-@pytest.mark.parametrize("w,h,batch", [(512, 256, 2), (1280, 720, 3), (644, 364, 2), (640, 131, 1)])
-def test_next_downsample_on_the_side_stream(oracle, mode, w, h, batch):
-    """MEAO_DEBUG_DS_SIDE_STREAM: the announced batch's downsample pass as its own kernel on the context's second,
-    low-priority stream, released at a gate of the call (1 = in front of the full-resolution launch ... 4 = in front of
-    render), tiles of 128 x 128 / 64 / 32 texels (16 / 8 / 4 loads in flight per lane).  Five steps WITHOUT a host
-    synchronisation between them (the orderings are events between the two streams), a hostile frame, a mispredicted
-    announcement whose stale side kernel writes the set the next call's own pass uses: every buffer against the oracle."""
-    import torch
-    dev = torch.device("cuda", 0)
-    s = H.settings(oracle, w, h)
-    seqs = [[synth.make("S2", w, h, seed=700 + 10 * k + f) for f in range(batch)] for k in range(5)]
-    seqs[1][batch - 1] = H.hostile_frame(w, h, 77, density=0.002)
-    dd = [[torch.from_numpy(f).to(dev) for f in b] for b in seqs]
-    out = [[torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in b] for b in seqs]
-    st = torch.cuda.current_stream(dev).cuda_stream
-    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_SIDE_STREAM: mode})
-    announce = {0: 1, 1: 2, 2: 4, 3: None, 4: None}          # step 2 announces set 4 but set 3 arrives
-    try:
-        for k in range(5):
-            if announce[k] is not None:
-                ao.prefetch_device([t.data_ptr() for t in dd[announce[k]]])
-            ao.execute_device([t.data_ptr() for t in dd[k]], [t.data_ptr() for t in out[k]], st)
-        torch.cuda.synchronize(dev)
-        for k in range(5):
-            for f in range(batch):
-                want = oracle.run(seqs[k][f], s, result_only=(k != 4))
-                ok, bad = H.nan_aware_equal(out[k][f].cpu().numpy(), want["result"])
-                assert ok, (k, f, int(bad.sum()))
-                if k == 4:
-                    for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
-                        ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
-                        assert ok, (H.NAMES[i], f, int(bad.sum()))
-        # steady state with intermediates: the consumer of a side-stream set
-        ao.set_profiling(True)
-        for k in (0, 1):
-            ao.prefetch_device([t.data_ptr() for t in dd[1]])
-            ao.execute_device([t.data_ptr() for t in dd[k]], [t.data_ptr() for t in out[k]], st)
-        torch.cuda.synchronize(dev)
-        for f in range(batch):
-            want = oracle.run(seqs[1][f], s)
-            for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
-                ok, bad = H.nan_aware_equal(ao.debug_buffer(i, frame=f), want[H.NAMES[i]])
-                assert ok, (H.NAMES[i], f, int(bad.sum()))
-        assert ao.hostile_frames() == 1 << (batch - 1)
-        ms, n = ao.pass_times_ms()
-        assert n == 2 and ms[0] > 0        # the side-stream kernel is timed in the downsample slot (events on ITS stream)
-    finally:
-        ao.close()
-
-
-
-def test_side_stream_downsample_survives_resize_params_and_destroy(oracle):
-    """The side-stream kernel of an announced batch may still be running when the host changes its mind: a property change
-    (drops the announcement), a resize (frees the arena it writes) and a destroy right behind the carrying execute must all be
-    safe, and the next results right."""
-    import torch
-    dev = torch.device("cuda", 0)
-    w, h, batch = 1920, 1080, 4
-    s = H.settings(oracle, w, h)
-    frames = [synth.make("S2", w, h, seed=910 + f) for f in range(batch)]
-    dd = [torch.from_numpy(f).to(dev) for f in frames]
-    out = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(batch)]
-    st = torch.cuda.current_stream(dev).cuda_stream
-    dp, op = [t.data_ptr() for t in dd], [t.data_ptr() for t in out]
-    ao = H.component(s, max_batch=batch, pipelined=True, debug={L.DEBUG_DS_SIDE_STREAM: 4})
-    try:
-        ao.prefetch_device(dp)
-        ao.execute_device(dp, op, st)              # side kernel for the announced batch is in flight now
-        ao.intensity = 0.5                         # meao_set_params: the announcement is void
-        s2 = H.settings(oracle, w, h, intensity=0.5)
-        ao.prefetch_device(dp)
-        ao.execute_device(dp, op, st)              # own downsample pass into the set the stale side kernel was writing
-        ao.execute_device(dp, op, st)              # consumer of the second side kernel
-        torch.cuda.synchronize(dev)
-        for f in (0, batch - 1):
-            assert np.array_equal(out[f].cpu().numpy(), oracle.run(frames[f], s2, result_only=True)["result"]), f
-        ao.prefetch_device(dp)
-        ao.execute_device(dp, op, st)
-        ao.resize(w - 64, h - 32)                  # frees the arena the side kernel may still be writing
-        s3 = H.settings(oracle, w - 64, h - 32, intensity=0.5)
-        ao.projection00 = s3.proj00
-        small = [np.ascontiguousarray(f[:h - 32, :w - 64]) for f in frames[:2]]
-        got = ao.render_batch(small)
-        for f in range(2):
-            assert np.array_equal(got[f], oracle.run(small[f], s3, result_only=True)["result"]), f
-        dsm = [torch.from_numpy(f).to(dev) for f in small]
-        osm = [torch.zeros((h - 32, w - 64), dtype=torch.uint8, device=dev) for _ in small]
-        ao.prefetch_device([t.data_ptr() for t in dsm])
-        ao.execute_device([t.data_ptr() for t in dsm], [t.data_ptr() for t in osm], st)
-    finally:
-        ao.close()                                 # destroy with a side kernel in flight
-    torch.cuda.synchronize(dev)
-    assert np.array_equal(osm[1].cpu().numpy(), oracle.run(small[1], s3, result_only=True)["result"])

@@ -60,20 +60,31 @@ def test_hostile_f32_depth_matches_oracle(oracle, w, h, seed, ao_format, f16_rou
     _compare(oracle, s, hostile_frame(w, h, seed))
 
 
-# render windows from the stored depth mips (frame-level hostile flag -> IEEE-division body) / from the raw depth frame, in one
-# launch with the downsample pass or on a second stream (per-texel IEEE division, no flag): meao_debug_set RENDER_FROM_DEPTH
-RENDER_SOURCES = {"stored_mips": 0, "raw_depth_one_launch": 1, "raw_depth_two_streams": 2}
+# Where a hostile texel sits decides who sees it: a texel of the LEVELS (even row and column) is found by the downsample pass, which
+# flags the frame (IEEE-division bodies in every later kernel); any other texel is only ever linearized by the full-resolution
+# upsample, which redoes the lane's texels with IEEE '/' (hi_depth_quad / the cold loop of upsample_tile<FINAL>), no frame flag.
+PLACEMENTS = ("anywhere", "odd_texels_only", "level_texels_only")
+
+
+def _placed(frame, clean, placement):
+    """Keep the hostile texels of `frame` only at the wanted positions (the others come from the clean frame)."""
+    if placement == "anywhere":
+        return frame
+    yy, xx = np.mgrid[0:frame.shape[0], 0:frame.shape[1]]
+    level = ((yy & 1) == 0) & ((xx & 1) == 0)
+    return np.where(level if placement == "level_texels_only" else ~level, frame, clean).astype(np.float32)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("source", sorted(RENDER_SOURCES))
+@pytest.mark.parametrize("placement", PLACEMENTS)
 @pytest.mark.parametrize("kind", ["nan", "pinf", "ninf", "neg", "big", "huge", "nhuge", "denorm", "negzero",
                                   "zero_den", "tiny_den", "one", "zero"])
-def test_each_hostile_value_alone(oracle, kind, source):
-    from miniengineao_amd import _lib as L
+def test_each_hostile_value_alone(oracle, kind, placement):
     w, h = 130, 70
     s = H.settings(oracle, w, h)
-    _compare(oracle, s, hostile_frame(w, h, 11, density=0.004, kinds=[kind]), debug={L.DEBUG_RENDER_FROM_DEPTH: RENDER_SOURCES[source]})
+    clean = synth.make("S2", w, h, seed=11)
+    frame = _placed(hostile_frame(w, h, 11, density=0.02, kinds=[kind]), clean, placement)
+    _compare(oracle, s, frame)
 
 
 @pytest.mark.gpu

@@ -35,11 +35,11 @@ def test_no_kernel_spills_or_uses_scratch(rows):
 HOT = {
     "render_kernel<0, false, 0, false>": (8, 64, 40960),                                   # 4 workgroups of 8 waves per CU
     "render_with_composite_kernel<0, false, 0>": (8, 64, 40960),
-    "upsample_kernel<0, false, true, 0>": (7, 72, 163840 // 7),                             # seven 256-thread workgroups per CU
+    "upsample_final_kernel<0, false, 0, true>": (7, 72, 163840 // 7),                       # seven 256-thread workgroups per CU
     "upsample_final_with_next_downsample_kernel<0, false, 0>": (7, 72, 163840 // 7),
-    "upsample_kernel<0, false, false, 0>": (8, 64, 163840 // 8),
+    "upsample_kernel<0, false, 0>": (8, 64, 163840 // 8),
     "upsample_two_level_kernel<0, false, 0>": (8, 64, 163840 // 8),                       # compiled for 8 waves per SIMD: 4080 workgroups = 1.99 rounds of the slots
-    "downsample_kernel<false, true, 0>": (8, 64, 0),
+    "downsample_kernel<true, 0, 2>": (8, 64, 0),
 }
 
 

@@ -97,8 +97,6 @@ def test_pool_pipelined_step_is_bit_exact(oracle, members):
                               projection00=cam.proj00(w, h), reversed_z=cam.reversed_z, pipelined=True) as pool:
         for m in range(members):
             L.check(lib.meao_set_profiling(pool.member_context(m), 1))
-            # the first step's own downsample pass as a launch of its own (not inside the render launch): its time is asserted below
-            L.check(lib.meao_debug_set(pool.member_context(m), L.DEBUG_RENDER_FROM_DEPTH, 0))
         for k in range(3):
             if k + 1 < 3:
                 pool.prefetch_device([t.data_ptr() for t in dd[k + 1]])
@@ -152,7 +150,7 @@ def test_pool_composite_rides_in_the_owning_members_render_kernel(oracle):
 
 @pytest.mark.gpu
 def test_pool_calls_leave_the_current_device_alone_and_destroy_with_work_in_flight(oracle):
-    """graph-mode members with replays in flight and a waiting composite are destroyed in the order
+    """members with launches in flight and a waiting composite are destroyed in the order
     context first, stream second; pool entry points restore the calling thread's device."""
     torch = pytest.importorskip("torch")
     import ctypes as C
@@ -167,7 +165,7 @@ def test_pool_calls_leave_the_current_device_alone_and_destroy_with_work_in_flig
     torch.cuda.synchronize(dev)
     cfg = L.Config()
     lib.meao_default_config(C.byref(cfg))
-    cfg.width, cfg.height, cfg.max_batch, cfg.launch_mode = w, h, 2, L.LAUNCH_GRAPH
+    cfg.width, cfg.height, cfg.max_batch = w, h, 2
     pool = C.c_void_p()
     L.check(lib.meao_pool_create(C.byref(cfg), (C.c_int32 * 2)(0, 0), 2, C.byref(pool)))
     prm = L.Params()
@@ -175,7 +173,7 @@ def test_pool_calls_leave_the_current_device_alone_and_destroy_with_work_in_flig
     prm.near_clip, prm.far_clip, prm.proj00, prm.reversed_z = cam.near, cam.far, cam.proj00(w, h), 1 if cam.reversed_z else 0
     L.check(lib.meao_pool_set_params(pool, C.byref(prm)))
     dp, op = (C.c_void_p * n)(*[t.data_ptr() for t in dd]), (C.c_void_p * n)(*[t.data_ptr() for t in out])
-    for _ in range(3):       # capture, then replays in flight
+    for _ in range(3):       # launches in flight
         L.check(lib.meao_pool_execute_batch(pool, n, dp, L.MEM_DEVICE, op, L.MEM_DEVICE))
     L.check(lib.meao_pool_composite_enqueue(pool, L.COMPOSITE_MULTIPLY, n, op, (C.c_void_p * n)(*[t.data_ptr() for t in col]), None))
     assert torch.cuda.current_device() == 0

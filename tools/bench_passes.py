@@ -17,9 +17,8 @@ ap.add_argument("--batch", type=int, default=None)
 ap.add_argument("--pipeline", action="store_true")
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--tag", default="")
-ap.add_argument("--ds-share", type=int, default=0, help="MEAO_DEBUG_DS_SHARE_IN_BLEND percent (pipelined only)")
 ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
-                help="meao_debug_set before the run, e.g. DS_SIDE_STREAM=1 (repeatable)")
+                help="meao_debug_set before the run, e.g. BLEND_TALL_MIN_TILES=0 (repeatable)")
 a = ap.parse_args()
 w, h, kind, cam, intensity, ao_format, _ = WORKLOADS[a.workload]
 B = a.batch or max(1, (3840 * 2160 * 16) // (w * h))
@@ -30,8 +29,6 @@ out = [torch.empty((h, w), dtype=torch.uint8 if ao_format == _lib.AO_R8 else tor
 ao = AmbientOcclusion(w, h, num_levels=4, ao_format=ao_format, max_batch=B, near_clip=cam.near, far_clip=cam.far,
                       projection00=cam.proj00(w, h), reversed_z=cam.reversed_z, pipelined=a.pipeline)
 ao.intensity = intensity
-if a.ds_share:
-    ao.debug_set(_lib.DEBUG_DS_SHARE_IN_BLEND, a.ds_share)
 for kv in a.debug_set:
     key, value = kv.split("=")
     ao.debug_set(getattr(_lib, "DEBUG_" + key), int(value))
@@ -63,6 +60,6 @@ if a.check:
         want = O.run(frames[f], s, nthreads=O.host_cores(), result_only=True)["result"]
         ok = ok and bool(np.array_equal(out[f].cpu().numpy().view(want.dtype), want))
     res["ok"] = ok
-res["tag"] = (a.tag or os.path.basename(os.environ.get("MEAO_LIB_PATH", "product"))) + (f"+share{a.ds_share}" if a.ds_share else "") + \
+res["tag"] = (a.tag or os.path.basename(os.environ.get("MEAO_LIB_PATH", "product"))) + \
     "".join("+" + kv for kv in a.debug_set)
 print(json.dumps(res), flush=True)

@@ -13,7 +13,6 @@ cp gpurun_out/fuzz_$T.log profiles/${T}_fuzz_gpu.log
 cp gpurun_out/pytest_gpu_$T.log profiles/${T}_pytest_gpu.log
 cp gpurun_out/ubench_issue_$T.txt profiles/${T}_ubench_issue.txt
 cp gpurun_out/ubench_lds_$T.txt profiles/${T}_ubench_lds.txt
-[ -f gpurun_out/bench_${T}_side_stream4.json ] && cp gpurun_out/bench_${T}_side_stream4.json profiles/${T}_bench_4k_side_stream4.json
 [ -f gpurun_out/bench_${T}_two_ranks_one_frame_each_gloo.log ] && grep '^{' gpurun_out/bench_${T}_two_ranks_one_frame_each_gloo.log > profiles/${T}_bench_4k_two_ranks_one_frame_each_gloo.json
 [ -f gpurun_out/pool_enqueue_cost_$T.jsonl ] && cp gpurun_out/pool_enqueue_cost_$T.jsonl profiles/${T}_pool_enqueue_cost_worker_threads.jsonl
 for f in pool2 pool3; do [ -f gpurun_out/bench_${T}_$f.log ] && grep '^{' gpurun_out/bench_${T}_$f.log > profiles/${T}_bench_4k_$f.json; done

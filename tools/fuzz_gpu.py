@@ -57,9 +57,6 @@ for k in range(count):
                           pipelined=bool(k % 2))
     ao.noiseFilterTolerance, ao.blurTolerance, ao.upsampleTolerance = s.noise_filter_tolerance, s.blur_tolerance, s.upsample_tolerance
     ao.thicknessModifier, ao.intensity = s.thickness_modifier, s.intensity
-    if k % 3 == 2:          # a third of the cases: render windows from the RAW depth frame (one launch with the pass / two streams)
-        from miniengineao_amd import _lib
-        ao.debug_set(_lib.DEBUG_RENDER_FROM_DEPTH, 1 + (k // 3) % 2)
     if k % 7 == 3:          # a seventh of the cases: the L2 -> L1 pass on 64 x 64 tiles whatever the size (large R8 batches take them by default)
         from miniengineao_amd import _lib
         ao.debug_set(_lib.DEBUG_BLEND_TALL_MIN_TILES, 1)
@@ -76,10 +73,6 @@ for k in range(count):
         d_in = [torch.from_numpy(raw_bytes.copy()).cuda() for _ in range(2)]
         d_out = [torch.zeros((h, w), dtype=torch.uint8 if s.ao_format == 0 else torch.int16, device="cuda") for _ in range(2)]
         pin, pout = [t.data_ptr() for t in d_in], [t.data_ptr() for t in d_out]
-        if k % 2 == 0:      # half of these cases: the announced downsample pass on the side stream, random gate / shape / split
-            from miniengineao_amd import _lib
-            gate, shape = int(rng.integers(1, 5)), int(rng.integers(0, 5))
-            ao.debug_set(_lib.DEBUG_DS_SIDE_STREAM, gate + 10 * shape + 1000 * int(rng.integers(0, 10)))
         ao.prefetch_device(pin)
         ao.execute_device(pin, pout)
         ao.execute_device(pin, pout)

@@ -5,8 +5,8 @@ property, the kernels' durations are not what is measured.
 
     python tools/pool_enqueue_cost.py [--members 8] [--workload 4k] [--steps 200]
 
-Per launch structure -- DIRECT (4-5 kernel launches per member and step), DIRECT pipelined (meao_pool_prefetch_batch +
-execute: 3-4 launches), MEAO_LAUNCH_GRAPH (one hipGraphLaunch per member) -- prints: host microseconds per step spent
+Per launch structure -- direct (4-5 kernel launches per member and step), pipelined (meao_pool_prefetch_batch +
+execute: 3-4 launches) -- prints: host microseconds per step spent
 inside meao_pool_prefetch_batch + meao_pool_execute_batch WITHOUT synchronising (queues drained first, `steps` steps
 enqueued back to back; the HIP queue depth bounds how far the host can run ahead, so the figure is taken over the first
 steps only as well), the same per member, and the GPU time of one member's frame for comparison: one host thread can
@@ -31,8 +31,7 @@ frames = [torch.from_numpy(make_frame(kind, w, h, frame_seed(0x1234ABCD, g), g))
 outs = [torch.empty((h, w), dtype=torch.uint8 if ao_format == _lib.AO_R8 else torch.int16, device=dev) for _ in range(G)]
 dp, op = [t.data_ptr() for t in frames], [t.data_ptr() for t in outs]
 rows = []
-for name, kw, prefetch in (("direct", {}, False), ("direct_pipelined", {"pipelined": True}, True),
-                           ("graph", {"launch_mode": _lib.LAUNCH_GRAPH}, False)):
+for name, kw, prefetch in (("direct", {}, False), ("direct_pipelined", {"pipelined": True}, True)):
     pool = AmbientOcclusionPool(w, h, [0] * G, max_batch=1, ao_format=ao_format, near_clip=cam.near, far_clip=cam.far,
                                 projection00=cam.proj00(w, h), reversed_z=cam.reversed_z, intensity=intensity, **kw)
 

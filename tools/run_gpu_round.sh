@@ -7,7 +7,6 @@ timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2
 ( time timeout 600 python bench.py --steps 20 --warmup 5 ) 2> gpurun_out/bench_${TAG}_time.log | grep '^{' > gpurun_out/bench_$TAG.json
 timeout 600 python bench.py --workload 1080p --no-other-workloads 2>/dev/null | grep '^{' > gpurun_out/bench_${TAG}_1080p.json
 timeout 600 python bench.py --workload 8k --no-other-workloads 2>/dev/null | grep '^{' > gpurun_out/bench_${TAG}_8k.json
-timeout 600 python bench.py --side-stream 4 --no-cpu-baseline --no-other-workloads --no-best-host-config --skip-latency 2>/dev/null | grep '^{' > gpurun_out/bench_${TAG}_side_stream4.json
 timeout 600 python bench.py --gpus 2 --dist-backend gloo --batch 1 --no-cpu-baseline --skip-latency --no-copy-ceiling > gpurun_out/bench_${TAG}_two_ranks_one_frame_each_gloo.log 2>&1
 timeout 300 python tools/pool_enqueue_cost.py > gpurun_out/pool_enqueue_cost_$TAG.jsonl 2>/dev/null
 timeout 600 python bench.py --pool 2 > gpurun_out/bench_${TAG}_pool2.log 2>&1
