@@ -406,6 +406,9 @@ typedef enum meao_debug_key {
     MEAO_DEBUG_FINAL_SMALL_MAX_TILES = 3, MEAO_DEBUG_DS_SMALL_MAX_TILES = 4,
     MEAO_DEBUG_BLEND_TALL_MIN_TILES = 5, /* L2 -> L1 blend launches of at least this many 64x32 tiles (frames x tiles) use 64x64 tiles, either AO
                                           * storage format; 0 = never.  Default: 4096, R8 storage only */
+    MEAO_DEBUG_NEXT_DOWNSAMPLE_OWN_LAUNCH = 7, /* 1 = the announced next batch's downsample pass (meao_prefetch_batch) runs as a launch of its own
+                                               * behind the last upsample kernel instead of inside it (what frames that do not take the
+                                               * carried tile's 16-byte loads get anyway); default 0 */
     MEAO_DEBUG_PROFILE_PASS_MASK = 6     /* meao_set_profiling: bit k set = launch slot k (meao_pass) is bracketed with events; 0 = all (default).
                                           * Each event record is a marker packet between two launches (1 - 4 % of a batched step for all
                                           * eight): a host that wants one kernel's duration in a throughput run asks for that slot only */

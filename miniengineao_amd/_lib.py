@@ -43,7 +43,7 @@ DEBUG_OCCLUSION_HQ1 = 18
 # meao_debug_key (ABI 6: the keys of the launch structures that lost every A/B are gone; fault injection -- meao_test_fail_next_allocs --
 # exists only in the `testhooks` variant library, built with -DMEAO_TESTING=1)
 (DEBUG_FUSE_COARSE_BLEND, DEBUG_NESTED_MAX_TILES, DEBUG_RENDER_SMALL_MAX_TILES, DEBUG_FINAL_SMALL_MAX_TILES,
- DEBUG_DS_SMALL_MAX_TILES, DEBUG_BLEND_TALL_MIN_TILES, DEBUG_PROFILE_PASS_MASK) = range(7)
+ DEBUG_DS_SMALL_MAX_TILES, DEBUG_BLEND_TALL_MIN_TILES, DEBUG_PROFILE_PASS_MASK, DEBUG_NEXT_DOWNSAMPLE_OWN_LAUNCH) = range(8)
 POOL_PATH_SAME_DEVICE, POOL_PATH_PEER_DIRECT, POOL_PATH_STAGED = 0, 1, 2
 NUM_BUFFERS = 21
 

@@ -83,6 +83,9 @@ struct meao_ctx {
     // (profiles/r05_ab_blend_tall.jsonl).  MEAO_DEBUG_BLEND_TALL_MIN_TILES overrides it for both storage formats.
     int blend_tall_min_tiles = 4096;
     bool blend_tall_forced = false;
+    // The announced next batch's downsample pass (meao_prefetch_batch) always as a launch of its own behind the last kernel instead of
+    // inside it (MEAO_DEBUG_NEXT_DOWNSAMPLE_OWN_LAUNCH; what calls whose frames do not take the carried tile's 16-byte loads do anyway)
+    bool next_ds_own_launch = false;
 
     // a composite batch waiting to ride inside the next execute's render kernel (meao_composite_enqueue),
     // and the stream its AO frames were produced on (where a flush that is not given a stream runs it)
@@ -347,7 +350,7 @@ struct BatchShape {           // what the structure of a call depends on
     int frames;
     bool prefetched;          // an earlier call carried this batch's downsample pass
     bool carry_composite;     // a composite batch waits for a render launch to ride in
-    int next;                 // 0 = nothing announced; 1 = the announced pass rides in the final kernel; 2 = it runs as its own launch
+    int next;                 // 0 = nothing announced; the announced pass 1 = rides in the final kernel, 2 = runs as its own launch
 };
 
 LaunchList plan_launches(const meao_ctx *ctx, const BatchShape &b)
@@ -580,6 +583,8 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
     const ArgBuilder args{ctx, n, depth_dev, out_dev, ctx->hostile_of(ctx->ds_cur), ctx->set_gen[ctx->ds_cur]};
     // The announced next batch: its pass rides in this call's last kernel where the fused form applies (f32 depth, 16-byte
     // loads, a workgroup per carried tile), else it runs as a launch of its own behind it.  Either way the next call finds it done.
+    // (Inside the render launch instead -- CarriedMips in the texel loop, round 6 -- it costs the same 56-60 us per 16 4K frames:
+    // profiles/r06_ab_next_downsample_in_render_vs_final_vs_own_launch.jsonl, r06_scripts/r06_downsample_in_render.patch.)
     const int other = 1 - ctx->ds_cur;
     DownsampleArgs next_ds{};
     UpsampleArgs final_up = args.upsample(0);
@@ -588,7 +593,7 @@ int run_batch(meao_ctx *ctx, int n, const void *const *depth_dev, void *const *o
         ctx->set_gen[other] = next_generation(ctx);
         next_ds = args.downsample(ctx->next_n, ctx->next_depth, other, ctx->set_gen[other], true, false);
         const UpsampleArgs carrying = args.upsample(0, true);
-        if (fused_downsample_applicable(carrying, hi_depth, next_ds, n)) {
+        if (!ctx->next_ds_own_launch && fused_downsample_applicable(carrying, hi_depth, next_ds, n)) {
             shape.next = 1;
             final_up = carrying;
         } else {
@@ -1299,6 +1304,7 @@ int32_t meao_debug_set(meao_ctx *ctx, int32_t key, int32_t value)
     case MEAO_DEBUG_RENDER_SMALL_MAX_TILES: ctx->render_small_max_tiles = value; break;
     case MEAO_DEBUG_FINAL_SMALL_MAX_TILES: ctx->final_small_max_tiles = value; break;
     case MEAO_DEBUG_DS_SMALL_MAX_TILES: ctx->ds_small_max_tiles = value; break;
+    case MEAO_DEBUG_NEXT_DOWNSAMPLE_OWN_LAUNCH: ctx->next_ds_own_launch = value != 0; break;
     case MEAO_DEBUG_PROFILE_PASS_MASK: ctx->profile_mask = value == 0 ? ~0u : static_cast<uint32_t>(value); break;
     case MEAO_DEBUG_BLEND_TALL_MIN_TILES:
         ctx->blend_tall_min_tiles = value <= 0 ? 0x7fffffff : value;

@@ -293,8 +293,10 @@ def test_oracle_matches_the_reference_text_at_baseline_sizes(oracle, name):
 @pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("name", R.CHECKSUM_CASES)
 def test_gpu_matches_the_reference_text_at_baseline_sizes(name, pipelined):
-    """The default launch structures at BASELINE's sizes (config 2's 1080p atrium frame, the metric's 4K frame; one call; and the pipelined path: the frame's downsample pass
-    carried by the previous call's last kernel) against what the reference's text produced -- no oracle in the loop."""
+    """The default launch structures at BASELINE's sizes (config 2's 1080p atrium frame, the metric's 4K frame, and -- round 6 -- two
+    1080p frames with fp16 AO storage, BASELINE config 5's storage mode, in either f16 rounding; one call; and the pipelined path:
+    the frame's downsample pass carried by the previous call's last kernel) against what the reference's text produced -- no
+    oracle in the loop."""
     import torch
     from oracle import oracle as O
     fx, depth, s = _checksum_case(O, name)
@@ -307,13 +309,14 @@ def test_gpu_matches_the_reference_text_at_baseline_sizes(name, pipelined):
             dev = torch.device("cuda", 0)
             other = R.make_depth("S2", s.width, s.height, 99, R.CASES[name][4], False)
             d = [torch.from_numpy(other).to(dev), torch.from_numpy(depth).to(dev)]
-            out = [torch.zeros((s.height, s.width), dtype=torch.uint8, device=dev) for _ in range(2)]
+            elem = torch.uint8 if s.ao_format == O.AO_R8 else torch.int16
+            out = [torch.zeros((s.height, s.width), dtype=elem, device=dev) for _ in range(2)]
             st = torch.cuda.Stream(dev)
             for k in range(2):          # the second call consumes the downsample pass the first one carried
                 ao.prefetch_device([t.data_ptr() for t in d])
                 ao.execute_device([t.data_ptr() for t in d], [t.data_ptr() for t in out], st.cuda_stream)
             st.synchronize()
-            got, frame = out[1].cpu().numpy(), 1
+            got, frame = out[1].cpu().numpy().view(np.uint8 if s.ao_format == O.AO_R8 else np.uint16), 1
         assert np.array_equal(got, fx["result"]), H.diff_report("result", got, fx["result"])
         for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
             assert np.uint64(H.checksum(ao.debug_buffer(i, frame=frame))) == fx["checksum_" + H.NAMES[i]], H.NAMES[i]
