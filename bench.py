@@ -32,10 +32,18 @@ import torch  # before libmeao_hip.so: both then share torch's libamdhip64 (see 
 
 from miniengineao_amd import AmbientOcclusion, AmbientOcclusionPool, _lib, synth
 from miniengineao_amd import distributed as mdist
+from miniengineao_amd import topology
 from miniengineao_amd.sharding import frame_checksum, frame_seed, frames_for_rank
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 HBM_COPY_CEILING_GBPS = 6290.0
+# VALU issue roof (MI355X_MICROARCH.md chip table): 256 CUs x 4 SIMDs, one wave64 v_fma_f32 per 2 cycles and SIMD, 2.4 GHz spec clock
+# (the clock a kernel really ran at is a few percent lower: GRBM_GUI_ACTIVE / 8 / duration of the PMC passes says ~2.3 GHz under
+# the render kernel; the SPEC clock is used here, so valu_frac is a lower bound of the issue-slot use)
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0
+# What the instruction mix of the north-star sub-path allows at best (tools/ubench_issue.hip): ~380 M VALU
+# wave-instructions per 16 4K frames, every one needed for a bit-exact result, issuing at 2.4 - 2.7 cycles each if nothing ever waited
+SUBPATH_VALU_FLOOR_FRAC_OF_HBM_ROOFLINE = 0.38
 
 WORKLOADS = {
     # name: (W, H, generator, camera, intensity, ao_format, description)
@@ -101,6 +109,21 @@ def cpu_baseline(w, h, cam, intensity, ao_format, depth, budget_s=20.0):
                     "kernel quality is judged by the roofline fraction, not by the GPU / CPU ratio"}
 
 
+_CODE_SHA = []
+
+
+def loaded_code_sha256() -> str:
+    if not _CODE_SHA:
+        from miniengineao_amd import codehash
+        _CODE_SHA.append(codehash.device_code_sha256(_lib.LIB_PATH))
+    return _CODE_SHA[0]
+
+
+def traffic_bytes(traffic):
+    """Bytes of a pmc_traffic() record, None when there is none or it belongs to another build."""
+    return traffic["bytes"] if traffic and not traffic.get("stale") and traffic.get("bytes") else None
+
+
 def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
     """HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes
     (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate runs by
@@ -111,7 +134,14 @@ def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
     try:
         table = json.load(open(path))
         row = table[workload][kernel]
-        out = {"bytes": int(row["bytes_per_frame"] * frames_per_launch),
+        # the counters belong to ONE build of the kernels: the device code (.hip_fatbin) they were collected from is hashed into the
+        # file; a library whose device code differs gets no traffic figure from it
+        measured_on = table.get("_code_sha256", {}).get(workload)
+        if measured_on != loaded_code_sha256():
+            return {"stale": True, "bytes": None,
+                    "source": f"profiles/pmc_traffic.json holds counters of device code {str(measured_on)[:12]}..., the loaded library is "
+                              f"{loaded_code_sha256()[:12]}...: not applicable to this build (re-run tools/run_pmc.sh + tools/make_pmc_traffic.py)"}
+        out = {"stale": False, "bytes": int(row["bytes_per_frame"] * frames_per_launch),
                "source": f"committed PMC pass {table.get('_tags', {}).get(workload, table.get('_tag', '(untagged)'))} in profiles/pmc_traffic.json -- "
                          "separate rocprofv3 --pmc runs, NOT measured in this run",
                "note": row.get("note", "")}
@@ -129,8 +159,13 @@ def pmc_traffic(workload: str, kernel: str, frames_per_launch: int):
 PASS_EVENT_PERIOD = 1
 
 
-def pass_table(ao, pass_ms, B, pipelined):
-    """Per-launch roofline rows: algorithmic bytes of what each launch carries / its HIP-event duration."""
+PMC_ROW_OF = {"upsample_L2_to_L1": "upsample_blend_passes", "upsample_L3_to_L2": "upsample_blend_passes", "upsample_L4_to_L3": "upsample_blend_passes"}
+
+
+def pass_table(ao, pass_ms, B, pipelined, workload=None, ceiling_gbps=None):
+    """Per-launch roofline rows: algorithmic bytes of what each launch carries / its HIP-event duration; with `workload`, next
+    to them the VALU issue fraction (committed SQ_INSTS_VALU of the launch / its duration / the VALU issue roof), the fraction of
+    the copy ceiling its moved bytes reach, and which of the two is larger (`limiter`)."""
     alg = ao.algorithmic_bytes()                 # per frame, reference storage formats
     names = list(_lib.PASS_NAMES)
     if pipelined:
@@ -157,9 +192,27 @@ def pass_table(ao, pass_ms, B, pipelined):
         if pass_ms[k] <= 0:
             continue
         gbps = alg[k] * B / (pass_ms[k] * 1e-3) / 1e9
-        rows.append({"kernel": names[k], "ms": round(pass_ms[k], 5), "algorithmic_MB": round(alg[k] * B / 1e6, 3),
-                     "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)})
+        row = {"kernel": names[k], "ms": round(pass_ms[k], 5), "algorithmic_MB": round(alg[k] * B / 1e6, 3),
+               "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+        if workload is not None:
+            row.update(limiter_fields(pmc_traffic(workload, PMC_ROW_OF.get(names[k], names[k]), B), pass_ms[k], ceiling_gbps))
+        rows.append(row)
     return rows, alg, names
+
+
+def limiter_fields(traffic, launch_ms, ceiling_gbps):
+    """valu_frac / moved_bytes_vs_copy_ceiling / limiter of one launch from its committed PMC record (None when there is none for
+    this build): limiter = whichever of the two fractions is larger."""
+    out = {"valu_frac": None, "moved_bytes_vs_copy_ceiling": None, "limiter": None}
+    if not traffic or traffic.get("stale"):
+        return out
+    if traffic.get("valu_wave_insts"):
+        out["valu_frac"] = round(traffic["valu_wave_insts"] / (launch_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S, 4)
+    if traffic.get("bytes") and ceiling_gbps:
+        out["moved_bytes_vs_copy_ceiling"] = round(traffic["bytes"] / (launch_ms * 1e-3) / 1e9 / ceiling_gbps, 4)
+    if out["valu_frac"] is not None and out["moved_bytes_vs_copy_ceiling"] is not None:
+        out["limiter"] = "valu" if out["valu_frac"] >= out["moved_bytes_vs_copy_ceiling"] else "hbm"
+    return out
 
 
 class Workload:
@@ -300,7 +353,7 @@ class Workload:
         self.ctxs = []
 
 
-def measure_other_workload(name, args, dev, local_rank):
+def measure_other_workload(name, args, dev, local_rank, ceiling_gbps=None):
     """A short sub-measurement of another BASELINE single-GPU configuration inside the default line, so that the
     driver's record covers all three (1080p Sponza-like S3, 8K fp16): pipelined timed region of >= 10 steps,
     validated against the oracle, and a plain-sequence leg for the render + upsample sub-path."""
@@ -310,10 +363,10 @@ def measure_other_workload(name, args, dev, local_rank):
         steps = wl.steps_for(30.0, 10)
         elapsed, _, pass_ms, _ = wl.timed(steps, 3)
         check, _ = wl.validate(1 if name == "8k" else 2)
-        rows, alg, names = pass_table(wl.ao, pass_ms, wl.B, wl.pipelined)
+        rows, alg, names = pass_table(wl.ao, pass_ms, wl.B, wl.pipelined, name, ceiling_gbps)
         dom = max(rows, key=lambda r: r["ms"])
         traffic = pmc_traffic(name, dom["kernel"], wl.B)       # committed PMC pass of THIS workload (profiles/pmc_traffic.json)
-        dom_real = None if not traffic else round(traffic["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        dom_real = None if traffic_bytes(traffic) is None else round(traffic_bytes(traffic) / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         out = {"workload": wl.desc, "frames_per_step": wl.B, "steps": steps,
                "value": round(float(wl.w) * wl.h * wl.B * steps / elapsed / 1e6, 1), "unit": "Mpixels/s",
                "ms_per_step": round(elapsed / steps * 1e3, 4),
@@ -556,11 +609,20 @@ def main() -> int:
                     help="with --gpus 1: run through the self-launcher as well (torch.distributed.run, rendezvous on 127.0.0.1, a "
                          "one-rank process group of --dist-backend whose collectives carry fences / MAX / checksums): the driver's "
                          "N > 1 command path rehearsed on a 1-GPU box")
+    ap.add_argument("--dry-run-topology", action="store_true",
+                    help="print the rank -> device -> NUMA node -> CPU binding map `--gpus N` would use on this box (JSON) and exit; "
+                         "nothing is launched")
+    ap.add_argument("--no-numa-binding", action="store_true",
+                    help="do not bind each rank's process to the CPUs of its GPU's NUMA node (default: bind where a node is known)")
     ap.add_argument("--skip-latency", action="store_true",
                     help="skip the single-frame latency loop (keeps profiler traces to the batched launches)")
     args = ap.parse_args()
     args.steps, args.min_time_ms = resolve_timed_region(args.steps, args.min_time_ms)
 
+    if args.dry_run_topology:
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        print(json.dumps({"ranks": args.gpus, "visible_devices": ndev, "map": topology.dry_run(args.gpus, ndev)}), flush=True)
+        return 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     if args.pool > 0:
@@ -581,6 +643,9 @@ def main() -> int:
     local_rank = local_rank % ndev                               # only ever wraps with --dist-backend gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # host placement: this rank's process on the socket its GPU hangs off (miniengineao_amd.topology; no-op where no node is known)
+    placement = topology.bind_rank(local_rank, rank) if not args.no_numa_binding else {"rank": rank, "device": local_rank, "bound": False,
+                                                                                      "action": "--no-numa-binding"}
     mdist.init(args.dist_backend, dev)                           # nccl == RCCL on ROCm
 
     wl = Workload(args.workload, args, dev, local_rank, rank, world, batch=args.batch, in_flight=args.in_flight)
@@ -593,12 +658,26 @@ def main() -> int:
     args.steps = wl.steps_for(args.min_time_ms, args.steps)
     elapsed, my_elapsed, pass_ms, samples = wl.timed(args.steps, args.warmup)
     per_rank_ms = mdist.gather_floats(my_elapsed / args.steps * 1e3, dev)
+    rank_nodes = mdist.gather_floats(float(-2 if placement.get("numa_node") is None else placement["numa_node"]), dev)
+    rank_bound = mdist.gather_floats(float(bool(placement.get("bound"))), dev)
     # physical devices behind the ranks (one node: the device index identifies the GPU); < world only with --dist-backend gloo
     n_devices = len({int(d) for d in mdist.gather_floats(float(local_rank), dev)})
 
     # ---- validation of the TIMED path, right behind its timed region: what out_dev holds now was written by the
     # last step of that region (prefetched downsample consumed, final pass = the fused kernel)
     check_timed, sums_timed = wl.validate(n_validate)
+
+    # A timed region shorter than 50 ms (the driver's --steps 20 = 10 ms) carries its own long-form cross-check: the same step
+    # timed over >= 100 ms right behind it (after the validation's idle gap: clocks ramped again).  Outside `value`.
+    long_form = None
+    if elapsed < 0.050:
+        wl.ramp(0.100)
+        long_steps = wl.steps_for(100.0, args.steps)
+        l_elapsed, _, _, _ = wl.timed(long_steps, 3)
+        long_form = {"value_long": round(float(w) * h * B * long_steps * world / l_elapsed / 1e6, 1),
+                     "ms_per_step_long": round(l_elapsed / long_steps * 1e3, 4), "steps_long": long_steps,
+                     "note": "the same pipelined step, per-pass events on, timed over >= 100 ms right after the headline region "
+                             "(which lasted < 50 ms); not part of `value`"}
 
     # The same K steps once more WITHOUT the per-pass HIP events (two event records per launch = eight marker packets per step
     # on the stream): what the library does for a host that does not profile it.  `value` stays on the timed region above, whose
@@ -654,7 +733,7 @@ def main() -> int:
     step_ms = elapsed / args.steps * 1e3
 
     # roofline of the dominant kernel: algorithmic bytes per launch / measured launch duration
-    passes, alg, names = pass_table(ao, pass_ms, B, pipelined)
+    passes, alg, names = pass_table(ao, pass_ms, B, pipelined, args.workload, ceiling_gbps)
     ren_ups_bytes = sum(ao.algorithmic_bytes()[1:])    # render + upsample passes only (north_star's sub-path)
     dominant = int(np.argmax(pass_ms))
     dom_gbps = alg[dominant] * B / (pass_ms[dominant] * 1e-3) / 1e9
@@ -664,7 +743,19 @@ def main() -> int:
     # north_star's sub-path: the render + upsample passes alone (plain launch sequence: nothing else rides in those kernels)
     ren_ups_ms = sum(plain_pass_ms[1:])
     ren_ups_gbps = ren_ups_bytes * B / (ren_ups_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "limiter": "valu" if dominant != 0 else "hbm",
+    # ... and the same sub-path against the VALU issue roof: committed SQ_INSTS_VALU of its launches (plain sequence) / their time
+    plain_rows, _, _ = pass_table(ao, plain_pass_ms, B, False, args.workload, ceiling_gbps)
+    sub_rows = [r for r in plain_rows if r["kernel"] != "downsample"]
+    sub_valu = None
+    if sub_rows and all(r["valu_frac"] is not None for r in sub_rows):
+        sub_valu = round(sum(r["valu_frac"] * r["ms"] for r in sub_rows) / sum(r["ms"] for r in sub_rows), 4)
+    dom_limits = limiter_fields(traffic, pass_ms[dominant], ceiling_gbps)
+    roofline = {"bound": "hbm",
+                # which roof the dominant kernel is nearer to: moved bytes / the copy ceiling of this run vs VALU wave-instructions / the
+                # VALU issue roof (both from the committed PMC passes of this build; None when those belong to another build)
+                "limiter": dom_limits["limiter"], "valu_frac": dom_limits["valu_frac"],
+                "valu_peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
+                "valu_clock": "2.4 GHz spec clock (the PMC passes' GRBM_GUI_ACTIVE implies ~2.3 GHz under load: fractions are lower bounds)",
                 "kernel": names[dominant], "achieved": round(dom_gbps, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "launch_ms": round(pass_ms[dominant], 5), "event_samples": samples,
@@ -675,16 +766,21 @@ def main() -> int:
                 "render_plus_upsample": {"GBps": round(ren_ups_gbps, 1), "frac": round(ren_ups_gbps / HBM_PEAK_GBPS, 4),
                                          "ms_per_launch": round(ren_ups_ms, 5),
                                          "algorithmic_MB": round(ren_ups_bytes * B / 1e6, 2),
-                                         "timed_in": "plain_launch_sequence (same process, per-pass HIP events)"},
+                                         "timed_in": "plain_launch_sequence (same process, per-pass HIP events)",
+                                         "valu_frac": sub_valu,
+                                         "valu_floor_as_frac_of_hbm_roofline": SUBPATH_VALU_FLOOR_FRAC_OF_HBM_ROOFLINE,
+                                         "reading": "the sub-path is VALU-bound: `frac` of the HBM roofline, `valu_frac` of the VALU issue "
+                                                    "roof; with its bit-exact instruction mix issuing at the measured best rate and nothing "
+                                                    "ever waiting it would reach `valu_floor_as_frac_of_hbm_roofline` of the HBM roofline",
+                                         "passes": sub_rows},
                 # the same fraction in bytes that actually moved (committed PMC traffic of the dominant kernel / its time in THIS run)
-                "real_traffic_frac": None if not traffic else round(
-                    traffic["bytes"] / (pass_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "real_traffic_frac": None if traffic_bytes(traffic) is None else round(
+                    traffic_bytes(traffic) / (pass_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 # against what a plain copy reaches on this box in this run (guide figure 6290 GB/s only with --no-copy-ceiling)
                 "copy_ceiling_measured_GBps": copy_ceiling["GBps"] if copy_ceiling else None,
                 "copy_ceiling": copy_ceiling,
                 "vs_copy_ceiling_frac": round(dom_gbps / ceiling_gbps, 4),
-                "real_traffic_vs_copy_ceiling_frac": None if not traffic else round(
-                    traffic["bytes"] / (pass_ms[dominant] * 1e-3) / 1e9 / ceiling_gbps, 4),
+                "real_traffic_vs_copy_ceiling_frac": dom_limits["moved_bytes_vs_copy_ceiling"],
                 "passes": passes}
 
     cpu = None
@@ -800,7 +896,7 @@ def main() -> int:
         for name in ("1080p", "8k"):
             if name != args.workload:
                 torch.cuda.empty_cache()
-                others[name] = measure_other_workload(name, args, dev, local_rank)
+                others[name] = measure_other_workload(name, args, dev, local_rank, ceiling_gbps)
 
     # The best VALIDATED host configuration on one device, measured in the same run: the step's frames dealt
     # to two pool members (meao_pool_*), whose launch tails and heads overlap.  `value` / `roofline` stay on the single
@@ -845,6 +941,10 @@ def main() -> int:
             "roofline": roofline, "cpu_baseline": cpu, "composite_next_tier": composite,
             "depth_in_to_shaded_frame_out": shaded,
             "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+            # rank -> device -> NUMA node of the device -> was the rank's process bound to that node's CPUs (rank 0's record in full)
+            "topology": {"rank0": placement,
+                         "ranks": [{"rank": r, "numa_node": None if n < -1 else int(n), "bound": bool(b)}
+                                   for r, (n, b) in enumerate(zip(rank_nodes, rank_bound))]},
             "world_seen_by_process_group": mdist.world_size(),
             "world_seen_by_rccl": mdist.world_size() if (world == 1 or args.dist_backend == "nccl") else None,
             # what the collectives of this run actually went through (world_seen_by_rccl is 1 with no group at all, too)
@@ -852,6 +952,9 @@ def main() -> int:
             "validation": validation,
             "single_frame_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "single_frame": single,
+            "value_long": None if long_form is None else long_form["value_long"],
+            "ms_per_step_long": None if long_form is None else long_form["ms_per_step_long"],
+            "long_form_cross_check": long_form,
             "plain_launch_sequence": plain,
             "without_pass_events": without_events,
             "with_dominant_kernel_events_only": dominant_events_only,

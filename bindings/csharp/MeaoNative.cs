@@ -25,6 +25,7 @@ namespace MiniEngineAO.Native
     public enum MeaoCompositeMode { Multiply = 0, AmbientOnly = 1, Debug = 2 }
     public enum MeaoFormat { F32 = 0, F16 = 1, Unorm8 = 2 }
     public enum MeaoSampleSet { Checker = 0, Exhaustive = 1 }
+    public enum MeaoPoolOption { SpinUs = 0, BindNuma = 1 }
 
     [StructLayout(LayoutKind.Sequential)]
     public struct MeaoConfig
@@ -151,6 +152,10 @@ namespace MiniEngineAO.Native
         [DllImport(Lib)] public static extern int meao_pool_gather_to_device(IntPtr pool, int n, IntPtr[] ao_src, IntPtr[] dst, int dst_device);
         [DllImport(Lib)] public static extern int meao_pool_gather_path(IntPtr pool, int member, int dst_device);   // 0 same device, 1 peer (xGMI), 2 staged
         [DllImport(Lib)] public static extern int meao_pool_synchronize(IntPtr pool);
+        // host placement: NUMA node of a device (cpulist: the node's CPUs, "0-15,32-47"), pool options (MeaoPoolOption), where a member's worker runs
+        [DllImport(Lib)] public static extern int meao_device_numa_node(int device, out int node, System.Text.StringBuilder cpulist, ulong cpulist_capacity);
+        [DllImport(Lib)] public static extern int meao_pool_configure(IntPtr pool, int key, int value);
+        [DllImport(Lib)] public static extern int meao_pool_member_placement(IntPtr pool, int member, out int numa_node, out int worker_bound);
         [DllImport(Lib)] public static extern int meao_hostile_frames(IntPtr ctx, out ulong mask);
         [DllImport(Lib)] public static extern int meao_debug_set(IntPtr ctx, int key, int value);   // launch-structure overrides (tests, A/B runs)
         [DllImport(Lib)] public static extern int meao_debug_view(IntPtr ctx, int frame, int debug_id, IntPtr dst, int out_loc, IntPtr stream);

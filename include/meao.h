@@ -388,6 +388,18 @@ MEAO_API int32_t meao_pool_gather_to_device(meao_pool *pool, int32_t n, const vo
 typedef enum meao_pool_path { MEAO_POOL_PATH_SAME_DEVICE = 0, MEAO_POOL_PATH_PEER_DIRECT = 1, MEAO_POOL_PATH_STAGED = 2 } meao_pool_path;
 MEAO_API int32_t meao_pool_gather_path(const meao_pool *pool, int32_t member, int32_t dst_device);
 MEAO_API int32_t meao_pool_synchronize(meao_pool *pool);
+/* Host placement.  The eight GPUs of a node hang off two sockets; the thread that enqueues a GPU's launches should run on the
+ * socket the GPU hangs off.  meao_device_numa_node: *out_node = NUMA node of HIP device `device` (sysfs numa_node of its PCI
+ * function; -1 = the kernel knows none: single-node hosts, most VMs), cpulist (may be NULL) = that node's CPUs in the kernel's
+ * "0-15,32-47" form -- what a one-process-per-GPU host (bench.py --gpus N) binds its rank to.  The pool does the same for its
+ * worker threads: each binds itself to the allowed CPUs of its member's node when it starts (MEAO_POOL_BIND_NUMA, default 1; the
+ * calling thread's cgroup / taskset mask is respected; nothing happens where no node is known).  MEAO_POOL_SPIN_US: how long a
+ * worker spins for its next job before it sleeps on a condition variable (default 100; 0 = sleep at once; a stream of 4K steps
+ * posts a job every ~60 us per member).  meao_pool_member_placement reports the member's node and whether its worker is bound. */
+typedef enum meao_pool_option { MEAO_POOL_SPIN_US = 0, MEAO_POOL_BIND_NUMA = 1 } meao_pool_option;
+MEAO_API int32_t meao_device_numa_node(int32_t device, int32_t *out_node, char *cpulist, uint64_t cpulist_capacity);
+MEAO_API int32_t meao_pool_configure(meao_pool *pool, int32_t key, int32_t value);
+MEAO_API int32_t meao_pool_member_placement(const meao_pool *pool, int32_t member, int32_t *out_numa_node, int32_t *out_worker_bound);
 
 /* Which frames of the last meao_execute* held "hostile" depth texels (NaN, inf, negative, > 1, denormal --
  * anything outside the operand range the exact v_rcp_f32 division sequences are verified for) and therefore

@@ -243,6 +243,14 @@ public:
         return static_cast<meao_pool_path>(meao_pool_gather_path(pool_, member, dstDevice));
     }
     void Synchronize() { check(meao_pool_synchronize(pool_)); }
+    // MEAO_POOL_SPIN_US / MEAO_POOL_BIND_NUMA (the workers bind themselves to their device's NUMA node; before the first device batch)
+    void Configure(meao_pool_option key, int32_t value) { check(meao_pool_configure(pool_, key, value)); }
+    int32_t NumaNodeOfMember(int32_t member) const
+    {
+        int32_t node = -1;
+        (void)meao_pool_member_placement(pool_, member, &node, nullptr);
+        return node;
+    }
     meao_pool *native() { return pool_; }
 
 private:

@@ -45,6 +45,7 @@ DEBUG_OCCLUSION_HQ1 = 18
 (DEBUG_FUSE_COARSE_BLEND, DEBUG_NESTED_MAX_TILES, DEBUG_RENDER_SMALL_MAX_TILES, DEBUG_FINAL_SMALL_MAX_TILES,
  DEBUG_DS_SMALL_MAX_TILES, DEBUG_BLEND_TALL_MIN_TILES, DEBUG_PROFILE_PASS_MASK, DEBUG_NEXT_DOWNSAMPLE_OWN_LAUNCH) = range(8)
 POOL_PATH_SAME_DEVICE, POOL_PATH_PEER_DIRECT, POOL_PATH_STAGED = 0, 1, 2
+POOL_SPIN_US, POOL_BIND_NUMA = 0, 1
 NUM_BUFFERS = 21
 
 
@@ -134,6 +135,9 @@ SIGNATURES = {
     "meao_pool_composite_flush": (C.c_int32, [C.c_void_p]),
     "meao_pool_composite_pending": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "meao_pool_gather_path": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "meao_device_numa_node": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.c_char_p, C.c_uint64]),
+    "meao_pool_configure": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "meao_pool_member_placement": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "meao_hostile_frames": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "meao_debug_set": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     "meao_debug_view": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

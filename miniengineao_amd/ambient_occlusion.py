@@ -364,6 +364,17 @@ class AmbientOcclusionPool:
         self._check(self._lib.meao_pool_composite_pending(self._pool, C.byref(n)))
         return n.value > 0
 
+    def configure(self, key: int, value: int) -> None:
+        """meao_pool_configure: L.POOL_SPIN_US (how long a worker spins for its next job), L.POOL_BIND_NUMA (workers bind to their
+        device's NUMA node; before the first DEVICE batch)."""
+        self._check(self._lib.meao_pool_configure(self._pool, key, value))
+
+    def member_placement(self, member: int) -> dict:
+        """{"numa_node": node of the member's device (-1 unknown), "worker_bound": its worker thread runs on that node}."""
+        node, bound = C.c_int32(), C.c_int32()
+        self._check(self._lib.meao_pool_member_placement(self._pool, member, C.byref(node), C.byref(bound)))
+        return {"numa_node": node.value, "worker_bound": bool(bound.value)}
+
     def gather_path(self, member: int, dst_device: int) -> int:
         """L.POOL_PATH_*: how gather_to_device copies from `member`'s device to dst_device."""
         return self._lib.meao_pool_gather_path(self._pool, member, dst_device)

@@ -14,10 +14,13 @@
 // one device (hipMemcpyPeerAsync; device-to-device over xGMI where peer access could be enabled at
 // creation, meao_pool_gather_path says which) when a single consumer wants the whole batch.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <functional>
@@ -29,6 +32,90 @@
 #include <vector>
 
 #include "meao_kernels.hpp"
+
+#ifndef MEAO_TESTING
+#define MEAO_TESTING 0      // 1: the `testhooks` variant library (meao_test_* entry points), never the product
+#endif
+
+namespace {
+
+// NUMA node of a HIP device and that node's CPUs, from sysfs (numa_node of the device's PCI function; -1 = the kernel does
+// not know one: single-node hosts, most VMs).  Eight GPUs of one node hang off two sockets: a thread that enqueues for a GPU
+// and waits on its events should run next to it.
+struct NumaPlacement {
+    int node = -1;
+    std::string pci, cpulist;
+    cpu_set_t cpus;
+    int cpu_count = 0;
+};
+
+bool read_line(const std::string &path, std::string *out)
+{
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096];
+    const bool ok = std::fgets(buf, sizeof buf, f) != nullptr;
+    std::fclose(f);
+    if (!ok) return false;
+    out->assign(buf);
+    while (!out->empty() && (out->back() == '\n' || out->back() == ' ')) out->pop_back();
+    return true;
+}
+
+// "0-15,32-47" -> cpu_set_t
+int parse_cpulist(const std::string &list, cpu_set_t *set)
+{
+    CPU_ZERO(set);
+    int count = 0;
+    size_t i = 0;
+    while (i < list.size()) {
+        char *end = nullptr;
+        const long a = std::strtol(list.c_str() + i, &end, 10);
+        if (end == list.c_str() + i) break;
+        long b = a;
+        i = static_cast<size_t>(end - list.c_str());
+        if (i < list.size() && list[i] == '-') {
+            b = std::strtol(list.c_str() + i + 1, &end, 10);
+            i = static_cast<size_t>(end - list.c_str());
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+            if (c >= 0) { CPU_SET(static_cast<int>(c), set); ++count; }
+        }
+        if (i < list.size() && list[i] == ',') ++i;
+    }
+    return count;
+}
+
+NumaPlacement numa_placement_of(int device)
+{
+    NumaPlacement np;
+    CPU_ZERO(&np.cpus);
+    char pci[64] = {};
+    if (hipDeviceGetPCIBusId(pci, sizeof pci, device) != hipSuccess) { (void)hipGetLastError(); return np; }
+    np.pci = pci;
+    for (char &c : np.pci) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+    std::string node;
+    if (!read_line("/sys/bus/pci/devices/" + np.pci + "/numa_node", &node)) return np;
+    np.node = std::atoi(node.c_str());
+    if (np.node < 0) return np;
+    if (read_line("/sys/devices/system/node/node" + std::to_string(np.node) + "/cpulist", &np.cpulist))
+        np.cpu_count = parse_cpulist(np.cpulist, &np.cpus);
+    return np;
+}
+
+// Bind the calling thread to the CPUs of `np` that it is allowed to run on (cgroup / taskset masks are respected); false =
+// nothing to bind to (unknown node, or no allowed CPU on it) and the thread keeps its mask.
+bool bind_this_thread(const NumaPlacement &np)
+{
+    if (np.node < 0 || np.cpu_count == 0) return false;
+    cpu_set_t allowed, target;
+    if (pthread_getaffinity_np(pthread_self(), sizeof allowed, &allowed) != 0) return false;
+    CPU_AND(&target, &allowed, &np.cpus);
+    if (CPU_COUNT(&target) == 0) return false;
+    return pthread_setaffinity_np(pthread_self(), sizeof target, &target) == 0;
+}
+
+}  // namespace
 
 // One worker per member: runs the member's share of a pool call on the member's device.  The caller posts a job to
 // every worker and waits for all of them, so a context is only ever touched by one thread at a time.  A worker spins for
@@ -42,13 +129,18 @@ struct PoolWorker {
     std::function<int32_t()> job;
     int32_t rc = 0;
     int32_t device = 0;
+    NumaPlacement numa;                   // of `device`; the worker binds itself to it when bind_numa is set
+    bool bind_numa = true;
+    std::atomic<int> bound{0};            // 1 once the thread runs on its device's node
+    std::atomic<int> spin_us{100};        // MEAO_POOL_SPIN_US
     void loop()
     {
         (void)hipSetDevice(device);
+        if (bind_numa && bind_this_thread(numa)) bound.store(1, std::memory_order_release);
         for (;;) {
             // (a stream of 4K steps posts a job every ~60 us per member; 100 us of spinning covers that and gives the core
-            // back soon after the stream ends -- the host may be running CPU work next to the pool)
-            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
+            // back soon after the stream ends -- the host may be running CPU work next to the pool, ADVICE r4.  MEAO_POOL_SPIN_US)
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us.load(std::memory_order_relaxed));
             int st;
             while ((st = state.load(std::memory_order_acquire)) != 1 && st != 3) {
                 if (std::chrono::steady_clock::now() > spin_until) {
@@ -97,6 +189,12 @@ struct meao_pool {
     int32_t device_count = 0;
     int32_t max_batch = 1;
     uint64_t out_bytes = 0;
+    int32_t spin_us = 100;             // meao_pool_configure
+    bool bind_numa = true;
+    std::vector<NumaPlacement> numa;   // per member: where its device hangs
+#if MEAO_TESTING
+    bool refuse_peer = false;          // meao_test_pool_refuse_peer: every gather copy goes through hipMemcpyPeerAsync as if no link were enabled
+#endif
     std::string err;
 };
 
@@ -147,6 +245,9 @@ int32_t for_each_member(meao_pool *p, const std::function<int32_t(int32_t)> &fn,
             for (int32_t m = 0; m < G; ++m) {
                 p->worker.emplace_back(new PoolWorker());
                 p->worker.back()->device = p->device[m];
+                p->worker.back()->numa = p->numa[m];
+                p->worker.back()->bind_numa = p->bind_numa;
+                p->worker.back()->spin_us.store(p->spin_us, std::memory_order_relaxed);
                 PoolWorker *w = p->worker.back().get();
                 w->thread = std::thread([w] { w->loop(); });
             }
@@ -218,6 +319,7 @@ int32_t meao_pool_create(const meao_config *cfg, const int32_t *devices, int32_t
         p->ctx.push_back(ctx);
         p->device.push_back(dev);
         p->stream.push_back(s);
+        p->numa.push_back(numa_placement_of(dev));
     }
     // Peer access, both ways, between every pair of distinct member devices: without it hipMemcpyPeerAsync
     // still works but bounces through host memory.  "Already enabled" (another pool, the host itself) is fine.
@@ -250,7 +352,7 @@ int32_t meao_pool_destroy(meao_pool *p)
     p->worker.clear();
     for (size_t i = 0; i < p->ctx.size(); ++i) {
         (void)hipSetDevice(p->device[i]);
-        // The member's context has this stream as the stream of its last call (graph replays in flight,
+        // The member's context has this stream as the stream of its last call (launches in flight,
         // meao_destroy synchronises them): the context goes first, its stream after it.
         if (p->stream[i]) (void)hipStreamSynchronize(p->stream[i]);
         meao_destroy(p->ctx[i]);
@@ -403,6 +505,9 @@ int32_t meao_pool_gather_path(const meao_pool *p, int32_t member, int32_t dst_de
 {
     if (!p || member < 0 || member >= static_cast<int32_t>(p->ctx.size()) || dst_device < 0 || dst_device >= p->device_count)
         return MEAO_ERR_INVALID_ARGUMENT;
+#if MEAO_TESTING
+    if (p->refuse_peer) return MEAO_POOL_PATH_STAGED;
+#endif
     if (p->device[member] == dst_device) return MEAO_POOL_PATH_SAME_DEVICE;
     return p->peer_ok[static_cast<size_t>(member) * p->device_count + dst_device] ? MEAO_POOL_PATH_PEER_DIRECT : MEAO_POOL_PATH_STAGED;
 }
@@ -418,7 +523,11 @@ int32_t meao_pool_gather_to_device(meao_pool *p, int32_t n, const void *const *a
         const int32_t m = f % G;
         if (hipSetDevice(p->device[m]) != hipSuccess) return pool_fail(p, MEAO_ERR_HIP, "meao_pool_gather_to_device: hipSetDevice");
         // on the producing member's stream: ordered behind the kernels that wrote the frame
-        const hipError_t e = p->device[m] == dst_device
+        bool same_device = p->device[m] == dst_device;
+#if MEAO_TESTING
+        if (p->refuse_peer) same_device = false;       // the cross-device call, on whatever devices there are (one-GPU boxes)
+#endif
+        const hipError_t e = same_device
                                  ? hipMemcpyAsync(dst[f], ao_src[f], p->out_bytes, hipMemcpyDeviceToDevice, p->stream[m])
                                  : hipMemcpyPeerAsync(dst[f], dst_device, ao_src[f], p->device[m], p->out_bytes, p->stream[m]);
         if (e != hipSuccess) {
@@ -434,7 +543,6 @@ int32_t meao_pool_synchronize(meao_pool *p)
     if (!p) return MEAO_ERR_INVALID_ARGUMENT;
     DeviceGuard guard;
     for (size_t i = 0; i < p->ctx.size(); ++i) {
-        // meao_synchronize also waits for a downsample pass the member put on its side stream (MEAO_DEBUG_DS_SIDE_STREAM)
         if (hipSetDevice(p->device[i]) != hipSuccess || meao_synchronize(p->ctx[i], p->stream[i]) != MEAO_OK) {
             (void)hipGetLastError();
             return pool_fail(p, MEAO_ERR_HIP, "meao_pool_synchronize: stream synchronisation failed");
@@ -442,5 +550,59 @@ int32_t meao_pool_synchronize(meao_pool *p)
     }
     return MEAO_OK;
 }
+
+int32_t meao_device_numa_node(int32_t device, int32_t *out_node, char *cpulist, uint64_t cpulist_capacity)
+{
+    if (!out_node) return MEAO_ERR_INVALID_ARGUMENT;
+    *out_node = -1;
+    if (cpulist && cpulist_capacity > 0) cpulist[0] = 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return MEAO_ERR_NO_DEVICE; }
+    if (device < 0 || device >= count) return MEAO_ERR_INVALID_ARGUMENT;
+    const NumaPlacement np = numa_placement_of(device);
+    *out_node = np.node;
+    if (cpulist && cpulist_capacity > 0) {
+        if (np.cpulist.size() + 1 > cpulist_capacity) return MEAO_ERR_BUFFER_TOO_SMALL;
+        std::memcpy(cpulist, np.cpulist.c_str(), np.cpulist.size() + 1);
+    }
+    return MEAO_OK;
+}
+
+int32_t meao_pool_configure(meao_pool *p, int32_t key, int32_t value)
+{
+    if (!p) return MEAO_ERR_INVALID_ARGUMENT;
+    switch (key) {
+    case MEAO_POOL_SPIN_US:
+        if (value < 0 || value > 1000000) return pool_fail(p, MEAO_ERR_INVALID_ARGUMENT, "meao_pool_configure: SPIN_US is 0..1000000");
+        p->spin_us = value;
+        for (auto &w : p->worker) w->spin_us.store(value, std::memory_order_relaxed);
+        return MEAO_OK;
+    case MEAO_POOL_BIND_NUMA:
+        if (!p->worker.empty()) return pool_fail(p, MEAO_ERR_UNSUPPORTED, "meao_pool_configure: BIND_NUMA must be set before the first DEVICE batch (the workers are running)");
+        p->bind_numa = value != 0;
+        return MEAO_OK;
+    default: return pool_fail(p, MEAO_ERR_INVALID_ARGUMENT, "meao_pool_configure: unknown key");
+    }
+}
+
+int32_t meao_pool_member_placement(const meao_pool *p, int32_t member, int32_t *out_numa_node, int32_t *out_worker_bound)
+{
+    if (!p || member < 0 || member >= static_cast<int32_t>(p->ctx.size())) return MEAO_ERR_INVALID_ARGUMENT;
+    if (out_numa_node) *out_numa_node = p->numa[member].node;
+    if (out_worker_bound)
+        *out_worker_bound = member < static_cast<int32_t>(p->worker.size()) ? p->worker[member]->bound.load(std::memory_order_acquire) : 0;
+    return MEAO_OK;
+}
+
+#if MEAO_TESTING
+// testhooks variant only: every later meao_pool_gather_to_device copy takes the cross-device call (hipMemcpyPeerAsync) and
+// meao_pool_gather_path reports STAGED, as on a node whose devices offer no peer access -- testable on a one-GPU box.
+__attribute__((visibility("default"))) int32_t meao_test_pool_refuse_peer(meao_pool *p, int32_t refuse)
+{
+    if (!p) return MEAO_ERR_INVALID_ARGUMENT;
+    p->refuse_peer = refuse != 0;
+    return MEAO_OK;
+}
+#endif
 
 }  // extern "C"

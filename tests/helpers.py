@@ -110,3 +110,21 @@ def hostile_frame(w, h, seed, cam=synth.DEFAULT_CAMERA, density=0.01, kinds=None
     return d
 
 
+
+
+def run_against_testhooks(script):
+    """Run tests/<script> in its own process against the `testhooks` variant library (-DMEAO_TESTING=1: the only build that exports
+    meao_test_*).  The library is built on the spot when it is missing -- a GPU run must never skip these checks silently
+     -- and its absence after that is a failure, not a skip."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "miniengineao_amd", "lib", "variants", "libmeao_testhooks.so")
+    if not os.path.exists(lib):
+        from miniengineao_amd import build
+        build.build_variants(["testhooks"], strict=True)
+    assert os.path.exists(lib), "the testhooks variant library could not be built"
+    proc = subprocess.run([sys.executable, os.path.join(root, "tests", script)], cwd=root,
+                          env=dict(os.environ, MEAO_LIB_PATH=lib), capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, (proc.stdout[-1500:], proc.stderr[-1500:])

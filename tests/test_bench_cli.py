@@ -52,3 +52,30 @@ def test_an_explicit_steps_is_timed_exactly():
     assert bench.resolve_timed_region(None, None) == (30, 100.0)
     assert bench.resolve_timed_region(20, 100.0) == (20, 100.0)
     assert bench.resolve_timed_region(None, 0.0) == (30, 0.0)
+
+
+def test_numa_binding_plan_without_a_gpu():
+    """VERDICT r5 #6a: the rank -> device -> NUMA node -> CPU map is a pure function of (device placement, allowed mask)."""
+    from miniengineao_amd import topology as T
+    assert T.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and T.parse_cpulist("") == set()
+    place = {"device": 3, "numa_node": 1, "cpulist": "64-127,192-255"}
+    plan = T.plan_binding(place, allowed=set(range(256)))
+    assert plan["action"] == "bind" and plan["bind_to"][0] == 64 and len(plan["bind_to"]) == 128 and plan["node_cpus"] == 128
+    # a cgroup / taskset mask is respected: only the allowed CPUs of the node; none of them allowed -> the mask is left alone
+    assert T.plan_binding(place, allowed={0, 1, 70, 71})["bind_to"] == [70, 71]
+    assert T.plan_binding(place, allowed={0, 1})["action"].startswith("leave the mask")
+    assert T.plan_binding({"device": 0, "numa_node": -1, "cpulist": ""}, allowed={0, 1})["action"].startswith("leave the mask")
+    assert T.plan_binding(place, allowed={64, 65})["action"] == "already inside the node"
+
+
+def test_dry_run_topology_prints_the_rank_map_and_launches_nothing():
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-topology"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 8 and len(line["map"]) == 8 and [m["rank"] for m in line["map"]] == list(range(8))
+    if line["visible_devices"] == 0:
+        assert all(m["action"] == "no device visible" for m in line["map"])
+    else:       # on a GPU box: every rank has a device and a decision
+        assert all(m["device"] == m["rank"] % line["visible_devices"] and m["action"] for m in line["map"])

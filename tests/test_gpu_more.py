@@ -422,25 +422,19 @@ def test_failed_resize_leaves_the_context_usable():
     buffers.  The failure is injected through meao_test_fail_next_allocs, which only the `testhooks`
     variant library exports (-DMEAO_TESTING=1; the product ABI has no fault injection): the check runs in its
     own process against that library (tests/resize_failure_check.py)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "miniengineao_amd", "lib", "variants", "libmeao_testhooks.so")
-    if not os.path.exists(lib):
-        pytest.skip("the testhooks variant library is not built (python -c 'from miniengineao_amd import build; build.build_variants()')")
-    proc = subprocess.run([sys.executable, os.path.join(root, "tests", "resize_failure_check.py")], cwd=root,
-                          env=dict(os.environ, MEAO_LIB_PATH=lib), capture_output=True, text=True, timeout=600)
-    assert proc.returncode == 0, (proc.stdout[-1500:], proc.stderr[-1500:])
+    H.run_against_testhooks("resize_failure_check.py")
 
 
 def test_the_product_library_has_no_fault_injection(meao_lib):
-    """Key 5 of meao_debug_set (FAIL_NEXT_ALLOCS until round 5) is refused and no meao_test_* symbol is exported."""
+    """No meao_test_* entry point is exported by the product (they exist in the `testhooks` variant only) and meao_debug_set
+    refuses keys it does not know (fault injection was key 5 of ABI <= 4)."""
     from miniengineao_amd import AmbientOcclusion
-    assert not hasattr(meao_lib, "meao_test_fail_next_allocs")
+    assert not hasattr(meao_lib, "meao_test_fail_next_allocs") and not hasattr(meao_lib, "meao_test_pool_refuse_peer")
     with AmbientOcclusion(64, 64) as ao:
-        with pytest.raises(L.MeaoError) as e:
-            ao.debug_set(5, 1)
-        assert e.value.status == L.ERR_INVALID_ARGUMENT
+        for key in (8, 99, -1):
+            with pytest.raises(L.MeaoError) as e:
+                ao.debug_set(key, 1)
+            assert e.value.status == L.ERR_INVALID_ARGUMENT
 
 
 @pytest.mark.parametrize("depth_off,out_off", [(4, 0), (0, 1), (8, 2), (0, 0)])

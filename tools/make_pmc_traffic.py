@@ -19,13 +19,15 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 # kernel-name fragment -> (bench pass name(s), FETCH_SIZE factor, note)
 FETCH_FACTOR = 2.0       # profiles/r05_pmc_calibration.json: the counter reports half of the bytes read, at every access width
 KERNELS = {
-    "downsample_kernel": ("downsample", FETCH_FACTOR, "FETCH_SIZE x2 (calibrated); equals the known 4*W*H bytes per frame to 2e-4"),
+    "downsample_kernel": ("downsample", FETCH_FACTOR, "FETCH_SIZE x2 (calibrated); the pass reads the even rows of the frame: 2*W*H bytes of f32 depth"),
     "render_kernel": ("render", FETCH_FACTOR, "FETCH_SIZE x2 (calibrated)"),
-    "upsample_kernel<A, false, true": ("upsample_L1_to_L0", FETCH_FACTOR, "FETCH_SIZE x2 (calibrated; rounds 2-4 left this row raw = half)"),
-    "upsample_kernel<A, false, false": ("upsample_blend_passes", FETCH_FACTOR, "mean of the stand-alone main_blendout launches (L2->L1 only when L4->L3 rides inside L3->L2); FETCH_SIZE x2 (calibrated)"),
+    "upsample_final_kernel<A, false": ("upsample_L1_to_L0", FETCH_FACTOR, "FETCH_SIZE x2 (calibrated); HiResDB is evaluated from the raw depth frame (4*W*H bytes read)"),
+    "upsample_kernel<A, false": ("upsample_blend_passes", FETCH_FACTOR, "mean of the stand-alone main_blendout launches (L2->L1 only when L4->L3 rides inside L3->L2); FETCH_SIZE x2 (calibrated)"),
     "upsample_blend_tall_kernel<A, false": ("upsample_blend_passes", FETCH_FACTOR, "the L2->L1 launch with 64 x 64 tiles (large R8 batches); FETCH_SIZE x2 (calibrated)"),
     "upsample_two_level_kernel<A, false": ("upsample_L4_to_L3+L3_to_L2", FETCH_FACTOR, "the fused two-level launch; FETCH_SIZE x2 (calibrated)"),
     "upsample_final_with_next_downsample_kernel<A, false": ("upsample_L1_to_L0+downsample_next", FETCH_FACTOR,
@@ -70,6 +72,13 @@ def main():
     full.setdefault("_tags", {"4k": full.get("_tag", "(untagged)")} if "4k" in full and workload != "4k" else {})
     full["_tags"][workload] = os.path.basename(os.path.normpath(root)).replace("pmc_", "")
     full["_tag"] = full["_tags"].get("4k", full["_tags"][workload])
+    # the device code the counters were collected from (run_pmc.sh writes it on the GPU box; bench.py compares it with what it loads)
+    from miniengineao_amd import codehash, _lib
+    try:
+        sha = open(os.path.join(root, "code_sha256.txt")).read().split()[0]
+    except (OSError, IndexError):
+        sha = codehash.device_code_sha256(_lib.LIB_PATH)
+    full.setdefault("_code_sha256", {})[workload] = sha
     full["_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/run_pmc.sh); FETCH_SIZE x2 for every kernel "
                        "(profiles/r05_pmc_calibration.json); see tools/make_pmc_traffic.py")
     json.dump(full, open(path, "w"), indent=1, sort_keys=True)

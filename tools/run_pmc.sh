@@ -4,6 +4,7 @@ TAG=${1:-r01}; shift
 REPO=$(pwd)
 export OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+python -m miniengineao_amd.codehash > $OUT/code_sha256.txt      # the device code these counters belong to (profiles/pmc_traffic.json "_code_sha256")
 cd /tmp && export TMPDIR=/tmp
 timeout 120 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 run() { name=$1; shift; case " ${PMC_GROUPS:-sq1 sq2 sq3 sq4 sq5 fetch write} " in *" $name "*) ;; *) return;; esac; timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o pmc -- python $REPO/bench.py --no-cpu-baseline --skip-latency --no-other-workloads --no-copy-ceiling --no-best-host-config --validate-frames 0 --min-time-ms 0 --steps 3 --warmup 1 $BENCH_ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
