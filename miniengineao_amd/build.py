@@ -42,6 +42,9 @@ FLAGS = [
 ]
 
 
+COMPILE_ONLY_PREFIXES = ("-O", "-std=", "-ffp-contract", "-fhip-fp32-correctly-rounded", "-fno-slp-vectorize", "-W")
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -75,6 +78,8 @@ def _unit_stale(src: str, obj: str) -> bool:
     built = os.path.getmtime(obj)
     deps = [src, os.path.join(_INCLUDE, "meao.h"), os.path.abspath(__file__)]
     deps += [os.path.join(_CSRC, h) for h in HEADERS if h.endswith(".hpp")]
+    if os.path.basename(src) == "meao_kernels.hip":         # the unity unit #includes every kernel unit
+        deps += [os.path.join(_CSRC, u) for u in KERNEL_UNITS]
     return any(os.path.getmtime(d) > built for d in deps)
 
 
@@ -108,7 +113,9 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out_pa
             list(ex.map(lambda c: _run(c, verbose), todo))
     open(flags_stamp, "w").write(stamp)
     tmp = final + ".tmp"
-    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", *objs, "-o", tmp], verbose)
+    # the link line comes from FLAGS too: everything but what only means something to the compiler proper
+    link_flags = [f for f in FLAGS if not f.startswith(COMPILE_ONLY_PREFIXES)]
+    _run([hipcc(), *link_flags, *objs, "-o", tmp], verbose)
     os.replace(tmp, final)
     return final
 

@@ -66,6 +66,9 @@ def dry_run(ranks: int, visible_devices: int) -> List[dict]:
     out = []
     for r in range(ranks):
         d = r % max(visible_devices, 1)
-        out.append(dict(plan_binding(device_placement(d)) if visible_devices else
-                        {"device": None, "numa_node": None, "action": "no device visible"}, rank=r))
+        row = dict(plan_binding(device_placement(d)) if visible_devices else
+                   {"device": None, "numa_node": None, "action": "no device visible"}, rank=r)
+        if "bind_to" in row:            # the report names the node's cpulist; the expanded list is for bind_rank
+            row["bind_to"] = len(row["bind_to"])
+        out.append(row)
     return out

@@ -1,3 +1,5 @@
+"""Which of the 17 buffers differ from the oracle, and where, at four small sizes (vector and scalar paths): the first thing to run on a
+GPU box after a kernel change.  python tools/parity_probe.py"""
 import numpy as np, sys
 sys.path.insert(0, '.')
 from miniengineao_amd import synth
