@@ -159,15 +159,17 @@ __device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_dept
 // every operand finite, weights and AO values >= 0, hi_ao <= 1).
 //
 // The code is floor(RN(RN(sat(q) * 255) + 0.5)) for the q of the correctly rounded chain (bilateral_upsample).  An estimate q~
-// from the same operations with every division replaced by dividend * v_rcp_f32 differs from q by at most 35 u relatively
-// (u = 2^-24):
+// with every division replaced by dividend * v_rcp_f32 (and the weights' constant factors folded into fused multiply-adds, below)
+// differs from q by at most 31 u relatively (u = 2^-24), both chains measured against the real-number value:
 //   v_rcp_f32 is within one ulp of the correctly rounded reciprocal (meao_selftest(4): every binary32 in range), i.e. within
 //             1.5 ulp = 3u of the true one;
-//   weights   RN(K * rcp(x)) against RN(K / x): 3u + u (the product) + u (the quotient's rounding) = 5u;
-//   the sums  have non-negative terms only, so they inherit the largest relative error of a term plus one u per rounding in
-//             either chain: total 5u + 2 * 4u = 13u, weighted sum (times hi_ao) 5u + 2 * 6u = 17u;
-//   quotient  u (RN) + 4u (rcp + product) on top: 13u + 17u + 5u = 35u = 1.1 * 2^-19.
-// The weighted average times hi_ao is at most 1 (+ rounding), so the estimate is off by < 5.4e-4 of a code; the reference's
+//   the sums  have non-negative terms only, so a sum inherits the largest relative error of its terms plus one u per rounding.
+//             Estimate: r1 + r3 and r2 + noise 4u, fma(3, ., .) 5u, total = fma(9, r0, .) 6u; a_i r_i 4u, fma(a3, r3, a1 r1) 5u,
+//             fma(a2, r2, noise) 4u, fma(3, ., .) 6u, sum = fma(9, a0 r0, .) 7u, times hi_ao 8u; rcp(total) 6u + 3u, the product
+//             u: q~ is within 18u.  Exact chain (one correctly rounded operation each): weights u, total u + 4u, weighted sum
+//             times hi_ao u + 6u, quotient u: q is within 13u.  (The round-2..5 form, factors applied to the reciprocals first,
+//             summed like the reference: 22u + 13u = 35u; the three-reciprocal form PAIRED: 22u + 13u = 35u with these sums.)
+// The weighted average times hi_ao is at most 1 (+ rounding), so the estimate is off by < 4.8e-4 of a code; the reference's
 // two roundings in the conversion and the fused one of the estimate add < 2.3e-5.  If v~ = fma(sat(q~), 255, 0.5) is further
 // than kR8Margin = 2^-10 (1.7 x that bound) from an integer, floor(v~) IS the reference's code.  Otherwise -- 2^-9 of the texels
 // of a noisy frame, none where the AO is flat (q~ = 1 -> v~ = 255.5) -- the lane runs the exact sequence.  The agreement of
@@ -181,8 +183,8 @@ __device__ __forceinline__ void bilateral_upsample_grouped(const float (&hi_dept
 // product, 1/x0 = x1 * rcp(x0 * x1), 1/x1 = x0 * rcp(x0 * x1): a quarter-rate transcendental (8 - 11 issue cycles inside this
 // mix) is traded for three full-rate multiplies.  x = |dHi - dLo| + tolerance lies in [2^-44, 2^21] (exact_rcp_div_applicable +
 // nice depths), so a product of two lies in [2^-88, 2^42]: no overflow, no denormal anywhere.  Error: product u, v_rcp_f32 3u,
-// multiply u = 5u per reciprocal instead of 3u, i.e. weights 7u, total 7u + 2 * 4u = 15u, weighted sum 7u + 2 * 6u = 19u,
-// quotient + 5u: 39u = 1.22 * 2^-19 of q, < 6.0e-4 of a code (+ 2.3e-5 for the conversions) -- still inside kR8Margin = 9.8e-4.
+// multiply u = 5u per reciprocal instead of 3u: total 8u, weighted sum times hi_ao 10u, quotient 8u + 3u + u on top = 22u, + 13u
+// of the exact chain = 35u = 1.1 * 2^-19 of q, < 5.4e-4 of a code (+ 2.3e-5 for the conversions) -- inside kR8Margin = 9.8e-4.
 // The exact path cannot start from these reciprocals (the correctly-rounded guarantee of the Newton step is verified for the
 // v_rcp_f32 seed, meao_selftest(4..6), not for a 5u one): PAIRED implies !REUSE.  Checked like the five-reciprocal form:
 // tests/test_r8_estimate_bound.py (adversarial errors), meao_selftest(7) (2^32 operand sets on the device).
@@ -219,13 +221,13 @@ __device__ __forceinline__ uint32_t bilateral_upsample_r8(float hi_depth, float 
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(x[i]);
     }
-    const float w0 = k.nine * r[0], w1 = k.three * r[1], w2 = r[2], w3 = k.three * r[3];
-    const float total = (((w0 + w1) + w2) + w3) + k.noise;
-    float sm = a[0] * w0;
-    sm = mad(a[1], w1, sm);
-    sm = mad(a[2], w2, sm);
-    sm = mad(a[3], w3, sm);
-    const float q = (hi_ao * (sm + k.noise)) * __builtin_amdgcn_rcpf(total);
+    // The estimate only has to stay inside its error bound, not to follow the reference's operation order (round 6): the constant
+    // factors of the weights are folded into fused multiply-adds -- total = 9 r0 + 3 (r1 + r3) + (r2 + noise), sum = 9 a0 r0 +
+    // 3 (a1 r1 + a3 r3) + (a2 r2 + noise) -- 10 operations instead of 12 (last kernel 250.8 -> 245.6 us, full-resolution pass 191.3 ->
+    // 186.0, L2 -> L1 49.9 -> 49.1 per 16 4K frames: profiles/r06_ab_bilateral_estimate_fused_weights.jsonl).
+    const float total = mad(k.nine, r[0], mad(k.three, r[1] + r[3], r[2] + k.noise));
+    const float sum = mad(k.nine, a[0] * r[0], mad(k.three, mad(a[3], r[3], a[1] * r[1]), mad(a[2], r[2], k.noise)));
+    const float q = (hi_ao * sum) * __builtin_amdgcn_rcpf(total);
     const float v = mad(sat(q), 255.0f, 0.5f + kR8Margin);          // v~ + margin: its floor is the code unless its fraction is < 2 margins
     uint32_t code = static_cast<uint32_t>(v);
     const bool near_boundary = __builtin_amdgcn_fractf(v) < 2.0f * kR8Margin;
@@ -361,7 +363,7 @@ __device__ __forceinline__ bool hi_depth_words(const uint4v (&raw)[QUADS], int f
                 r[q][h] = float2v{rx, ry};
             }
         __builtin_amdgcn_sched_barrier(0);
-        bool far = false;
+        bool far = false;      // (one min / max chain over the lane's texels and one compare instead of a compare per texel: slower, r06 A/B)
 #pragma unroll
         for (int q = 0; q < QUADS; ++q)
 #pragma unroll
@@ -668,6 +670,26 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             }
         }
     }
+    // ---- HiResDB of the lane's 16 (8) texels from the hoisted raw depth loads (hi_depth_words), at the end of the fill phase, in
+    // front of the FIRST barrier: the bilateral phase finds packed f16 words, as it did when LinearDepth was a buffer, and only
+    // those eight registers -- not the sixteen of the raw quads -- stay live across the blur phases.  (In front of the second /
+    // third barrier instead: last kernel 247 / 248 us against 239.5, full-resolution pass 192 / 185 against 181 per 16 4K frames,
+    // profiles/r06_ab_hi_depth_block_position.jsonl.)
+    uint32_t hd_words[2 * kPasses][2];
+    bool lane_clean = true;
+    auto hi_depth_block = [&]() __attribute__((always_inline)) {
+        if constexpr (FINAL) {
+            if (hoist_ok) {
+                uint4v rawq[2 * kPasses];
+#pragma unroll
+                for (int pass = 0; pass < kPasses; ++pass)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) rawq[2 * pass + f] = hoist_hraw[pass][f];
+                lane_clean = hi_depth_words<RTNE, DIV, RAW_F32, 2 * kPasses>(rawq, raw_format, zp0, zp1, sky_depth, hd_words);
+            }
+        }
+    };
+    hi_depth_block();      // (at s_setprio 3 like the fill it ends: at priority 0 the pass is 16 us slower per 16 4K frames, r06 A/B)
     clk.mark(0);         // 0: window loaded, converted, stored to LDS
     __syncthreads();
     clk.mark(1);         // 1: barrier
@@ -725,21 +747,6 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         for (int n = 0; n < T::kVRun; ++n) s_vb[(r0 + n) * T::kBlurPitch + c] = o[n];
     }
     clk.mark(4);         // 4: V-blur
-    // ---- HiResDB of the lane's 16 (8) texels from the hoisted raw depth loads (hi_depth_words), in front of the last barrier: the
-    // loads went out at the top of the tile and have long landed; the bilateral phase finds packed f16 words, as it did when
-    // LinearDepth was a buffer
-    uint32_t hd_words[2 * kPasses][2];
-    bool lane_clean = true;
-    if constexpr (FINAL) {
-        if (hoist_ok) {
-            uint4v rawq[2 * kPasses];
-#pragma unroll
-            for (int pass = 0; pass < kPasses; ++pass)
-#pragma unroll
-                for (int f = 0; f < 2; ++f) rawq[2 * pass + f] = hoist_hraw[pass][f];
-            lane_clean = hi_depth_words<RTNE, DIV, RAW_F32, 2 * kPasses>(rawq, raw_format, zp0, zp1, sky_depth, hd_words);
-        }
-    }
     __syncthreads();
     clk.mark(5);         // 5: barrier
     if constexpr (Hook::kBeforeBilateral) {

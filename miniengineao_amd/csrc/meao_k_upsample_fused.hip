@@ -15,7 +15,7 @@ struct IssueCarriedLoadsLean {
     // copy existed both lost here): exact sequences 272 us, UNORM8 estimate 257, grouped reciprocals 264, both 256 us per 16 frames.
     static constexpr bool kGroupReciprocals = true;
     static constexpr bool kEstimateR8 = true;
-    static constexpr bool kReuseEstimate = false;        // (the VGPRs that seven workgroups per CU allow: reuse spills)
+    static constexpr bool kReuseEstimate = false;        // (round 6, with registers to spare: 240.1 vs 240.3 us -- the exact path is rare; left off)
     static constexpr bool kPairReciprocals = MEAO_X_BIL_PAIR_RCP != 0;
     const DownsampleArgs &d;
     float4v (&q)[2];
