@@ -672,7 +672,8 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     }
     // ---- HiResDB of the lane's 16 (8) texels from the hoisted raw depth loads (hi_depth_words), at the end of the fill phase, in
     // front of the FIRST barrier: the bilateral phase finds packed f16 words, as it did when LinearDepth was a buffer, and only
-    // those eight registers -- not the sixteen of the raw quads -- stay live across the blur phases.  (In front of the second /
+    // those eight registers -- not the sixteen of the raw quads -- stay live across the blur phases (converted back to f32 here
+    // already, sixteen registers: 236.5 vs 237.0 us, not kept).  (In front of the second /
     // third barrier instead: last kernel 247 / 248 us against 239.5, full-resolution pass 192 / 185 against 181 per 16 4K frames,
     // profiles/r06_ab_hi_depth_block_position.jsonl.)
     uint32_t hd_words[2 * kPasses][2];
