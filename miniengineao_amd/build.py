@@ -128,6 +128,7 @@ VARIANTS = {
     "testhooks": ["-DMEAO_TESTING=1"],              # the product + meao_test_fail_next_allocs (fault injection for the resize tests; not in the product ABI)
     "pair": ["-DMEAO_X_BIL_PAIR_RCP=1"],            # three reciprocals per UNORM8 bilateral texel instead of five (round-5 A/B: no gain in the kernels)
     "ntstore": ["-DMEAO_X_FINAL_NT_STORE=1"],       # non-temporal stores for the result texels of the full-resolution pass (the form of rounds 2-4)
+    "lowbuf": ["-DMEAO_X_LOWDEPTH_FROM_RAW=0"],     # the full-resolution pass reads its LoResDB window from the LowDepth1 buffer (the form up to round 6a)
     "nowt": ["-DMEAO_X_BIL_WHOLE_TILE=0"],          # without the unmasked copy of the bilateral phase (the round-3 form of the upsample tile)
 }
 

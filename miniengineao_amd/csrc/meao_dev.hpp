@@ -30,6 +30,11 @@
                                    // halves cost 1.31x their bytes in HBM writes (WRITE_SIZE 10.82 MB per 4K frame for 8.29 MB of results; temporal:
                                    // 8.30 MB -- L2 merges the halves), last kernel 268.7 -> 267.1 us: profiles/r05_result_store_write_size.txt,
                                    // r05_ab_result_stores.jsonl.  (fp16 results are whole lines per tile row: 1.00x either way.)
+#ifndef MEAO_X_LOWDEPTH_FROM_RAW
+#define MEAO_X_LOWDEPTH_FROM_RAW 1 // 0 = the full-resolution pass reads its LoResDB window from the LowDepth1 buffer (rounds 1-6a; variant `lowbuf`).  1: a tile
+#endif                             // inside the frame never reads LowDepth1 -- the 32 x 32 interior of its window ARE the pre-rounding values of its own
+                                   // even-even raw texels (DS1:64-70), which hi_depth_words has in registers, and the 3-texel apron is linearized from
+                                   // raw texels of the neighbouring tiles' lines (L2 hits: they are those tiles' HiResDB): 8.3 MB per 4K frame less
 #ifndef MEAO_X_HOT_PATH_ONLY
 #define MEAO_X_HOT_PATH_ONLY 0  // ANALYSIS builds only (tools/kernel_isa.py -DMEAO_X_HOT_PATH_ONLY=1 --stats; never a library): the upsample
 #endif                          // and render kernels keep nothing but the path an interior tile of a clean frame takes, so that the

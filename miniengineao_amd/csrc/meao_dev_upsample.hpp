@@ -317,13 +317,18 @@ __device__ __forceinline__ void decode_raw_quad(const uint4v &q, int format, flo
     }
 }
 
-template <bool RAW_F32>
+// STREAMED: the frame is read once -- past the caches' LRU (the hi-res operands); the apron texels of a from-raw window are lines
+// the neighbouring tiles read as THEIR hi-res operands: plain loads.
+template <bool RAW_F32, bool STREAMED = true>
 __device__ __forceinline__ uint4v load_raw_quad(const void *frame_base, int format, uint32_t texel)
 {
     typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
-    if (RAW_F32 || format == MEAO_DEPTH_F32 || format == MEAO_DEPTH_UNORM24)      // the frame is read once: streamed past the caches' LRU
-        return __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(at_byte_offset(static_cast<const char *>(frame_base), texel * 4u)));
-    const uint2v h = __builtin_nontemporal_load(reinterpret_cast<const uint2v *>(at_byte_offset(static_cast<const char *>(frame_base), texel * 2u)));
+    if (RAW_F32 || format == MEAO_DEPTH_F32 || format == MEAO_DEPTH_UNORM24) {
+        const uint4v *p = reinterpret_cast<const uint4v *>(at_byte_offset(static_cast<const char *>(frame_base), texel * 4u));
+        return STREAMED ? __builtin_nontemporal_load(p) : *p;
+    }
+    const uint2v *p = reinterpret_cast<const uint2v *>(at_byte_offset(static_cast<const char *>(frame_base), texel * 2u));
+    const uint2v h = STREAMED ? __builtin_nontemporal_load(p) : *p;
     return uint4v{h.x, h.y, 0u, 0u};
 }
 
@@ -338,9 +343,11 @@ __device__ __forceinline__ uint4v load_raw_quad(const void *frame_base, int form
 // 65504 for every den in (0, 2^-16) whose reciprocal is finite (round toward zero), +0 for den > 2^24.  A non-negative finite
 // HiResDB keeps every operand of the bilateral step inside the exact sequences' ranges (x = |hi - lo| + tolerance with lo a
 // nice level texel).  So: one packed unsigned max over the words, one compare per lane.  Returns false = redo the lane (IEEE).
+// even[q][j]: Linearize of texels 0 and 2 of quad q BEFORE the f16 store -- for a quad of an even row these are the LowDepth1
+// texels under it (DS2x[st >> 1], DS1:64-70); the from-raw window of the full-resolution pass takes its interior from them.
 template <bool RTNE, int DIV, bool RAW_F32, int QUADS>
 __device__ __forceinline__ bool hi_depth_words(const uint4v (&raw)[QUADS], int format, float zp0, float zp1, float sky_depth,
-                                               uint32_t (&words)[QUADS][2])
+                                               uint32_t (&words)[QUADS][2], float (&even)[QUADS][2])
 {
     float d[QUADS][4];
 #pragma unroll
@@ -387,6 +394,7 @@ __device__ __forceinline__ bool hi_depth_words(const uint4v (&raw)[QUADS], int f
             for (int h = 0; h < 2; ++h) {
                 const auto p = __builtin_amdgcn_cvt_pkrtz(lin[q][h].x, lin[q][h].y);                                              // the HalfUAV store, AO.cs:454
                 words[q][h] = __builtin_bit_cast(uint32_t, p);
+                even[q][h] = lin[q][h].x;
                 top = __builtin_elementwise_max(top, __builtin_bit_cast(ushort2v, p));
             }
         return top.x < 0x7c00u && top.y < 0x7c00u;
@@ -395,7 +403,8 @@ __device__ __forceinline__ bool hi_depth_words(const uint4v (&raw)[QUADS], int f
         for (int q = 0; q < QUADS; ++q)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t lo = f32_to_f16_bits<RTNE>(linearize<DIV>(d[q][2 * h], zp0, zp1, sky_depth));
+                even[q][h] = linearize<DIV>(d[q][2 * h], zp0, zp1, sky_depth);
+                const uint32_t lo = f32_to_f16_bits<RTNE>(even[q][h]);
                 const uint32_t hi = f32_to_f16_bits<RTNE>(linearize<DIV>(d[q][2 * h + 1], zp0, zp1, sky_depth));
                 words[q][h] = lo | (hi << 16);
             }
@@ -431,6 +440,7 @@ struct UpsLoads {
     float4v wd[kRounds];
     typename AO::type4 wa[kRounds];
     uint4v hraw[kPasses][2];            // FINAL: four raw depth texels, undecoded (load_raw_quad)
+    uint4v araw[2];                     // FINAL, from-raw window: the eight raw texels over an apron item's four LowDepth1 texels
     float4v hd32[kPasses][2];
     // four AO texels as ONE integer: a <4 x i8> value is split into bytes where it is loaded, which puts the wait for it there
     typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type ao_bits_t;
@@ -503,6 +513,70 @@ __device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, 
     }
     __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
     ups_issue_hoisted<AOFMT, FINAL, TILE_H, true, RAW_F32>(a, hi, tile, frame, L);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The from-raw window of the full-resolution pass (MEAO_X_LOWDEPTH_FROM_RAW): LowDepth1[X, Y] = Linearize(raw[2X, 2Y]) before the f16
+// store (DS1:37-48, 64-70), so a tile that lies inside the frame reads no LowDepth1 at all.  Interior texels (32 x kLowH): from the
+// tile's own hi-res operands (hi_depth_words' `even`).  Apron (3 texels all round): 2 * kRawH + 48 items of four texels -- the
+// row quads k = 0 and k = 9 of every window row, the quads 1..8 of the three rows above and below -- dealt to lanes 0..123 (91),
+// i.e. to the first two waves only: the other two skip the conversion with a scalar branch.
+template <int TILE_H>
+struct UpsApron {
+    typedef UpsTile<TILE_H> T;
+    static constexpr int kSide = 2 * T::kRawH, kItems = kSide + 6 * 8;
+    static_assert(kItems <= 128, "two waves");
+    // item t -> window row r, row quad k (window columns 4k - 1 .. 4k + 2)
+    // (bit selects, not ?: -- the compiler turns the nested conditionals into exec-masked branches)
+    static __device__ __forceinline__ void item(int t, int &r, int &k)
+    {
+        const int u = t - kSide, rr = u >> 3;
+        const int rows = ~(u >> 31);                                  // all ones for the items of the rows above and below
+        const int r_rows = rr + (((2 - rr) >> 31) & T::kLowH), k_rows = 1 + (u & 7);
+        const int r_side = t >> 1, k_side = (-(t & 1)) & 9;
+        r = (r_rows & rows) | (r_side & ~rows);
+        k = (k_rows & rows) | (k_side & ~rows);
+    }
+};
+
+template <bool FINAL, int TILE_H>
+__device__ __forceinline__ bool ups_tile_from_raw(const UpsampleArgs &a, int tile)
+{
+    if constexpr (!FINAL || !MEAO_X_LOWDEPTH_FROM_RAW) return false;
+    return MEAO_X_HOT_PATH_ONLY || (ups_tile_is_interior<FINAL, TILE_H>(a, tile) && (tile / a.tiles_x + 1) * TILE_H <= a.hh);
+}
+
+// Loads of a from-raw tile: the AO window (L2: the previous pass wrote it), the apron's raw texels (lines of the neighbouring
+// tiles' hi-res operands), the tile's own hi-res operands (HBM) -- in that order, vmcnt retires in issue order.
+template <int AOFMT, int TILE_H, bool RAW_F32>
+__device__ __forceinline__ void ups_issue_from_raw_loads(const UpsampleArgs &a, const HiDepthArgs *hi, int tile, int frame, UpsLoads<AOFMT, true, TILE_H> &L)
+{
+    const int tid = thread_index_opaque();
+    typedef UpsLoads<AOFMT, true, TILE_H> Loads;
+    typedef typename Loads::AO AO;
+    typedef typename AO::type ao_t;
+    const int HX0 = (tile % a.tiles_x) * kUpsTileW;
+    const int LX0 = HX0 >> 1, LY0 = ((tile / a.tiles_x) * TILE_H) >> 1;
+    const int lw = a.lw, lh = a.lh;
+    const ao_t *__restrict__ lo_ao = frame_ptr(static_cast<const ao_t *>(a.lo_ao), a.frame_stride, frame);
+#pragma unroll
+    for (int round = 0; round < Loads::kRounds; ++round) {
+        const int i = min(tid + round * kThreads, Loads::kItems - 1);
+        const int r = i / 10, k = i % 10;
+        const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
+        const uint32_t idx = static_cast<uint32_t>(cy * lw + (LX0 - 4 + 4 * k));
+        L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(lo_ao, idx * static_cast<uint32_t>(sizeof(ao_t))));
+    }
+    {   // every lane loads (lanes past the last item repeat it), so that the code is branch-free
+        int r, k;
+        UpsApron<TILE_H>::item(min(tid, UpsApron<TILE_H>::kItems - 1), r, k);
+        const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
+        const uint32_t at = static_cast<uint32_t>(2 * cy * a.hw + (HX0 - 8 + 8 * k));      // raw texel (2X, 2Y) of LowDepth1 texel (X, Y)
+        L.araw[0] = load_raw_quad<RAW_F32, false>(hi->raw[frame], hi->depth_format, at);
+        L.araw[1] = load_raw_quad<RAW_F32, false>(hi->raw[frame], hi->depth_format, at + 4u);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, apron, hi-res
+    ups_issue_hoisted<AOFMT, true, TILE_H, true, RAW_F32>(a, hi, tile, frame, L);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -584,13 +658,56 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     auto &hoist_ha = L.ha;
     const bool hoist_ok = MEAO_X_HOT_PATH_ONLY || a.vec_ok != 0;
     // interior tile, 16-byte loads everywhere, no second AO input: window loads first (ups_issue_interior_loads)
-    const bool window_first = !NESTED && (MEAO_X_HOT_PATH_ONLY || ups_tile_is_interior<FINAL, TILE_H>(a, tile));
-    if (hoist_ok && !window_first) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false, RAW_F32>(a, hi, tile, frame, L);
+    // full-resolution pass, tile inside the frame: no LowDepth1 read at all (ups_issue_from_raw_loads)
+    const bool from_raw = !NESTED && ups_tile_from_raw<FINAL, TILE_H>(a, tile);
+    const bool window_first = !NESTED && !from_raw && (MEAO_X_HOT_PATH_ONLY || ups_tile_is_interior<FINAL, TILE_H>(a, tile));
+    if (hoist_ok && !window_first && !from_raw) ups_issue_hoisted<AOFMT, FINAL, TILE_H, false, RAW_F32>(a, hi, tile, frame, L);
 
     // ---- PrefetchData (UPS:54-72): raw window = virtual low-res texels
     // [LX0-3, LX0+34] x [LY0-3, LY0+kLowH+2], clamp addressing per texel.
     const bool interior_x = ((lw & 3) == 0) && LX0 >= 4 && LX0 + 35 < lw;
-    if (window_first) {
+    if (from_raw) {
+        if constexpr (FINAL && !NESTED) {
+            constexpr int kItems = Loads::kItems, kRounds = Loads::kRounds;
+            ups_issue_from_raw_loads<AOFMT, TILE_H, RAW_F32>(a, hi, tile, frame, L);
+            auto &wa = L.wa;
+#pragma unroll
+            for (int round = 0; round < kRounds; ++round) {
+                typedef typename std::conditional<sizeof(typename AO::type4) == 4, uint32_t, uint64_t>::type bits_t;
+                asm volatile("" : : "v"(__builtin_bit_cast(bits_t, wa[round])));      // (as below: keeps the partial round's loads in front)
+                const int i = tid + round * kThreads;
+                if (i < kItems) {
+                    const int r = i / 10, k = i % 10;
+                    const float av[4] = {AO::decode(wa[round].x), AO::decode(wa[round].y), AO::decode(wa[round].z), AO::decode(wa[round].w)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 4 * k + e - 1;
+                        if (c >= 0 && c < T::kRawW) s_ao[r * T::kRawPitch + c] = av[e];
+                    }
+                }
+            }
+            // the apron of LoResDB: Linearize of the raw texels under it.  Every LowDepth1 texel of a frame that is not hostile has a
+            // nice denominator (that is what the flag means), so the exact sequence is what the downsample pass stored.
+            asm volatile("" : : "v"(L.araw[0]), "v"(L.araw[1]));
+            if (tid < UpsApron<TILE_H>::kItems) {
+                int r, k;
+                UpsApron<TILE_H>::item(tid, r, k);
+                float q0[4], q1[4];
+                decode_raw_quad<RAW_F32>(L.araw[0], raw_format, q0);
+                decode_raw_quad<RAW_F32>(L.araw[1], raw_format, q1);
+                const float rawv[4] = {q0[0], q0[2], q1[0], q1[2]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * k + e - 1;
+                    if (c >= 0 && c < T::kRawW) {
+                        const float d = linearize<DIV>(rawv[e], zp0, zp1, sky_depth);        // DS1:40-45, 64-70
+                        if (dep_kept(r, c)) dep_at(r, c) = d;
+                        s_inv[r * T::kRawPitch + c] = rcp_strict<DIV>(d);                   // UPS:67
+                    }
+                }
+            }
+        }
+    } else if (window_first) {
         constexpr int kItems = Loads::kItems, kRounds = Loads::kRounds;
         if constexpr (!NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H, RAW_F32>(a, hi, tile, frame, L);
         auto &wd = L.wd;
@@ -686,7 +803,20 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 for (int pass = 0; pass < kPasses; ++pass)
 #pragma unroll
                     for (int f = 0; f < 2; ++f) rawq[2 * pass + f] = hoist_hraw[pass][f];
-                lane_clean = hi_depth_words<RTNE, DIV, RAW_F32, 2 * kPasses>(rawq, raw_format, zp0, zp1, sky_depth, hd_words);
+                float even[2 * kPasses][2];
+                lane_clean = hi_depth_words<RTNE, DIV, RAW_F32, 2 * kPasses>(rawq, raw_format, zp0, zp1, sky_depth, hd_words, even);
+                if (from_raw) {
+                    // the interior of the LoResDB window: the lane's own even-even texels before the f16 store
+                    const int r0 = 3 + (tid >> 4), c = 3 + 2 * (tid & 15);
+#pragma unroll
+                    for (int pass = 0; pass < kPasses; ++pass)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float d = even[2 * pass][j];
+                            dep_at(r0 + 16 * pass, c + j) = d;
+                            s_inv[(r0 + 16 * pass) * T::kRawPitch + c + j] = rcp_strict<DIV>(d);   // UPS:67
+                        }
+                }
             }
         }
     };
