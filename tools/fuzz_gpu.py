@@ -61,6 +61,9 @@ for k in range(count):
         from miniengineao_amd import _lib
         ao.debug_set(_lib.DEBUG_BLEND_TALL_MIN_TILES, 1)
         ao.debug_set(_lib.DEBUG_NESTED_MAX_TILES, 0)
+    if k % 5 == 2:          # a fifth: the full-resolution pass on 64 x 64 tiles whatever the size (calls with many tiles take them by default)
+        from miniengineao_amd import _lib
+        ao.debug_set(_lib.DEBUG_FINAL_SMALL_MAX_TILES, 0)
     outs = ao.render_batch([depth, depth])
     ok = same(outs[0], want["result"]) and same(outs[1], want["result"])
     for i in H.valid_debug_ids(s.num_levels, s.hq_levels):
