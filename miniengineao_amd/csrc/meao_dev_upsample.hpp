@@ -447,6 +447,9 @@ struct UpsLoads {
     ao_bits_t ha[kPasses][2];
 };
 
+// i / 10 for 0 <= i < 1024 (the window items: 10 row quads per row) as one multiply and a shift
+__device__ __forceinline__ int tenth(int i) { return static_cast<int>((static_cast<uint32_t>(i) * 205u) >> 11); }
+
 template <bool FINAL, int TILE_H>
 __device__ __forceinline__ bool ups_tile_is_interior(const UpsampleArgs &a, int tile)
 {
@@ -488,11 +491,38 @@ __device__ __forceinline__ void ups_issue_hoisted(const UpsampleArgs &a, const H
         }
 }
 
+// The same for a tile that lies inside the frame: no clamps, one 24-bit multiply -- the rows of a lane are its first one plus
+// multiples of the level's width that are uniform (scalar).
+template <int AOFMT, bool FINAL, int TILE_H, bool RAW_F32>
+__device__ __forceinline__ void ups_issue_hoisted_inside(const UpsampleArgs &a, const HiDepthArgs *hi, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
+{
+    const int tid = thread_index_opaque();
+    typedef typename AoTexel<AOFMT>::type ao_t;
+    const int HX0 = (tile % a.tiles_x) * kUpsTileW, HY0 = (tile / a.tiles_x) * TILE_H;
+    const uint32_t hw = static_cast<uint32_t>(a.hw);
+    const uint32_t first = __umul24(static_cast<uint32_t>(HY0 + 2 * (tid >> 4)), hw) + static_cast<uint32_t>(HX0 + 4 * (tid & 15));    // rows, widths < 2^24
+#pragma unroll
+    for (int pass = 0; pass < TILE_H / 32; ++pass)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const uint32_t hrow = first + static_cast<uint32_t>(32 * pass + f) * hw;
+            if constexpr (FINAL) {
+                L.hraw[pass][f] = load_raw_quad<RAW_F32>(hi->raw[frame], hi->depth_format, hrow);
+            } else {
+                L.hd32[pass][f] = *reinterpret_cast<const float4v *>(at_byte_offset(
+                    frame_ptr(static_cast<const float *>(a.hi_depth), a.frame_stride, frame), hrow * 4u));
+                L.ha[pass][f] = *reinterpret_cast<const typename UpsLoads<AOFMT, FINAL, TILE_H>::ao_bits_t *>(at_byte_offset(
+                    frame_ptr(static_cast<const ao_t *>(a.hi_ao), a.frame_stride, frame), hrow * static_cast<uint32_t>(sizeof(ao_t))));
+            }
+        }
+}
+
 // All loads of an interior tile: window first, hi-res operands behind them.  The window comes from L2 (written by the
 // previous pass), the hi-res operands of the final pass from HBM; vmcnt retires loads in issue order, so with the hi-res
 // loads in front the window wait would last an HBM latency.
 template <int AOFMT, bool FINAL, int TILE_H, bool RAW_F32>
-__device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, const HiDepthArgs *hi, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L)
+__device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, const HiDepthArgs *hi, int tile, int frame, UpsLoads<AOFMT, FINAL, TILE_H> &L,
+                                                         bool inside)
 {
     const int tid = thread_index_opaque();
     typedef UpsLoads<AOFMT, FINAL, TILE_H> Loads;
@@ -505,14 +535,15 @@ __device__ __forceinline__ void ups_issue_interior_loads(const UpsampleArgs &a, 
 #pragma unroll
     for (int round = 0; round < Loads::kRounds; ++round) {
         const int i = min(tid + round * kThreads, Loads::kItems - 1);
-        const int r = i / 10, k = i % 10;
+        const int r = tenth(i), k = i - 10 * r;
         const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
         const uint32_t idx = static_cast<uint32_t>(cy * lw + (LX0 - 4 + 4 * k));
         L.wd[round] = *reinterpret_cast<const float4v *>(at_byte_offset(lo_depth, idx * 4u));
         L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(lo_ao, idx * static_cast<uint32_t>(sizeof(ao_t))));
     }
     __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, then hi-res
-    ups_issue_hoisted<AOFMT, FINAL, TILE_H, true, RAW_F32>(a, hi, tile, frame, L);
+    if (inside) ups_issue_hoisted_inside<AOFMT, FINAL, TILE_H, RAW_F32>(a, hi, tile, frame, L);      // (wave-uniform; the same loads either way)
+    else ups_issue_hoisted<AOFMT, FINAL, TILE_H, true, RAW_F32>(a, hi, tile, frame, L);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -549,7 +580,8 @@ __device__ __forceinline__ bool ups_tile_from_raw(const UpsampleArgs &a, int til
 // Loads of a from-raw tile: the AO window (L2: the previous pass wrote it), the apron's raw texels (lines of the neighbouring
 // tiles' hi-res operands), the tile's own hi-res operands (HBM) -- in that order, vmcnt retires in issue order.
 template <int AOFMT, int TILE_H, bool RAW_F32>
-__device__ __forceinline__ void ups_issue_from_raw_loads(const UpsampleArgs &a, const HiDepthArgs *hi, int tile, int frame, UpsLoads<AOFMT, true, TILE_H> &L)
+__device__ __forceinline__ void ups_issue_from_raw_loads(const UpsampleArgs &a, const HiDepthArgs *hi, int tile, int frame, UpsLoads<AOFMT, true, TILE_H> &L,
+                                                         int apron_r, int apron_k)
 {
     const int tid = thread_index_opaque();
     typedef UpsLoads<AOFMT, true, TILE_H> Loads;
@@ -562,21 +594,19 @@ __device__ __forceinline__ void ups_issue_from_raw_loads(const UpsampleArgs &a, 
 #pragma unroll
     for (int round = 0; round < Loads::kRounds; ++round) {
         const int i = min(tid + round * kThreads, Loads::kItems - 1);
-        const int r = i / 10, k = i % 10;
+        const int r = tenth(i), k = i - 10 * r;
         const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
         const uint32_t idx = static_cast<uint32_t>(cy * lw + (LX0 - 4 + 4 * k));
         L.wa[round] = *reinterpret_cast<const typename AO::type4 *>(at_byte_offset(lo_ao, idx * static_cast<uint32_t>(sizeof(ao_t))));
     }
     {   // every lane loads (lanes past the last item repeat it), so that the code is branch-free
-        int r, k;
-        UpsApron<TILE_H>::item(min(tid, UpsApron<TILE_H>::kItems - 1), r, k);
-        const int cy = clampi(LY0 - 3 + r, 0, lh - 1);
-        const uint32_t at = static_cast<uint32_t>(2 * cy * a.hw + (HX0 - 8 + 8 * k));      // raw texel (2X, 2Y) of LowDepth1 texel (X, Y)
+        const int cy = clampi(LY0 - 3 + apron_r, 0, lh - 1);
+        const uint32_t at = static_cast<uint32_t>(2 * cy * a.hw + (HX0 - 8 + 8 * apron_k));      // raw texel (2X, 2Y) of LowDepth1 texel (X, Y)
         L.araw[0] = load_raw_quad<RAW_F32, false>(hi->raw[frame], hi->depth_format, at);
         L.araw[1] = load_raw_quad<RAW_F32, false>(hi->raw[frame], hi->depth_format, at + 4u);
     }
     __builtin_amdgcn_sched_barrier(0);          // keep the issue order: window, apron, hi-res
-    ups_issue_hoisted<AOFMT, true, TILE_H, true, RAW_F32>(a, hi, tile, frame, L);
+    ups_issue_hoisted_inside<AOFMT, true, TILE_H, RAW_F32>(a, hi, tile, frame, L);      // a from-raw tile lies inside the frame
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -669,7 +699,11 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     if (from_raw) {
         if constexpr (FINAL && !NESTED) {
             constexpr int kItems = Loads::kItems, kRounds = Loads::kRounds;
-            ups_issue_from_raw_loads<AOFMT, TILE_H, RAW_F32>(a, hi, tile, frame, L);
+            static_assert(kItems <= 1024, "tenth()");
+            int apron_r, apron_k;      // the lane's apron item, computed once: pinned, or the compiler derives it again where it is converted
+            UpsApron<TILE_H>::item(min(tid, UpsApron<TILE_H>::kItems - 1), apron_r, apron_k);
+            asm volatile("" : "+v"(apron_r), "+v"(apron_k));
+            ups_issue_from_raw_loads<AOFMT, TILE_H, RAW_F32>(a, hi, tile, frame, L, apron_r, apron_k);
             auto &wa = L.wa;
 #pragma unroll
             for (int round = 0; round < kRounds; ++round) {
@@ -677,7 +711,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
                 asm volatile("" : : "v"(__builtin_bit_cast(bits_t, wa[round])));      // (as below: keeps the partial round's loads in front)
                 const int i = tid + round * kThreads;
                 if (i < kItems) {
-                    const int r = i / 10, k = i % 10;
+                    const int r = tenth(i), k = i - 10 * r;
                     const float av[4] = {AO::decode(wa[round].x), AO::decode(wa[round].y), AO::decode(wa[round].z), AO::decode(wa[round].w)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -690,8 +724,7 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             // nice denominator (that is what the flag means), so the exact sequence is what the downsample pass stored.
             asm volatile("" : : "v"(L.araw[0]), "v"(L.araw[1]));
             if (tid < UpsApron<TILE_H>::kItems) {
-                int r, k;
-                UpsApron<TILE_H>::item(tid, r, k);
+                const int r = apron_r, k = apron_k;
                 float q0[4], q1[4];
                 decode_raw_quad<RAW_F32>(L.araw[0], raw_format, q0);
                 decode_raw_quad<RAW_F32>(L.araw[1], raw_format, q1);
@@ -709,7 +742,8 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
         }
     } else if (window_first) {
         constexpr int kItems = Loads::kItems, kRounds = Loads::kRounds;
-        if constexpr (!NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H, RAW_F32>(a, hi, tile, frame, L);
+        if constexpr (!NESTED) ups_issue_interior_loads<AOFMT, FINAL, TILE_H, RAW_F32>(a, hi, tile, frame, L,
+                                                                                       MEAO_X_HOT_PATH_ONLY || (HX0 + kUpsTileW <= hw && HY0 + kTileH <= hh));
         auto &wd = L.wd;
         auto &wa = L.wa;
 #pragma unroll
@@ -725,7 +759,8 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
             // (storing the window as aligned 16-byte quads -- fourth column from the next lane by DPP -- removes the 4-way
             // bank conflicts of these scalar stores and changes nothing: profiles/r02_ab_v23_aligned_fill.jsonl)
             if (i < kItems) {
-                const int r = i / 10, k = i % 10;
+                static_assert(kItems <= 1024, "tenth()");
+                const int r = tenth(i), k = i - 10 * r;
                 const float dv[4] = {wd[round].x, wd[round].y, wd[round].z, wd[round].w};
                 float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if constexpr (!NESTED) {
