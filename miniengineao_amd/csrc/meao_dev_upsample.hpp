@@ -664,6 +664,9 @@ __device__ __forceinline__ void upsample_tile(const UpsampleArgs &a, float *smem
     const ao_t *__restrict__ lo_ao = frame_ptr(static_cast<const ao_t *>(a.lo_ao), a.frame_stride, frame);
     // main_premin*: LoResAO1 = min(LoResAO1, LoResAO2) (COMBINE_LOWER_RESOLUTIONS, UPS:58-60)
     const ao_t *__restrict__ lo_ao2 = a.lo_ao2 ? frame_ptr(static_cast<const ao_t *>(a.lo_ao2), a.frame_stride, frame) : nullptr;
+    // (SGPR operands: 207 of the 2 471 VALU instructions of the full-resolution pass's hot path read one.  Pinned in VGPRs instead
+    // -- an SGPR source halves the issue rate of a full-rate instruction in isolation -- the pass runs 183.9 vs 184.8 us, the fused
+    // last kernel 235.7 vs 233.8: nothing, in round 6 as in round 2; profiles/r06_ab_upsample_uniforms_in_vgprs.jsonl)
     const BlurConsts bk = {a.step_size, a.blur_tolerance};
     const BilateralConsts bilateral_k(a.upsample_tolerance, a.noise_filter_strength);
     // (fetched here, not where the bilateral phase first stores: a.dst[frame] is a scalar load whose latency would sit right
