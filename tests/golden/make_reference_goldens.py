@@ -67,11 +67,15 @@ CASES = {
     "ref_s2_1920x1080_f16_rtz_checksums": (1920, 1080, "S2", 51, synth.DEFAULT_CAMERA, dict(ao_format=1), True),
     "ref_s2_1920x1080_f16_rtne_convz_checksums": (1920, 1080, "S2", 52, synth.Camera(reversed_z=False),
                                                   dict(ao_format=1, f16_rounding=1, intensity=1.1), True),
+    # ... and at the metric's frame size in the canonical rounding (3 h 42 min of interpreter time,
+    # profiles/r06_reference_text_4k_f16_rtz_interpretation.log)
+    "ref_s2_3840x2160_f16_rtz_checksums": (3840, 2160, "S2", 61, synth.DEFAULT_CAMERA, dict(ao_format=1), True),
 }
 # BASELINE config 2's size (1080p, the atrium frame the bench uses for it): an hour of interpreter time; the fixture keeps the result
 # texture and a 64-bit order-sensitive checksum (tests.helpers.checksum) of each of the 17 buffers instead of the buffers (35 MB)
 CHECKSUM_CASES = ("ref_s3_1920x1080_sponza_r8_checksums", "ref_s2_3840x2160_r8_checksums",
-                  "ref_s2_1920x1080_f16_rtz_checksums", "ref_s2_1920x1080_f16_rtne_convz_checksums")
+                  "ref_s2_1920x1080_f16_rtz_checksums", "ref_s2_1920x1080_f16_rtne_convz_checksums",
+                  "ref_s2_3840x2160_f16_rtz_checksums")
 # fixtures whose UNORM8 / f16 encode-decode is NOT the oracle's (VERDICT r4 weak #1a)
 NUMPY_CODEC_CASES = ("ref_s2_150x86_r8_numpy_codecs", "ref_s2_134x70_f16_rtz_numpy_codecs")
 # frames with NaN texels: compare bit patterns with any-NaN == any-NaN (tests.helpers.nan_aware_equal)

@@ -294,7 +294,7 @@ def test_oracle_matches_the_reference_text_at_baseline_sizes(oracle, name):
 @pytest.mark.parametrize("name", R.CHECKSUM_CASES)
 def test_gpu_matches_the_reference_text_at_baseline_sizes(name, pipelined):
     """The default launch structures at BASELINE's sizes (config 2's 1080p atrium frame, the metric's 4K frame, and -- round 6 -- two
-    1080p frames with fp16 AO storage, BASELINE config 5's storage mode, in either f16 rounding; one call; and the pipelined path:
+    1080p frames with fp16 AO storage, BASELINE config 5's storage mode, in either f16 rounding, and a 4K frame in that mode; one call; and the pipelined path:
     the frame's downsample pass carried by the previous call's last kernel) against what the reference's text produced -- no
     oracle in the loop."""
     import torch
