@@ -1,3 +1,4 @@
+# (.ab_r05 = `git worktree add .ab_r05 3241d53 && (cd .ab_r05 && python -m miniengineao_amd.build)`: the round-5 HEAD with its own library; removed at the end of the round)
 # usage: bash profiles/r06_scripts/r06_ab_quick.sh <tag> [alternations=2]: correctness probe + alternating A/B of bench_passes (r05 worktree vs this tree)
 TAG=$1; N=${2:-2}
 mkdir -p gpurun_out
